@@ -1,0 +1,618 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator for the RIME hot path.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container, where the reference
+lives (read-only) at /root/reference; it imports the reference's Python on the
+CPU in float64, feeds it seeded synthetic inputs and writes inputs + outputs
+(+ gradients) as small .npz files next to this script.  Only those .npz data
+files travel to the GPU box; nothing here is imported by the product, the GPU
+tests, smoke() or bench.py.
+
+Import recipe: astropy / h5py are absent, so their
+top-level imports are satisfied with MagicMock modules; bayeslim/__init__.py is
+bypassed (calibration.py needs py>=3.11 syntax); eq2top never reaches astropy
+because TelescopeModel.conv_cache is pre-populated with our own (zen, az).
+
+Usage:  python tests/golden/make_golden.py            # regenerates every file
+"""
+import os
+import sys
+import types
+import importlib
+import importlib.machinery
+import warnings
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference/bayeslim'
+
+
+def bootstrap_reference():
+    sys.dont_write_bytecode = True
+    for n in ['astropy', 'astropy.units', 'astropy.constants', 'astropy.coordinates',
+              'astropy.time', 'astropy.cosmology', 'h5py']:
+        sys.modules[n] = MagicMock(name=n)
+    pkg = types.ModuleType('bayeslim')
+    pkg.__path__ = [REF]
+    pkg.__spec__ = importlib.machinery.ModuleSpec('bayeslim', None, is_package=True)
+    sys.modules['bayeslim'] = pkg
+    sys.modules['bayeslim.calibration'] = MagicMock()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        mods = {m: importlib.import_module('bayeslim.' + m) for m in
+                ['version', 'utils', 'special', 'linalg', 'fft', 'linear_model', 'paramdict',
+                 'dataset', 'cosmology', 'sph_harm', 'telescope_model', 'beam_model',
+                 'sky_model', 'io', 'rime_model']}
+    return types.SimpleNamespace(**mods)
+
+
+def npy(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrs.items()})
+    print('wrote %-28s %7.1f kB' % (name + '.npz', os.path.getsize(path) / 1e3))
+
+
+# ---------------------------------------------------------------------------
+# synthetic inputs (numpy only -- independent of both the reference and the build)
+# ---------------------------------------------------------------------------
+def random_dirs(rng, n, zen_max=120.0):
+    """uniform-on-sphere directions down to zen_max [deg]; returns zen, az in deg"""
+    cz = rng.uniform(np.cos(np.deg2rad(zen_max)), 1.0, n)
+    zen = np.rad2deg(np.arccos(cz))
+    az = rng.uniform(0.0, 360.0, n)
+    return zen, az
+
+
+def radec_to_zenaz(ra, dec, lst, lat):
+    """plain LST rotation (degrees in / out); az East of North"""
+    H = np.deg2rad(lst - ra)
+    d = np.deg2rad(dec)
+    p = np.deg2rad(lat)
+    x = -np.cos(d) * np.sin(H)
+    y = np.sin(d) * np.cos(p) - np.cos(d) * np.sin(p) * np.cos(H)
+    z = np.sin(d) * np.sin(p) + np.cos(d) * np.cos(p) * np.cos(H)
+    zen = np.rad2deg(np.arccos(np.clip(z, -1, 1)))
+    az = np.rad2deg(np.arctan2(x, y)) % 360.0
+    return zen, az
+
+
+def lst_of(jd):
+    return (100.0 + 360.0 * 1.00273790935 * (jd - 2459861.0)) % 360.0
+
+
+LAT = -30.72148
+
+
+# ---------------------------------------------------------------------------
+def gen_fringe_cases(ba):
+    rng = np.random.default_rng(1)
+    zen, az = random_dirs(rng, 150)
+    zen[0], az[0] = 0.0, 0.0                      # zenith: fringe == 1
+    blvecs = rng.normal(0, 60, (6, 3))
+    blvecs[:, 2] *= 0.02
+    blvecs[0] = 0.0                                # auto-correlation
+    blvecs[1] = [14.6, 0, 0]
+    for tag, freqs in [('uniform', np.linspace(120e6, 180e6, 7)),
+                       ('ragged', np.array([100e6, 101e6, 125.5e6, 180e6, 181.25e6]))]:
+        antpos = ba.utils.AntposDict([0, 1], np.array([[0., 0, 0], [14.6, 0, 0]]))
+        arr = ba.telescope_model.ArrayModel(antpos, freqs=torch.as_tensor(freqs), cache_s=False)
+        f1 = arr.gen_fringe(torch.as_tensor(blvecs), torch.as_tensor(zen), torch.as_tensor(az))
+        f2 = arr.gen_fringe(torch.as_tensor(blvecs), torch.as_tensor(zen), torch.as_tensor(az),
+                            conj=True)
+        save('fringe_' + tag, blvecs=blvecs, zen=zen, az=az, freqs=freqs, fringe=f1,
+             fringe_conj=f2)
+
+
+def gen_apply_beam_cases(ba):
+    rng = np.random.default_rng(2)
+    Nf, P = 4, 37
+    freqs = torch.linspace(120e6, 130e6, Nf)
+    bls = [(0, 1), (0, 2), (1, 2), (2, 2), (1, 0)]
+
+    def rnd(*shape, comp=False):
+        x = rng.normal(size=shape)
+        if comp:
+            x = x + 1j * rng.normal(size=shape)
+        return torch.as_tensor(x)
+
+    cases = {}
+    # 1pol power beam
+    cases['1pol_power'] = dict(beam=rnd(1, 1, 1, Nf, P).abs(), sky=rnd(1, 1, Nf, P),
+                               powerbeam=True, ant2beam=None)
+    # 1pol non-power, 3 models, complex antenna beams
+    cases['1pol_nonpower_3model'] = dict(beam=rnd(1, 1, 3, Nf, P, comp=True), sky=rnd(1, 1, Nf, P),
+                                         powerbeam=False, ant2beam={0: 0, 1: 1, 2: 2})
+    # 1pol non-power, 1 model, real beam
+    cases['1pol_nonpower_1model'] = dict(beam=rnd(1, 1, 1, Nf, P), sky=rnd(1, 1, Nf, P),
+                                         powerbeam=False, ant2beam=None)
+    # 1pol full stokes (Nvec = 2)
+    cases['1pol_nvec2'] = dict(beam=rnd(1, 2, 2, Nf, P, comp=True), sky=rnd(2, 2, Nf, P, comp=True),
+                               powerbeam=False, ant2beam={0: 0, 1: 1, 2: 0})
+    # 2pol power
+    cases['2pol_power'] = dict(beam=rnd(2, 1, 1, Nf, P).abs(), sky=rnd(1, 1, Nf, P),
+                               powerbeam=True, ant2beam=None)
+    # 4pol, 1 model and 3 models
+    cases['4pol_1model'] = dict(beam=rnd(2, 2, 1, Nf, P, comp=True), sky=rnd(2, 2, Nf, P, comp=True),
+                                powerbeam=False, ant2beam=None)
+    cases['4pol_3model'] = dict(beam=rnd(2, 2, 3, Nf, P, comp=True), sky=rnd(2, 2, Nf, P, comp=True),
+                                powerbeam=False, ant2beam={0: 0, 1: 1, 2: 2})
+    out = {}
+    for k, c in cases.items():
+        b = c['beam']
+        pb = ba.beam_model.PixelBeam(b.clone(), freqs, R=None if b.shape[2] == 1 else None,
+                                     ant2beam=c['ant2beam'] if c['ant2beam'] is None else None,
+                                     parameter=False, powerbeam=c['powerbeam'], pol='e') \
+            if c['ant2beam'] is None else None
+        if pb is None:
+            # ant2beam given: the constructor only installs the default SimpleIndex when
+            # ant2beam is None (beam_model.py:153-155), so set the attribute ourselves
+            pb = ba.beam_model.PixelBeam.__new__(ba.beam_model.PixelBeam)
+            ba.utils.Module.__init__(pb)
+            pb.params = b.clone()
+            pb.p0 = None
+            pb.device = b.device
+            pb.powerbeam = c['powerbeam']
+            pb.Npol, pb.Nvec, pb.Nmodel = b.shape[:3]
+            pb.freqs = freqs
+            pb.ant2beam = c['ant2beam']
+        psky = pb.apply_beam(b, bls, c['sky'])
+        out[k + '__beam'] = b
+        out[k + '__sky'] = c['sky']
+        out[k + '__psky'] = psky.contiguous()
+        out[k + '__powerbeam'] = np.array(c['powerbeam'])
+        a2b = c['ant2beam']
+        out[k + '__ant2beam'] = np.array([-1]) if a2b is None else np.array([a2b[a] for a in range(3)])
+    out['bls'] = np.array(bls)
+    save('apply_beam', **out)
+
+
+def gen_interp_cases(ba):
+    rng = np.random.default_rng(3)
+    theta_grid = torch.arange(0, 90.1, 1.0)
+    phi_grid = torch.arange(0, 360, 1.0)
+    # random samples kept clear of exact grid half-way ties (undefined argsort order)
+    zen = rng.uniform(0.02, 89.9, 120)
+    az = rng.uniform(0.0, 359.999, 120)
+    frac = (zen % 1.0)
+    zen = np.where(np.abs(frac - 0.5) < 0.02, zen + 0.1, zen)
+    frac = (az % 1.0)
+    az = np.where(np.abs(frac - 0.5) < 0.02, az + 0.1, az)
+    # edge samples: az wrap, on-node, beyond last zenith node, near zenith, first az cell
+    edge_zen = np.array([30.2, 45.0, 90.4, 0.3, 10.3, 89.7, 12.25, 0.0])
+    edge_az = np.array([359.6, 100.0, 12.3, 200.2, 0.2, 358.8, 0.0, 0.0])
+    zen = np.concatenate([zen, edge_zen])
+    az = np.concatenate([az, edge_az])
+    Npb = len(theta_grid) * len(phi_grid)
+    m = torch.as_tensor(rng.normal(size=(2, 3, Npb)))
+    out = dict(theta_grid=theta_grid, phi_grid=phi_grid, zen=zen, az=az, m=m)
+    for mode in ['nearest', 'linear', 'quadratic', 'cubic', 'linear,quadratic']:
+        zz, aa = zen, az
+        if mode in ('nearest', 'quadratic', 'linear,quadratic'):
+            pass
+        PI = ba.utils.PixInterp('rect', interp_mode=mode, theta_grid=theta_grid,
+                                phi_grid=phi_grid)
+        tz, ta = torch.as_tensor(zz), torch.as_tensor(aa)
+        inds, wgts = PI.get_interp(tz, ta)
+        mm = m.clone().requires_grad_(True)
+        y = PI.interp(mm, tz, ta)
+        g = torch.as_tensor(np.random.default_rng(33).normal(size=tuple(y.shape)))
+        (y * g).sum().backward()
+        key = mode.replace(',', '_')
+        out[key + '__inds'] = inds
+        out[key + '__wgts'] = wgts
+        out[key + '__out'] = y
+        out[key + '__gout'] = g
+        out[key + '__gm_nnz_idx'] = torch.nonzero(mm.grad.reshape(-1)).reshape(-1)
+        out[key + '__gm_nnz_val'] = mm.grad.reshape(-1)[torch.nonzero(mm.grad.reshape(-1)).reshape(-1)]
+    # coarse grid as well (2.5 deg), linear only
+    tg2, pg2 = torch.arange(0, 92.5, 2.5), torch.arange(0, 360, 5.0)
+    PI = ba.utils.PixInterp('rect', interp_mode='linear', theta_grid=tg2, phi_grid=pg2)
+    inds, wgts = PI.get_interp(torch.as_tensor(zen), torch.as_tensor(az))
+    out['coarse__theta_grid'] = tg2
+    out['coarse__phi_grid'] = pg2
+    out['coarse__inds'] = inds
+    out['coarse__wgts'] = wgts
+    # drop the dense m from the file: regenerate from seed in the test instead
+    del out['m']
+    out['m_seed'] = np.array([3])
+    save('interp_rect', **out)
+
+
+def gen_sph_cases(ba):
+    rng = np.random.default_rng(4)
+    lmax = 8
+    l, m = ba.sph_harm.gen_lm(lmax)
+    theta = np.rad2deg(np.arccos(rng.uniform(-1, 1, 50)))
+    phi = rng.uniform(0, 360, 50)
+    out = dict(lmax=np.array(lmax), l=l, m=m, theta=theta, phi=phi)
+    for real in (False, True):
+        Y, norm, mult = ba.sph_harm.gen_sph2pix(theta * ba.utils.D2R, phi * ba.utils.D2R, l, m,
+                                                high_prec=False, real=real)
+        k = 'real' if real else 'comp'
+        out['Ylm_' + k] = Y
+        out['alm_mult_' + k] = mult
+    # separable grid
+    tg = np.linspace(1.0, 89.0, 9)
+    pg = np.linspace(0.0, 350.0, 12)
+    (T, Ph), _, mult = ba.sph_harm.gen_sph2pix(tg * ba.utils.D2R, pg * ba.utils.D2R, l, m,
+                                               separable=True, high_prec=False)
+    out.update(theta_grid=tg, phi_grid=pg, Theta=T, Phi=Ph, alm_mult_sep=mult)
+    # forward_alm, full: complex params (3, Ncoeff)
+    a = torch.as_tensor(rng.normal(size=(3, len(l))) + 1j * rng.normal(size=(3, len(l))))
+    a[:, m == 0] = a[:, m == 0].real + 0j
+    A = ba.sph_harm.AlmModel(l, m, real_output=True)
+    A.setup_Ylm(theta, phi, Ylm=out['Ylm_comp'], alm_mult=out['alm_mult_comp'])
+    ar = torch.view_as_real(a).clone().requires_grad_(True)
+    y = A.forward_alm(ar)
+    g = torch.as_tensor(rng.normal(size=tuple(y.shape)))
+    (y * g).sum().backward()
+    out.update(alm=a, fwd_full=y, gout_full=g, galm_full=ar.grad)
+    # separable
+    A2 = ba.sph_harm.AlmModel(l, m, real_output=True)
+    A2.setup_Ylm(tg, pg, Ylm=(T, Ph), alm_mult=mult, separable=True)
+    ar2 = torch.view_as_real(a).clone().requires_grad_(True)
+    y2 = A2.forward_alm(ar2)
+    g2 = torch.as_tensor(rng.normal(size=tuple(y2.shape)))
+    (y2 * g2).sum().backward()
+    out.update(fwd_sep=y2, gout_sep=g2, galm_sep=ar2.grad)
+    # complex output (real_output False)
+    A3 = ba.sph_harm.AlmModel(l, m, real_output=False)
+    A3.setup_Ylm(theta, phi, Ylm=out['Ylm_comp'], alm_mult=out['alm_mult_comp'])
+    out['fwd_full_complex'] = A3.forward_alm(a)
+    save('sph_harm', **out)
+
+
+def gen_sky_beam_response_cases(ba):
+    rng = np.random.default_rng(5)
+    freqs = torch.linspace(120e6, 180e6, 6)
+    out = dict(freqs=freqs)
+    # PointSkyResponse powerlaw
+    params = torch.as_tensor(np.stack([rng.uniform(0.5, 3, 9), rng.uniform(-3, -1, 9)])[None, None])
+    R = ba.sky_model.PointSkyResponse(freqs, freq_mode='powerlaw', f0=freqs[0])
+    out['point_params'] = params
+    out['point_powerlaw'] = R(params)
+    Rl = ba.sky_model.PointSkyResponse(freqs, freq_mode='powerlaw', f0=freqs[2], log=True)
+    out['point_powerlaw_log'] = Rl(params)
+    out['point_f0_log'] = freqs[2]
+    # Airy / Gauss beams
+    zen, az = random_dirs(rng, 40, zen_max=100)
+    out.update(zen=zen, az=az)
+    tz, ta = torch.as_tensor(zen), torch.as_tensor(az)
+    RA = ba.beam_model.AiryResponse(powerbeam=True)
+    out['airy_D14'] = RA(torch.ones(1, 1, 1, 1, 1) * 14.0, tz, ta, freqs)
+    RA2 = ba.beam_model.AiryResponse(powerbeam=False)
+    out['airy_asym'] = RA2(torch.as_tensor([12.0, 15.0]).reshape(1, 1, 1, 1, 2), tz, ta, freqs)
+    RG = ba.beam_model.GaussResponse(powerbeam=True)
+    gp = torch.as_tensor(rng.uniform(0.2, 0.5, (1, 1, 1, 6, 2)))
+    out['gauss_params'] = gp
+    out['gauss'] = RG(gp, tz, ta, freqs)
+    # PixelResponse.forward variants on a tiny rect grid
+    tg, pg = torch.arange(0, 91, 10.0), torch.arange(0, 360, 30.0)
+    Npb = len(tg) * len(pg)
+    p = torch.as_tensor(rng.normal(size=(1, 1, 1, 6, Npb)))
+    b0 = torch.as_tensor(rng.uniform(0, 1, size=(1, 1, 1, 6, Npb)))
+    out.update(pr_theta_grid=tg, pr_phi_grid=pg, pr_params=p, pr_beam0=b0)
+    for tag, kw in [('abs', dict()), ('log', dict(log=True)), ('beam0', dict(beam0=b0.clone())),
+                    ('normpix', dict(norm_pix=3)), ('nonpower', dict(powerbeam=False))]:
+        Rp = ba.beam_model.PixelResponse(freqs, 'rect', interp_mode='linear', theta_grid=tg,
+                                         phi_grid=pg, **kw)
+        out['pr_fwd_' + tag] = Rp.forward(p.clone())
+    save('responses', **out)
+
+
+# ---------------------------------------------------------------------------
+# full RIME cases
+# ---------------------------------------------------------------------------
+def hex_array(ba, N, freqs, D=14.6, extra=None):
+    ants, vecs = ba.utils._make_hex(N, D=D)
+    if extra is not None:
+        ants = list(ants) + [len(ants)]
+        vecs = np.vstack([vecs, extra])
+    antpos = ba.utils.AntposDict(ants, vecs)
+    arr = ba.telescope_model.ArrayModel(antpos, freqs=freqs, cache_s=True, redtol=1.0)
+    return arr
+
+
+def airy_pixbeam(ba, freqs, D=14.0, dtheta=5.0, dphi=10.0, interp_mode='linear', parameter=True):
+    theta = torch.arange(0, 90 + dtheta / 2, dtheta)
+    phi = torch.arange(0, 360, dphi)
+    b_phi, b_theta = torch.meshgrid(phi, theta, indexing='xy')
+    b_phi, b_theta = b_phi.ravel(), b_theta.ravel()
+    airy = ba.beam_model.airy_disk(b_theta * ba.utils.D2R, b_phi * ba.utils.D2R, D, freqs,
+                                   square=True)
+    R = ba.beam_model.PixelResponse(freqs, 'rect', interp_mode=interp_mode,
+                                    theta=b_theta, phi=b_phi, theta_grid=theta, phi_grid=phi,
+                                    freq_mode='channel', powerbeam=True, realbeam=True)
+    p = torch.as_tensor(airy[None, None, None, :, :]).clone()
+    beam = ba.beam_model.PixelBeam(p, freqs, R=R, pol='e', powerbeam=True, fov=180,
+                                   parameter=parameter)
+    return beam, theta, phi
+
+
+def fill_eq2top(telescope, sky_name, ra, dec, times):
+    zas = []
+    for t in times:
+        zen, az = radec_to_zenaz(npy(ra), npy(dec), lst_of(float(t)), LAT)
+        telescope.conv_cache[(sky_name, len(ra), float(t))] = torch.stack(
+            [torch.as_tensor(zen), torch.as_tensor(az)])
+        zas.append(np.stack([zen, az]))
+    return np.stack(zas)
+
+
+def run_rime(ba, rime, params):
+    """forward + backward of loss = sum(w * |V|^2)-like functional with fixed random weights"""
+    vd = rime()
+    V = vd.data
+    rng = np.random.default_rng(77)
+    gw = torch.as_tensor(rng.normal(size=tuple(V.shape)) + 1j * rng.normal(size=tuple(V.shape)))
+    loss = (V * gw.conj()).real.sum()
+    for p in params:
+        if p.grad is not None:
+            p.grad = None
+    loss.backward()
+    return V.detach(), gw, [p.grad.detach().clone() for p in params]
+
+
+def gen_rime_c1(ba):
+    """config 1: 7-antenna hex, 10 point sources, 8 freqs, 2 times (CPU plumbing case)"""
+    freqs = torch.linspace(120e6, 130e6, 8)
+    times = np.array([2459861.0, 2459861.0 + 10.0 / 1440])
+    arr = hex_array(ba, 2, freqs)
+    tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+    Nsrc = 10
+    R = ba.sky_model.PointSkyResponse(freqs, freq_mode='powerlaw', f0=freqs[0])
+    rng = np.random.default_rng(10)
+    params = torch.ones(1, 1, 2, Nsrc)
+    params[..., 0, :] = torch.as_tensor(rng.uniform(0.5, 2.0, Nsrc))
+    params[..., 1, :] = -2.2
+    ra = torch.as_tensor(lst_of(times[0]) + rng.uniform(-40, 40, Nsrc))
+    dec = torch.as_tensor(LAT + rng.uniform(-35, 35, Nsrc))
+    angs = torch.stack([ra, dec])
+    sky = ba.sky_model.PointSky(params.clone(), angs, R=R, parameter=True, name='ptsky')
+    beam = ba.beam_model.PixelBeam(torch.ones(1, 1, 1, 1, 1) * 14.0, freqs,
+                                   R=ba.beam_model.AiryResponse(powerbeam=True), pol='e',
+                                   powerbeam=True, fov=180, parameter=False)
+    sim_bls = arr.get_bls(uniq_bls=False, keep_autos=False)
+    rime = ba.rime_model.RIME(sky, tel, beam, arr, sim_bls, times, freqs)
+    zenaz = fill_eq2top(tel, sky.name, ra, dec, times)
+    V, gw, grads = run_rime(ba, rime, [sky.params])
+    save('rime_c1', freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(arr.ants),
+         sim_bls=np.array(sim_bls), sky_params=params, ra=ra, dec=dec, zenaz=zenaz,
+         vis=V, gvis=gw, g_sky_params=grads[0], airy_D=np.array(14.0))
+
+
+def gen_rime_c2_mini(ba):
+    """mini config 2: hex-19 (171 bl), diffuse pixel sky, rect-linear interpolated PixelBeam,
+    fwd + grads wrt sky pixels and beam map; time-minibatched == unbatched; data_bls inflation"""
+    Nf = 8
+    freqs = torch.linspace(120e6, 180e6, Nf)
+    times = 2459861.0 + np.arange(3) * 10.0 / 1440
+    arr = hex_array(ba, 3, freqs)
+    tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+    rng = np.random.default_rng(20)
+    Npix = 600
+    # quasi-uniform sky directions (Fibonacci lattice) cut at dec < 59.27852 like tests/test_sky.py
+    k = np.arange(Npix) + 0.5
+    dec = np.rad2deg(np.arcsin(1 - 2 * k / Npix))
+    ra = (k * 137.50776405) % 360.0
+    keep = dec < 59.27852
+    ra, dec = torch.as_tensor(ra[keep]), torch.as_tensor(dec[keep])
+    px_area = 4 * np.pi / Npix
+    Rs = ba.sky_model.PixelSkyResponse(freqs, cosmo=object())
+    sp = torch.as_tensor(rng.normal(size=(1, 1, Nf, len(ra))))
+    sky = ba.sky_model.PixelSky(sp.clone(), torch.stack([ra, dec]), px_area, R=Rs,
+                                parameter=True, name='pixsky')
+    beam, tg, pg = airy_pixbeam(ba, freqs, parameter=True)
+    sim_bls = arr.get_bls(uniq_bls=False, keep_autos=False)
+    rime = ba.rime_model.RIME(sky, tel, beam, arr, sim_bls, times, freqs)
+    zenaz = fill_eq2top(tel, sky.name, ra, dec, times)
+    V, gw, grads = run_rime(ba, rime, [sky.params, beam.params])
+    # minibatched over time: must equal unbatched (tests/test_rime.py:41-51)
+    rime.setup_sim_times(ba.utils.split_into_groups(times, Nelem=2))
+    with torch.no_grad():
+        Vb = rime.run_batches().data
+    assert (Vb - V).abs().max() < 1e-10
+    # redundant inflation: simulate unique bls only, inflate to all data_bls grouped by redundancy
+    uniq = arr.get_bls(uniq_bls=True, keep_autos=False)
+    data_bls = arr.get_bls(uniq_bls=False, keep_autos=False)
+    rime2 = ba.rime_model.RIME(sky, tel, beam, arr, uniq, times, freqs, data_bls=data_bls)
+    with torch.no_grad():
+        V2 = rime2().data
+    save('rime_c2_mini', freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(arr.ants),
+         sim_bls=np.array(sim_bls), ra=ra, dec=dec, zenaz=zenaz, px_area=np.array(px_area),
+         sky_params=sp, beam_params=beam.params.detach(), theta_grid=tg, phi_grid=pg,
+         vis=V, gvis=gw, g_sky_params=grads[0], g_beam_params=grads[1],
+         uniq_bls=np.array(uniq), data_bls=np.array(rime2.data_bls),
+         sim2data=rime2._sim2data[0], vis_inflated=V2)
+
+
+def gen_rime_c3_mini(ba):
+    """mini config 3: a_lm sky (AlmModel, lmax 6) + YlmResponse beam (interpolate mode, rect grid)"""
+    Nf = 6
+    freqs = torch.linspace(120e6, 180e6, Nf)
+    times = 2459861.0 + np.arange(2) * 10.0 / 1440
+    arr = hex_array(ba, 2, freqs)
+    tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+    rng = np.random.default_rng(30)
+    Npix = 400
+    k = np.arange(Npix) + 0.5
+    dec = np.rad2deg(np.arcsin(1 - 2 * k / Npix))
+    ra = (k * 137.50776405) % 360.0
+    ra_t, dec_t = torch.as_tensor(ra), torch.as_tensor(dec)
+    # sky a_lm
+    lmax = 6
+    l, m = ba.sph_harm.gen_lm(lmax)
+    Ncoeff = len(l)
+    colat = 90.0 - dec
+    Ysky, _, mult = ba.sph_harm.gen_sph2pix(colat * ba.utils.D2R, ra * ba.utils.D2R, l, m,
+                                            high_prec=False)
+    A = ba.sph_harm.AlmModel(l, m, real_output=True)
+    A.setup_Ylm(colat, ra, Ylm=Ysky, alm_mult=mult)
+    a = rng.normal(size=(1, 1, Nf, Ncoeff)) + 1j * rng.normal(size=(1, 1, Nf, Ncoeff))
+    a /= (1.0 + l)
+    a[..., m == 0] = a[..., m == 0].real
+    sp = torch.view_as_real(torch.as_tensor(a)).clone()
+    Rs = ba.sky_model.PixelSkyResponse(freqs, spatial_mode='alm', spat_LM=A, comp_params=False,
+                                       cosmo=object())
+    px_area = 4 * np.pi / Npix
+    sky = ba.sky_model.PixelSky(sp.clone(), torch.stack([ra_t, dec_t]), px_area, R=Rs,
+                                parameter=True, name='almsky')
+    # beam a_lm on a rect grid, interpolate mode
+    bl_, bm_ = ba.sph_harm.gen_lm(4)
+    tg = torch.arange(0, 91, 5.0)
+    pg = torch.arange(0, 360, 10.0)
+    b_phi, b_theta = torch.meshgrid(pg, tg, indexing='xy')
+    b_phi, b_theta = b_phi.ravel(), b_theta.ravel()
+    Yb, _, bmult = ba.sph_harm.gen_sph2pix(npy(b_theta) * ba.utils.D2R, npy(b_phi) * ba.utils.D2R,
+                                           bl_, bm_, high_prec=False)
+    RB = ba.beam_model.YlmResponse(bl_, bm_, freqs, pixtype='rect', mode='interpolate',
+                                   interp_mode='linear', theta=b_theta, phi=b_phi,
+                                   theta_grid=tg, phi_grid=pg, powerbeam=True, comp_params=True)
+    RB.set_Ylm(Yb, (b_theta, b_phi), alm_mult=bmult)
+    bp = rng.normal(size=(1, 1, 1, Nf, len(bl_))) + 1j * rng.normal(size=(1, 1, 1, Nf, len(bl_)))
+    bp /= (1.0 + bl_) ** 2
+    bp[..., 0] += 3.0
+    bp[..., bm_ == 0] = bp[..., bm_ == 0].real
+    bpr = torch.view_as_real(torch.as_tensor(bp)).clone()
+    beam = ba.beam_model.PixelBeam(bpr.clone(), freqs, R=RB, pol='e', powerbeam=True, fov=180,
+                                   parameter=True)
+    sim_bls = arr.get_bls(uniq_bls=False, keep_autos=False)
+    rime = ba.rime_model.RIME(sky, tel, beam, arr, sim_bls, times, freqs)
+    zenaz = fill_eq2top(tel, sky.name, ra_t, dec_t, times)
+    V, gw, grads = run_rime(ba, rime, [sky.params, beam.params])
+    with torch.no_grad():
+        skymap = sky().data
+        RB.clear_beam_cache()
+        bcache = RB.set_beam_cache(beam.params.detach())
+    save('rime_c3_mini', freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(arr.ants),
+         sim_bls=np.array(sim_bls), ra=ra, dec=dec, zenaz=zenaz, px_area=np.array(px_area),
+         sky_l=l, sky_m=m, sky_params=sp, sky_map=skymap,
+         beam_l=bl_, beam_m=bm_, beam_params=bpr, beam_cache=bcache, theta_grid=tg, phi_grid=pg,
+         vis=V, gvis=gw, g_sky_params=grads[0], g_beam_params=grads[1])
+
+
+def gen_rime_c5_mini(ba):
+    """mini config 5: 4-pol (Npol = Nvec = 2) Jones PixelBeam (2 beam models), coherency sky from
+    Stokes2Coherency of (I, 0.1 I, 0.05 I) (no V, so the coherency stays real).  Beam and sky
+    are REAL-valued: under torch 2.10 the reference's PixInterp.interp raises on a complex map
+    (einsum of complex `nearest` with real `wgts`, utils.py:841) and apply_beam's einsum raises
+    on a real beam with a complex sky (beam_model.py:363), so the all-real case is the one the
+    reference can run end to end.  Complex psky is pinned by apply_beam.npz instead."""
+    Nf = 5
+    freqs = torch.linspace(120e6, 180e6, Nf)
+    times = 2459861.0 + np.arange(2) * 10.0 / 1440
+    arr = hex_array(ba, 2, freqs, extra=np.array([[120.0, -35.0, 1.5]]))
+    tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+    rng = np.random.default_rng(50)
+    Npix = 300
+    k = np.arange(Npix) + 0.5
+    dec = np.rad2deg(np.arcsin(1 - 2 * k / Npix))
+    ra = (k * 137.50776405) % 360.0
+    ra_t, dec_t = torch.as_tensor(ra), torch.as_tensor(dec)
+    I = torch.as_tensor(np.abs(rng.normal(size=(1, 1, Nf, Npix))))
+    S2C = ba.sky_model.Stokes2Coherency(
+        params=torch.as_tensor(np.array([0.1, 0.05]).reshape(2, 1, 1, 1)) * torch.ones(2, 1, Nf, Npix))
+    Rs = ba.sky_model.PixelSkyResponse(freqs, cosmo=object())
+    px_area = 4 * np.pi / Npix
+    stokes_sky = ba.sky_model.PixelSky(I.clone(), torch.stack([ra_t, dec_t]), px_area, R=Rs,
+                                       parameter=True, name='polsky')
+
+    class CohSky(ba.utils.Module):
+        """Stokes-I PixelSky followed by Stokes2Coherency, exposing the sky interface RIME uses"""
+        def __init__(self, sky, s2c):
+            super().__init__(name='cohsky')
+            self.sky = sky
+            self.s2c = s2c
+            self.device = sky.device
+
+        def forward(self, prior_cache=None, **kw):
+            return self.s2c(self.sky(prior_cache=prior_cache))
+
+    sky = CohSky(stokes_sky, S2C)
+    # Jones beam: airy amplitude x small random phase, per (pol, vec, model)
+    tg = torch.arange(0, 91, 5.0)
+    pg = torch.arange(0, 360, 10.0)
+    b_phi, b_theta = torch.meshgrid(pg, tg, indexing='xy')
+    b_phi, b_theta = b_phi.ravel(), b_theta.ravel()
+    airy = ba.beam_model.airy_disk(b_theta * ba.utils.D2R, b_phi * ba.utils.D2R, 14.0, freqs,
+                                   square=False)
+    amp = npy(airy)[None, None, None] * rng.uniform(0.8, 1.2, (2, 2, 2, 1, 1))
+    amp[0, 1] *= 0.1
+    amp[1, 0] *= 0.1
+    ph = rng.normal(0, 0.2, (2, 2, 2, Nf, amp.shape[-1]))
+    Jr = torch.as_tensor(amp * np.cos(ph)).clone()
+    R = ba.beam_model.PixelResponse(freqs, 'rect', interp_mode='linear', theta=b_theta, phi=b_phi,
+                                    theta_grid=tg, phi_grid=pg, freq_mode='channel',
+                                    powerbeam=False, realbeam=True, comp_params=False)
+    ants = arr.ants
+    ant2beam = {a: (i % 2) for i, a in enumerate(ants)}
+    beam = ba.beam_model.PixelBeam(Jr.clone(), freqs, R=R, ant2beam=ant2beam, powerbeam=False,
+                                   fov=180, parameter=True)
+    beam.ant2beam = ant2beam
+    sim_bls = arr.get_bls(uniq_bls=False, keep_autos=False)
+    rime = ba.rime_model.RIME(sky, tel, beam, arr, sim_bls, times, freqs)
+    zenaz = fill_eq2top(tel, 'polsky', ra_t, dec_t, times)
+    V, gw, grads = run_rime(ba, rime, [stokes_sky.params, beam.params])
+    save('rime_c5_mini', freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(arr.ants),
+         sim_bls=np.array(sim_bls), ra=ra, dec=dec, zenaz=zenaz, px_area=np.array(px_area),
+         stokes_I=I, frac_pol=np.array([0.1, 0.05]), beam_params=Jr,
+         ant2beam=np.array([ant2beam[a] for a in ants]), theta_grid=tg, phi_grid=pg,
+         vis=V, gvis=gw, g_sky_params=grads[0], g_beam_params=grads[1])
+
+
+def gen_prod_and_sum(ba):
+    """RIME._prod_and_sum in isolation (rime_model.py:391-440), with and without sim2data"""
+    rng = np.random.default_rng(60)
+    Nf, P = 5, 64
+    freqs = torch.linspace(120e6, 180e6, Nf)
+    arr = hex_array(ba, 2, freqs)
+    arr.cache_s = False
+    tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+    bls = [(0, 1), (0, 2), (1, 3), (2, 6)]
+    blvecs = arr.get_blvecs(bls)
+    zen, az = random_dirs(rng, P, zen_max=89)
+    beam_t = torch.as_tensor(np.abs(rng.normal(size=(1, 1, 1, Nf, P))))
+    sky_t = torch.as_tensor(rng.normal(size=(1, 1, Nf, P)))
+    pb = ba.beam_model.PixelBeam(torch.ones(1, 1, 1, Nf, 1), freqs, parameter=False, pol='e')
+    dummy_sky = ba.sky_model.PointSky(torch.ones(1, 1, Nf, 1), torch.zeros(2, 1),
+                                      R=ba.sky_model.PointSkyResponse(freqs, freq_mode='channel'),
+                                      parameter=False)
+    rime = ba.rime_model.RIME(dummy_sky, tel, pb, arr, bls, np.array([2459861.0]), freqs)
+    vis = []
+    rime._prod_and_sum(beam_t, sky_t, bls, blvecs, torch.as_tensor(zen), torch.as_tensor(az),
+                       vis, None, 0)
+    idx = torch.as_tensor([0, 0, 1, 2, 2, 2, 3])
+    rime._prod_and_sum(beam_t, sky_t, bls, blvecs, torch.as_tensor(zen), torch.as_tensor(az),
+                       vis, idx, 0)
+    save('prod_and_sum', freqs=freqs, blvecs=blvecs, zen=zen, az=az, beam=beam_t, sky=sky_t,
+         sum_sky=vis[0], sim2data_idx=idx, sum_sky_inflated=vis[1])
+
+
+def main():
+    torch.set_default_dtype(torch.float64)
+    torch.manual_seed(0)
+    ba = bootstrap_reference()
+    gen_fringe_cases(ba)
+    gen_apply_beam_cases(ba)
+    gen_interp_cases(ba)
+    gen_sph_cases(ba)
+    gen_sky_beam_response_cases(ba)
+    gen_prod_and_sum(ba)
+    gen_rime_c1(ba)
+    gen_rime_c2_mini(ba)
+    gen_rime_c3_mini(ba)
+    gen_rime_c5_mini(ba)
+
+
+if __name__ == '__main__':
+    main()
