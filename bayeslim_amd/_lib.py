@@ -1,0 +1,66 @@
+"""
+ctypes binding of librime_hip.so -- the C-ABI boundary declared in include/rime_hip.h.
+
+The library is built in-tree (bayeslim_amd/lib/librime_hip.so) by `__graft_entry__.build()`
+or `make -C bayeslim_amd/csrc`.  There is NO fallback: if the shared object is missing or a
+symbol cannot be resolved, importing this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'librime_hip.so')
+
+RIME_F32, RIME_F64 = 0, 1
+ERRORS = {-1: 'RIME_EINVAL (bad shape/flag/null pointer)', -2: 'RIME_EWORKSPACE (workspace too small)',
+          -3: 'RIME_ELAUNCH (kernel launch failed)', -4: 'RIME_EUNSUPPORTED'}
+
+_vp, _i, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# symbol -> (restype, argtypes); mirrors include/rime_hip.h one to one
+SIGNATURES = {
+    'rime_version': (ctypes.c_char_p, []),
+    'rime_last_error': (ctypes.c_char_p, []),
+    'rime_fringe_sum_workspace': (_sz, [_i] * 9),
+    'rime_fringe_sum_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _ip, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
+                                 _i, _d, _d, _d, _vp, _vp, _sz, _vp]),
+    'rime_fringe_sum_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _ip, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
+                                 _i, _d, _d, _d, _vp, _vp, _sz, _vp]),
+    'rime_interp_gather_fwd': (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    'rime_interp_scatter_bwd': (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'rime_alm2pix_fwd': (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'rime_alm2pix_bwd': (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+}
+
+
+class RimeLibraryError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RimeLibraryError(
+            "librime_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C bayeslim_amd/csrc`.  bayeslim_amd has no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(code, what):
+    if code != 0:
+        msg = ERRORS.get(code, 'unknown error %d' % code)
+        if code == -3:
+            msg += ': ' + lib.rime_last_error().decode()
+        raise RimeLibraryError('%s failed: %s' % (what, msg))
+
+
+def version():
+    return lib.rime_version().decode()

@@ -1,0 +1,247 @@
+"""
+torch.autograd.Function wrappers over the C-ABI of librime_hip.so (include/rime_hip.h).
+
+These are the only callers of the native library.  Every function requires CUDA (ROCm)
+tensors and raises otherwise -- there is no CPU path in the product.
+
+  fringe_sum   : vis = sum_pix psky * exp(+-2 pi i nu/c b.s)     rime_model.py:423-429 +
+                                                                 telescope_model.py:310-358
+  interp_gather: out[..., p] = sum_k w[p,k] m[..., inds[p,k]]    utils.py:815-861
+  alm2pix      : out = Re(alm @ Ylm)                             sph_harm.py:1342-1372
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, RIME_F32, RIME_F64
+
+TILE = 64        # pixel-axis padding granule required by the fringe kernels (rime::TP)
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("bayeslim_amd ops need tensors on the GPU (got device '%s'); "
+                               "there is no CPU implementation" % t.device)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _real_dtype(t):
+    if t.dtype in (torch.float32, torch.complex64):
+        return RIME_F32, torch.float32
+    if t.dtype in (torch.float64, torch.complex128):
+        return RIME_F64, torch.float64
+    raise TypeError('unsupported dtype %s' % t.dtype)
+
+
+def pad_to_tile(n):
+    return ((int(n) + TILE - 1) // TILE) * TILE
+
+
+class FringeGeometry:
+    """
+    Everything the fringe kernels need besides psky: baseline vectors, per-time pointing
+    vectors, frequencies and the baseline -> beam-model-pair grouping.  Built once per RIME
+    minibatch and reused by forward and backward.
+
+    blvecs (Nbl, 3) [m]; sdir (Nt, 3, Pstride) unit vectors, zero-padded past each time's
+    pixel count; freqs (Nf,) [Hz]; bl_models: optional list of model-pair index per baseline.
+    """
+    def __init__(self, blvecs, sdir, freqs, bl_mp=None, Nmp=1, conj=False):
+        _require_cuda(blvecs, sdir)
+        dev = blvecs.device
+        self.blvecs = blvecs.detach().to(torch.float64).contiguous()
+        self.sdir = sdir.detach().to(torch.float64).contiguous()
+        f = torch.as_tensor(freqs, dtype=torch.float64)
+        fh = f.detach().cpu().numpy()
+        self.freqs = f.to(dev).contiguous()
+        self.Nbl, self.Nt, self.Nf = self.blvecs.shape[0], self.sdir.shape[0], len(fh)
+        self.Pstride = self.sdir.shape[2]
+        assert self.sdir.shape[1] == 3 and self.Pstride % TILE == 0
+        self.sign = -1 if conj else 1
+        # uniform channel spacing enables the rotation recurrence
+        if len(fh) > 1:
+            d = np.diff(fh)
+            self.uniform = bool(np.all(np.abs(d - d[0]) <= 1e-9 * max(abs(d[0]), 1.0)))
+            self.df = float((fh[-1] - fh[0]) / (len(fh) - 1))
+        else:
+            self.uniform, self.df = True, 0.0
+        self.f0 = float(fh[0])
+        self.max_blen = float(torch.linalg.norm(self.blvecs, dim=1).max().item())
+        # model-pair grouping
+        self.Nmp = int(Nmp)
+        if bl_mp is None or self.Nmp == 1:
+            self.Nmp = 1
+            self.mp_offsets = (ctypes.c_int * 2)(0, self.Nbl)
+            self.bl_order = None
+        else:
+            bl_mp = np.asarray(bl_mp, dtype=np.int64)
+            order = np.argsort(bl_mp, kind='stable')
+            counts = np.bincount(bl_mp, minlength=self.Nmp)
+            offs = np.concatenate([[0], np.cumsum(counts)])
+            self.mp_offsets = (ctypes.c_int * (self.Nmp + 1))(*[int(o) for o in offs])
+            self.bl_order = torch.as_tensor(order, dtype=torch.int32, device=dev)
+
+
+def _fringe_call(geom, backward, inp, out, Npp, cplx):
+    code, rdt = _real_dtype(inp)
+    fn = lib.rime_fringe_sum_bwd if backward else lib.rime_fringe_sum_fwd
+    nbytes = lib.rime_fringe_sum_workspace(code, geom.Nbl, geom.Nt, geom.Nf, geom.Pstride,
+                                           geom.Nmp, Npp, int(cplx), int(backward))
+    ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=inp.device)
+    rc = fn(code, _ptr(geom.blvecs), _ptr(geom.sdir), _ptr(geom.freqs), _ptr(inp),
+            geom.mp_offsets, _ptr(geom.bl_order), geom.Nbl, geom.Nt, geom.Nf, geom.Pstride,
+            geom.Nmp, Npp, int(cplx), geom.sign, int(geom.uniform), geom.f0, geom.df,
+            geom.max_blen, _ptr(out), _ptr(ws), ws.numel(), _stream())
+    check(rc, 'rime_fringe_sum_bwd' if backward else 'rime_fringe_sum_fwd')
+
+
+class _FringeSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, psky, geom):
+        _require_cuda(psky)
+        assert psky.dim() == 5, 'psky must be (Nt, Nmp, Npp, Nf, Pstride)'
+        Nt, Nmp, Npp, Nf, Ps = psky.shape
+        assert (Nt, Nmp, Nf, Ps) == (geom.Nt, geom.Nmp, geom.Nf, geom.Pstride), \
+            'psky %s does not match geometry (Nt=%d, Nmp=%d, Nf=%d, Pstride=%d)' % (
+                tuple(psky.shape), geom.Nt, geom.Nmp, geom.Nf, geom.Pstride)
+        cplx = psky.is_complex()
+        p = psky.detach().contiguous()
+        _, rdt = _real_dtype(p)
+        cdt = torch.complex64 if rdt == torch.float32 else torch.complex128
+        vis = torch.empty((Npp, geom.Nbl, Nt, Nf), dtype=cdt, device=p.device)
+        _fringe_call(geom, False, torch.view_as_real(p) if cplx else p, torch.view_as_real(vis),
+                     Npp, cplx)
+        ctx.geom, ctx.cplx, ctx.shape, ctx.dtype = geom, cplx, tuple(psky.shape), psky.dtype
+        return vis
+
+    @staticmethod
+    def backward(ctx, gvis):
+        geom = ctx.geom
+        g = gvis.contiguous()
+        gp = torch.empty(ctx.shape, dtype=ctx.dtype, device=g.device)
+        _fringe_call(geom, True, torch.view_as_real(g),
+                     torch.view_as_real(gp) if ctx.cplx else gp, ctx.shape[2], ctx.cplx)
+        return gp, None
+
+
+def fringe_sum(psky, geom):
+    """
+    psky (Nt, Nmp, Npp, Nf, Pstride) real or complex on the GPU; geom a FringeGeometry.
+    Returns vis (Npp, Nbl, Nt, Nf) complex.  Differentiable w.r.t. psky.
+    """
+    return _FringeSum.apply(psky, geom)
+
+
+# ---------------------------------------------------------------------------------------
+class InterpStencil:
+    """(inds, wgts) of PixInterp plus the CSR inverse index the deterministic adjoint uses."""
+    def __init__(self, inds, wgts, Npb):
+        _require_cuda(inds, wgts)
+        self.P, self.Nnn = inds.shape
+        self.Npb = int(Npb)
+        self.inds = inds.to(torch.int32).contiguous()
+        self.wgts = wgts.contiguous()
+        flat = self.inds.reshape(-1).to(torch.int64)
+        order = torch.sort(flat, stable=True).indices
+        counts = torch.bincount(flat, minlength=self.Npb)
+        ptr = torch.zeros(self.Npb + 1, dtype=torch.int64, device=inds.device)
+        ptr[1:] = torch.cumsum(counts, 0)
+        self.csr_ptr = ptr.to(torch.int32).contiguous()
+        self.csr_src = order.to(torch.int32).contiguous()
+        self._wcache = {self.wgts.dtype: self.wgts}
+
+    def weights(self, dtype):
+        if dtype not in self._wcache:
+            self._wcache[dtype] = self.wgts.to(dtype).contiguous()
+        return self._wcache[dtype]
+
+
+class _InterpGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, m, st, out_stride):
+        _require_cuda(m)
+        lead = m.shape[:-1]
+        Npb = m.shape[-1]
+        assert Npb == st.Npb, 'map has %d pixels, stencil was built for %d' % (Npb, st.Npb)
+        cplx = m.is_complex()
+        mm = m.detach().contiguous()
+        code, rdt = _real_dtype(mm)
+        R = int(np.prod(lead)) if len(lead) else 1
+        out = torch.zeros(lead + (out_stride,), dtype=m.dtype, device=m.device)
+        rc = lib.rime_interp_gather_fwd(code, int(cplx), _ptr(torch.view_as_real(mm) if cplx else mm),
+                                        _ptr(st.inds), _ptr(st.weights(rdt)), R, Npb, st.P, st.Nnn,
+                                        _ptr(torch.view_as_real(out) if cplx else out), out_stride,
+                                        _stream())
+        check(rc, 'rime_interp_gather_fwd')
+        ctx.st, ctx.shape, ctx.cplx, ctx.out_stride = st, tuple(m.shape), cplx, out_stride
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        st = ctx.st
+        g = gout.contiguous()
+        code, rdt = _real_dtype(g)
+        gm = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+        R = int(np.prod(ctx.shape[:-1])) if len(ctx.shape) > 1 else 1
+        rc = lib.rime_interp_scatter_bwd(code, int(ctx.cplx),
+                                         _ptr(torch.view_as_real(g) if ctx.cplx else g), ctx.out_stride,
+                                         _ptr(st.csr_ptr), _ptr(st.csr_src), _ptr(st.weights(rdt)),
+                                         R, st.Npb, st.P, st.Nnn,
+                                         _ptr(torch.view_as_real(gm) if ctx.cplx else gm), _stream())
+        check(rc, 'rime_interp_scatter_bwd')
+        return gm, None, None
+
+
+def interp_gather(m, stencil, out_stride=None):
+    """out[..., p] = sum_k w[p,k] m[..., inds[p,k]]; columns P..out_stride are zero padding."""
+    return _InterpGather.apply(m, stencil, stencil.P if out_stride is None else int(out_stride))
+
+
+# ---------------------------------------------------------------------------------------
+class _Alm2Pix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, alm, Ylm):
+        _require_cuda(alm, Ylm)
+        assert alm.is_complex() and Ylm.is_complex()
+        lead = alm.shape[:-1]
+        Nc, Npix = Ylm.shape
+        assert alm.shape[-1] == Nc
+        a = alm.detach().contiguous()
+        Y = Ylm.detach().contiguous()
+        code, rdt = _real_dtype(a)
+        assert Y.dtype == a.dtype, 'alm %s vs Ylm %s' % (a.dtype, Y.dtype)
+        R = int(np.prod(lead)) if len(lead) else 1
+        out = torch.empty(lead + (Npix,), dtype=rdt, device=a.device)
+        rc = lib.rime_alm2pix_fwd(code, _ptr(torch.view_as_real(a)), _ptr(torch.view_as_real(Y)),
+                                  R, Nc, Npix, _ptr(out), _stream())
+        check(rc, 'rime_alm2pix_fwd')
+        ctx.Y, ctx.shape, ctx.dtype = Y, tuple(alm.shape), alm.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        Y = ctx.Y
+        g = gout.contiguous()
+        code, _ = _real_dtype(g)
+        Nc, Npix = Y.shape
+        ga = torch.empty(ctx.shape, dtype=ctx.dtype, device=g.device)
+        R = int(np.prod(ctx.shape[:-1])) if len(ctx.shape) > 1 else 1
+        rc = lib.rime_alm2pix_bwd(code, _ptr(g), _ptr(torch.view_as_real(Y)), R, Nc, Npix,
+                                  _ptr(torch.view_as_real(ga)), _stream())
+        check(rc, 'rime_alm2pix_bwd')
+        return ga, None
+
+
+def alm2pix(alm, Ylm):
+    """Re(alm @ Ylm): alm (..., Ncoeff) complex, Ylm (Ncoeff, Npix) complex -> (..., Npix) real."""
+    return _Alm2Pix.apply(alm, Ylm)

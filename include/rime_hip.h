@@ -1,0 +1,131 @@
+/*
+ * rime_hip.h -- C ABI of the MI355X-native RIME visibility-synthesis library (librime_hip.so)
+ *
+ * This is the drop-in boundary for the hot path of BayesLIM's `rime_model.RIME.forward`
+ * and its autograd backward.  The reference has no FFI: its "interface" for this path is a
+ * handful of Python tensor functions.  Each entry point below replaces the arithmetic of the
+ * reference function named in its comment (file:line under /root/reference/bayeslim/).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`.
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no allocation, no
+ *     synchronisation, no host<->device copies: graph-capturable.  Workspace is caller-owned.
+ *   - returns 0 on success, a negative RIME_E* code on a rejected call (never throws).
+ *   - `dtype`: RIME_F32 (float / complex64) or RIME_F64 (double / complex128) for the
+ *     psky / vis / map tensors.  Geometry (blvecs, sdir, freqs) is always float64.
+ *   - tensors are dense, last index fastest, layouts given per function.
+ */
+#ifndef RIME_HIP_H
+#define RIME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RIME_F32 0
+#define RIME_F64 1
+
+#define RIME_OK          0
+#define RIME_EINVAL     -1   /* bad shape / flag / null pointer            */
+#define RIME_EWORKSPACE -2   /* workspace too small                         */
+#define RIME_ELAUNCH    -3   /* hipLaunchKernel reported an error           */
+#define RIME_EUNSUPPORTED -4
+
+/* library / build identification: "rime_hip <version> gfx950" */
+const char* rime_version(void);
+
+/* last HIP error string seen by a failed launch (thread-unsafe diagnostic) */
+const char* rime_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Fringe sum, forward.
+ *   vis[pp, b, t, f] = sum_p  psky[t, mp(b), pp, f, p] * exp(sign * 2 pi i * freq[f]/c * blvecs[b] . sdir[t, :, p])
+ * Replaces: ArrayModel.gen_fringe (telescope_model.py:310-358) fused with the product and
+ * pixel sum of RIME._prod_and_sum (rime_model.py:423-429).  The (Nbl, Nf, P) fringe tensor is
+ * never materialised.
+ *
+ *   blvecs   f64 [Nbl, 3]            baseline vectors, ENU metres
+ *   sdir     f64 [Nt, 3, Pstride]    unit pointing vectors per time step (x=E, y=N, z=Up);
+ *                                    columns p >= npix of a time step must be finite (zero)
+ *   freqs    f64 [Nf]                Hz
+ *   psky     T   [Nt, Nmp, Npp, Nf, Pstride]      (real)   or
+ *            T   [Nt, Nmp, Npp, Nf, Pstride, 2]   (complex, interleaved) perceived sky =
+ *                                    apply_beam output per beam-model pair; padded columns 0
+ *   mp_offsets_host  int[Nmp+1] (HOST) baselines of model pair g are bl_order[off[g] .. off[g+1])
+ *   bl_order int [Nbl] or NULL       baseline index per slot (NULL: identity; needs Nmp == 1
+ *                                    or baselines already grouped by model pair)
+ *   vis      complex<T> [Npp, Nbl, Nt, Nf]  (interleaved re, im)
+ *   freq_uniform_host: 1 if freqs are uniformly spaced (enables the rotation recurrence);
+ *                    freq0_host / dfreq_host give the first channel and spacing [Hz].
+ *   max_blen_host: upper bound on |blvecs[b]| [m] (<= 0: unknown).  Lets the library pick the
+ *                    3-FMA shear rotation when max_blen * |dfreq| / c < 0.3 turn per channel.
+ *   workspace: at least rime_fringe_sum_workspace(...) bytes.
+ * ------------------------------------------------------------------------------------- */
+size_t rime_fringe_sum_workspace(int dtype, int Nbl, int Nt, int Nf, int Pstride,
+                                 int Nmp, int Npp, int psky_complex, int backward);
+
+int rime_fringe_sum_fwd(int dtype,
+                        const double* blvecs, const double* sdir, const double* freqs,
+                        const void* psky, const int* mp_offsets_host, const int* bl_order,
+                        int Nbl, int Nt, int Nf, int Pstride, int Nmp, int Npp,
+                        int psky_complex, int sign,
+                        int freq_uniform_host, double freq0_host, double dfreq_host,
+                        double max_blen_host,
+                        void* vis, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fringe sum, backward (gradient w.r.t. psky; PyTorch convention grad = dL/dRe + i dL/dIm):
+ *   gpsky[t, mp, pp, f, p] = sum_{b in group mp} conj(F[b,t,f,p]) * gvis[pp, b, t, f]
+ *   (real part only when psky is real).  Regenerates the fringe; deterministic (no atomics).
+ * Replaces the autograd backward of rime_model.py:429 (SumBackward/MulBackward over the
+ * saved (Nbl,Nf,P) fringe and psky tensors).
+ *   gvis  complex<T> [Npp, Nbl, Nt, Nf];  gpsky same layout as psky (fully overwritten).
+ * ------------------------------------------------------------------------------------- */
+int rime_fringe_sum_bwd(int dtype,
+                        const double* blvecs, const double* sdir, const double* freqs,
+                        const void* gvis, const int* mp_offsets_host, const int* bl_order,
+                        int Nbl, int Nt, int Nf, int Pstride, int Nmp, int Npp,
+                        int psky_complex, int sign,
+                        int freq_uniform_host, double freq0_host, double dfreq_host,
+                        double max_blen_host,
+                        void* gpsky, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Pixel-beam interpolation gather:  out[r, p] = sum_k wgts[p, k] * m[r, inds[p, k]]
+ * Replaces PixInterp.interp (utils.py:815-861: index_select + einsum).
+ *   m    T [R, Npb]   (R = product of leading dims: Npol*Nvec*Nmodel*Nf), or complex<T>
+ *   inds int32 [P, Nnn];  wgts T [P, Nnn];  out T [R, out_stride] (columns >= P untouched)
+ * ------------------------------------------------------------------------------------- */
+int rime_interp_gather_fwd(int dtype, int is_complex, const void* m, const int* inds,
+                           const void* wgts, int R, int Npb, int P, int Nnn,
+                           void* out, int out_stride, void* stream);
+
+/* Adjoint of the gather, deterministic: gm[r, j] = sum over (p,k) with inds[p,k]==j of
+ * wgts[p,k] * gout[r, p], driven by a CSR inverse index built once per (inds, wgts):
+ *   csr_ptr int32 [Npb+1], csr_src int32 [nnz] (flat p*Nnn+k positions, ascending per row).
+ * Replaces the index_select/einsum backward (scatter-add) of utils.py:833-841. */
+int rime_interp_scatter_bwd(int dtype, int is_complex, const void* gout, int out_stride,
+                            const int* csr_ptr, const int* csr_src, const void* wgts,
+                            int R, int Npb, int P, int Nnn, void* gm, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a_lm -> pixel transform:  out[r, j] = sum_c ( are[r,c] * Yre[c,j] - aim[r,c] * Yim[c,j] )
+ *   = Re( (a * alm_mult) @ Ylm ), with alm_mult already folded into `alm` by the caller
+ *   (an elementwise torch op, kept in autograd).
+ * Replaces AlmModel.forward_alm (sph_harm.py:1342-1372), real_output=True branch.
+ *   alm  T [R, Ncoeff, 2] (interleaved complex);  Ylm T [Ncoeff, Npix, 2];  out T [R, Npix]
+ * Backward: galm[r, c] = sum_j gout[r, j] * conj(Ylm[c, j])   (complex, interleaved)
+ * ------------------------------------------------------------------------------------- */
+int rime_alm2pix_fwd(int dtype, const void* alm, const void* Ylm, int R, int Ncoeff, int Npix,
+                     void* out, void* stream);
+int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, int R, int Ncoeff, int Npix,
+                     void* galm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIME_HIP_H */

@@ -1,0 +1,265 @@
+"""
+GPU parity tests: the HIP kernels, called through the C ABI (bayeslim_amd.ops -> ctypes ->
+librime_hip.so), against the float64 CPU oracle and the committed golden vectors.
+
+Tolerances (BASELINE.json north_star): complex visibilities within rtol 1e-5 in fp32,
+gradients within 1e-4, both measured against the fp64 oracle and scaled by the tensor's
+max magnitude (SURVEY.md section 7 "hard parts": a per-element rtol is not meaningful for a sum
+of ~1e3-turn phasors).  The float64 kernels must agree to roundoff (1e-11).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import rime_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+T64 = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float64)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from bayeslim_amd import ops as _ops
+    return _ops
+
+
+def relmax(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def oracle_fringe_sum(psky, blvecs, zenaz, freqs, bl_mp, conj=False):
+    """psky (Nt, Nmp, Npp, Nf, P) float64/complex128 CPU -> (Npp, Nbl, Nt, Nf)"""
+    out = []
+    for t in range(psky.shape[0]):
+        fr = orc.gen_fringe(blvecs, zenaz[t, 0], zenaz[t, 1], freqs, conj=conj)    # (Nbl, Nf, P)
+        sel = psky[t][torch.as_tensor(bl_mp)]                                       # (Nbl, Npp, Nf, P)
+        out.append(torch.einsum('bfp,bqfp->qbf', fr, sel.to(fr.dtype)))
+    return torch.stack(out, dim=2)
+
+
+def make_case(seed, Nbl, Nt, Nf, P, Nmp, Npp, cplx, uniform=True, blen=60.0):
+    rng = np.random.default_rng(seed)
+    blvecs = rng.normal(0, blen, (Nbl, 3))
+    blvecs[:, 2] *= 0.05
+    if uniform:
+        freqs = np.linspace(120e6, 180e6, Nf)
+    else:
+        freqs = np.sort(rng.uniform(100e6, 200e6, Nf))
+    zen = np.rad2deg(np.arccos(rng.uniform(0.0, 1.0, (Nt, P))))
+    az = rng.uniform(0, 360, (Nt, P))
+    zenaz = np.stack([zen, az], axis=1)
+    psky = rng.normal(size=(Nt, Nmp, Npp, Nf, P))
+    if cplx:
+        psky = psky + 1j * rng.normal(size=psky.shape)
+    bl_mp = rng.integers(0, Nmp, Nbl)
+    return T64(blvecs), T64(freqs), T64(zenaz), torch.as_tensor(psky), bl_mp
+
+
+def to_gpu_geometry(ops, blvecs, freqs, zenaz, bl_mp, Nmp, conj=False):
+    Nt, _, P = zenaz.shape
+    Ps = ops.pad_to_tile(P)
+    sdir = torch.zeros(Nt, 3, Ps, dtype=torch.float64)
+    for t in range(Nt):
+        sdir[t, :, :P] = orc.pointing_vectors(zenaz[t, 0], zenaz[t, 1])
+    return ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, bl_mp=bl_mp, Nmp=Nmp, conj=conj), Ps
+
+
+def pad_psky(psky, Ps):
+    out = torch.zeros(psky.shape[:-1] + (Ps,), dtype=psky.dtype)
+    out[..., :psky.shape[-1]] = psky
+    return out
+
+
+CONFIGS = [(1, False), (2, False), (1, True), (4, False), (4, True)]
+
+
+@pytest.mark.parametrize('Npp,cplx', CONFIGS)
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+@pytest.mark.parametrize('uniform', [True, False])
+def test_fringe_sum_fwd_bwd(ops, Npp, cplx, dtype, uniform):
+    Nmp = 3 if (Npp, cplx) in [(1, True), (4, True)] else 1
+    blvecs, freqs, zenaz, psky, bl_mp = make_case(11 + Npp, Nbl=77, Nt=2, Nf=19, P=333,
+                                                  Nmp=Nmp, Npp=Npp, cplx=cplx, uniform=uniform)
+    geom, Ps = to_gpu_geometry(ops, blvecs, freqs, zenaz, bl_mp, Nmp)
+    ref_in = psky.clone().requires_grad_(True)
+    ref = oracle_fringe_sum(ref_in, blvecs, zenaz, freqs, bl_mp)
+    gv = torch.as_tensor(np.random.default_rng(5).normal(size=tuple(ref.shape))
+                         + 1j * np.random.default_rng(6).normal(size=tuple(ref.shape)))
+    (ref * gv.conj()).real.sum().backward()
+
+    rdt = torch.float64 if dtype == 'f64' else torch.float32
+    cdt = torch.complex128 if dtype == 'f64' else torch.complex64
+    x = pad_psky(psky, Ps).to(cdt if cplx else rdt).cuda().requires_grad_(True)
+    vis = ops.fringe_sum(x, geom)
+    assert vis.shape == ref.shape and vis.dtype == cdt
+    tol_f, tol_g = (1e-11, 1e-11) if dtype == 'f64' else (1e-5, 1e-4)
+    assert relmax(vis, ref) < tol_f
+    (vis * gv.to(cdt).cuda().conj()).real.sum().backward()
+    g = x.grad[..., :psky.shape[-1]]
+    assert relmax(g, ref_in.grad) < tol_g
+    assert x.grad[..., psky.shape[-1]:].abs().max() < 1e30        # padded columns: finite
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_fringe_sum_long_baselines_and_conj(ops, dtype):
+    """km baselines: step/channel > 0.3 turn -> standard rotation path; conj=True sign"""
+    blvecs, freqs, zenaz, psky, bl_mp = make_case(3, Nbl=130, Nt=1, Nf=64, P=200, Nmp=1, Npp=1,
+                                                  cplx=False, blen=2500.0)
+    geom, Ps = to_gpu_geometry(ops, blvecs, freqs, zenaz, bl_mp, 1, conj=True)
+    assert geom.max_blen * geom.df / 2.99792458e8 > 0.3
+    ref = oracle_fringe_sum(psky, blvecs, zenaz, freqs, bl_mp, conj=True)
+    rdt = torch.float64 if dtype == 'f64' else torch.float32
+    vis = ops.fringe_sum(pad_psky(psky, Ps).to(rdt).cuda(), geom)
+    assert relmax(vis, ref) < (1e-10 if dtype == 'f64' else 1e-5)
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_fringe_sum_split_paths(ops, dtype):
+    """few baselines x many pixels -> pixel-split partial slabs + reduce (fwd);
+    few pixels x many baselines -> baseline-split (bwd); also exercises the 2048-term flush"""
+    for (Nbl, P) in [(3, 9000), (700, 10)]:
+        blvecs, freqs, zenaz, psky, bl_mp = make_case(7, Nbl=Nbl, Nt=2, Nf=33, P=P, Nmp=1, Npp=1,
+                                                      cplx=False)
+        geom, Ps = to_gpu_geometry(ops, blvecs, freqs, zenaz, bl_mp, 1)
+        ref_in = psky.clone().requires_grad_(True)
+        ref = oracle_fringe_sum(ref_in, blvecs, zenaz, freqs, bl_mp)
+        gv = torch.as_tensor(np.random.default_rng(5).normal(size=tuple(ref.shape)) + 0j)
+        (ref * gv.conj()).real.sum().backward()
+        rdt = torch.float64 if dtype == 'f64' else torch.float32
+        x = pad_psky(psky, Ps).to(rdt).cuda().requires_grad_(True)
+        vis = ops.fringe_sum(x, geom)
+        assert relmax(vis, ref) < (1e-11 if dtype == 'f64' else 1e-5)
+        (vis * gv.cuda().to(vis.dtype).conj()).real.sum().backward()
+        assert relmax(x.grad[..., :P], ref_in.grad) < (1e-11 if dtype == 'f64' else 1e-4)
+
+
+def test_fringe_sum_golden_prod_and_sum(ops):
+    g = load_golden('prod_and_sum')
+    zenaz = T64(np.stack([g['zen'], g['az']]))[None]
+    psky = (T64(g['beam']) * T64(g['sky'])[:, :, None])[0, 0][None, :, None][:, :, 0][None]  # (1,1,1,Nf,P)
+    psky = (T64(g['beam'])[0, 0] * T64(g['sky'])[0, 0][None]).reshape(1, 1, 1, *g['sky'].shape[2:])
+    geom, Ps = to_gpu_geometry(ops, T64(g['blvecs']), T64(g['freqs']), zenaz, None, 1)
+    vis = ops.fringe_sum(pad_psky(psky, Ps).cuda(), geom)          # (1, Nbl, 1, Nf)
+    ref = g['sum_sky'][0, 0]                                       # (Nbl, Nf)
+    assert relmax(vis[0, :, 0], ref) < 1e-11
+    vis32 = ops.fringe_sum(pad_psky(psky, Ps).float().cuda(), geom)
+    assert relmax(vis32[0, :, 0], ref) < 1e-5
+
+
+def test_fringe_matches_golden_gen_fringe(ops):
+    """one-hot psky recovers individual fringe values exp(2 pi i nu b.s/c) of gen_fringe"""
+    for tag in ('uniform', 'ragged'):
+        g = load_golden('fringe_' + tag)
+        P = len(g['zen'])
+        zenaz = T64(np.stack([g['zen'], g['az']]))[None]
+        Nf = len(g['freqs'])
+        for conj, key in [(False, 'fringe'), (True, 'fringe_conj')]:
+            geom, Ps = to_gpu_geometry(ops, T64(g['blvecs']), T64(g['freqs']), zenaz, None, 1,
+                                       conj=conj)
+            for p in (0, 17, P - 1):
+                psky = torch.zeros(1, 1, 1, Nf, Ps, dtype=torch.float64)
+                psky[..., p] = 1.0
+                vis = ops.fringe_sum(psky.cuda(), geom)[0, :, 0]
+                assert relmax(vis, g[key][:, :, p]) < 1e-11
+                vis32 = ops.fringe_sum(psky.float().cuda(), geom)[0, :, 0]
+                assert np.abs(vis32.cpu().numpy() - g[key][:, :, p]).max() < 2e-6
+
+
+@pytest.mark.parametrize('mode', ['nearest', 'linear', 'quadratic', 'cubic', 'linear,quadratic'])
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_interp_gather(ops, mode, dtype):
+    g = load_golden('interp_rect')
+    key = mode.replace(',', '_')
+    Npb = len(g['theta_grid']) * len(g['phi_grid'])
+    rng = np.random.default_rng(3)
+    rng.uniform(0.02, 89.9, 120)
+    rng.uniform(0.0, 359.999, 120)
+    m = T64(rng.normal(size=(2, 3, Npb)))
+    inds, wgts = torch.as_tensor(g[key + '__inds']), T64(g[key + '__wgts'])
+    rdt = torch.float64 if dtype == 'f64' else torch.float32
+    st = ops.InterpStencil(inds.cuda(), wgts.to(rdt).cuda(), Npb)
+    x = m.to(rdt).cuda().requires_grad_(True)
+    P = inds.shape[0]
+    y = ops.interp_gather(x, st, out_stride=ops.pad_to_tile(P))
+    assert y.shape == (2, 3, ops.pad_to_tile(P))
+    assert (y[..., P:] == 0).all()
+    tol = 1e-12 if dtype == 'f64' else 2e-6
+    assert relmax(y[..., :P], g[key + '__out']) < tol
+    gout = torch.zeros_like(y)
+    gout[..., :P] = T64(g[key + '__gout']).to(rdt).cuda()
+    (y * gout).sum().backward()
+    ref = np.zeros(2 * 3 * Npb)
+    ref[g[key + '__gm_nnz_idx']] = g[key + '__gm_nnz_val']
+    assert relmax(x.grad.reshape(-1), ref) < (1e-12 if dtype == 'f64' else 2e-6)
+    # determinism of the adjoint
+    x.grad = None
+    y2 = ops.interp_gather(x, st, out_stride=ops.pad_to_tile(P))
+    (y2 * gout).sum().backward()
+    g1 = x.grad.clone()
+    x.grad = None
+    y3 = ops.interp_gather(x, st, out_stride=ops.pad_to_tile(P))
+    (y3 * gout).sum().backward()
+    assert torch.equal(g1, x.grad)
+
+
+def test_interp_gather_complex_and_ragged_stencil(ops):
+    rng = np.random.default_rng(0)
+    Npb, P, Nnn = 500, 130, 6
+    inds = torch.as_tensor(rng.integers(0, Npb, (P, Nnn)))
+    wgts = T64(rng.normal(size=(P, Nnn)))
+    m = torch.as_tensor(rng.normal(size=(5, Npb)) + 1j * rng.normal(size=(5, Npb)))
+    mr = m.clone().requires_grad_(True)
+    ref = orc.interp(mr, inds, wgts)
+    gv = torch.as_tensor(rng.normal(size=(5, P)) + 1j * rng.normal(size=(5, P)))
+    (ref * gv.conj()).real.sum().backward()
+    st = ops.InterpStencil(inds.cuda(), wgts.cuda(), Npb)
+    x = m.cuda().requires_grad_(True)
+    y = ops.interp_gather(x, st)
+    assert relmax(y, ref) < 1e-12
+    (y * gv.cuda().conj()).real.sum().backward()
+    assert relmax(x.grad, mr.grad) < 1e-12
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_alm2pix(ops, dtype):
+    g = load_golden('sph_harm')
+    a = torch.as_tensor(g['alm'])
+    Y = torch.as_tensor(g['Ylm_comp'])
+    mult = T64(g['alm_mult_comp'])
+    cdt = torch.complex128 if dtype == 'f64' else torch.complex64
+    x = torch.view_as_real(a).clone().to(torch.float64 if dtype == 'f64' else torch.float32).cuda()
+    x.requires_grad_(True)
+    xa = torch.view_as_complex(x) * mult.to(x.dtype).cuda()
+    y = ops.alm2pix(xa, Y.to(cdt).cuda())
+    tol = 1e-12 if dtype == 'f64' else 3e-6
+    assert relmax(y, g['fwd_full']) < tol
+    (y * T64(g['gout_full']).to(y.dtype).cuda()).sum().backward()
+    assert relmax(x.grad, g['galm_full']) < tol
+
+
+def test_alm2pix_larger_random(ops):
+    rng = np.random.default_rng(1)
+    l, m = orc.gen_lm(20)
+    th, ph = np.arccos(rng.uniform(-1, 1, 777)), rng.uniform(0, 2 * np.pi, 777)
+    Y = torch.as_tensor(orc.sph_Ylm(th, ph, l, m))
+    a = torch.as_tensor(rng.normal(size=(2, 1, 37, len(l))) + 1j * rng.normal(size=(2, 1, 37, len(l))))
+    ar = a.clone().requires_grad_(True)
+    ref = orc.forward_alm(ar, Y)
+    gv = T64(rng.normal(size=tuple(ref.shape)))
+    (ref * gv).sum().backward()
+    for cdt, tol in [(torch.complex128, 1e-12), (torch.complex64, 1e-5)]:
+        x = a.to(cdt).cuda().requires_grad_(True)
+        y = ops.alm2pix(x, Y.to(cdt).cuda())
+        assert relmax(y, ref) < tol
+        (y * gv.to(y.dtype).cuda()).sum().backward()
+        assert relmax(x.grad, ar.grad) < tol
+
+
+def test_ops_refuse_cpu_tensors(ops):
+    with pytest.raises(RuntimeError):
+        ops.alm2pix(torch.zeros(2, 3, dtype=torch.complex64), torch.zeros(3, 4, dtype=torch.complex64))
