@@ -27,6 +27,7 @@ SIGNATURES = {
                                  _i, _d, _d, _d, _vp, _vp, _sz, _vp]),
     'rime_fringe_sum_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _ip, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                  _i, _d, _d, _d, _vp, _vp, _sz, _vp]),
+    'rime_gen_fringe': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rime_interp_gather_fwd': (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'rime_interp_scatter_bwd': (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'rime_alm2pix_fwd': (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -411,6 +411,27 @@ fringe_bwd_kernel(FringeArgs A)
     if (since_flush > 0 || first) flush();
 }
 
+// materialised fringe (API parity with ArrayModel.gen_fringe; RIME itself never needs it):
+// out[b, f, p] = exp(sign 2 pi i freq[f]/c  blvecs[b] . sdir[:, p]),  sdir is [3, sstride]
+template <typename T>
+__global__ void __launch_bounds__(256)
+gen_fringe_kernel(const double* __restrict__ blvecs, const double* __restrict__ sdir,
+                  const double* __restrict__ freqs, int Nbl, int Nf, int P, int sstride, double sign,
+                  T* __restrict__ out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= P) return;
+    const double tau = sign * (blvecs[3 * b] * sdir[p] + blvecs[3 * b + 1] * sdir[sstride + p]
+                               + blvecs[3 * b + 2] * sdir[2 * (size_t)sstride + p]);
+    for (int f = 0; f < Nf; ++f) {
+        T s, c;
+        sincos_turns(reduce_turns<T>(tau * (freqs[f] * (1.0 / 2.99792458e8))), s, c);
+        T* o = out + (((size_t)b * Nf + f) * P + p) * 2;
+        o[0] = c; o[1] = s;
+    }
+}
+
 // deterministic reduction of S partial slabs: out[blk][i] = sum_s ws[s][blk][i]
 template <typename T>
 __global__ void reduce_partials_kernel(const T* __restrict__ ws, T* __restrict__ out,
@@ -650,4 +671,22 @@ extern "C" int rime_fringe_sum_bwd(int dtype, const double* blvecs, const double
     return fringe_common(true, dtype, blvecs, sdir, freqs, gvis, mp_offsets_host, bl_order, Nbl, Nt,
                          Nf, Pstride, Nmp, Npp, psky_complex, sign, freq_uniform_host, freq0_host,
                          dfreq_host, max_blen_host, gpsky, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rime_gen_fringe(int dtype, const double* blvecs, const double* sdir,
+                               const double* freqs, int Nbl, int Nf, int P, int sdir_stride,
+                               int sign, void* out, void* stream)
+{
+    if (!blvecs || !sdir || !freqs || !out) return RIME_EINVAL;
+    if (Nbl <= 0 || Nf <= 0 || P <= 0 || sdir_stride < P || (sign != 1 && sign != -1)) return RIME_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((P + 255) / 256, Nbl), block(256);
+    if (dtype == RIME_F32)
+        hipLaunchKernelGGL((gen_fringe_kernel<float>), grid, block, 0, st, blvecs, sdir, freqs, Nbl, Nf, P,
+                           sdir_stride, (double)sign, reinterpret_cast<float*>(out));
+    else if (dtype == RIME_F64)
+        hipLaunchKernelGGL((gen_fringe_kernel<double>), grid, block, 0, st, blvecs, sdir, freqs, Nbl, Nf, P,
+                           sdir_stride, (double)sign, reinterpret_cast<double*>(out));
+    else return RIME_EINVAL;
+    return check_launch();
 }

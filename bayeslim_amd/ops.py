@@ -142,6 +142,21 @@ def fringe_sum(psky, geom):
     return _FringeSum.apply(psky, geom)
 
 
+def gen_fringe(blvecs, sdir, freqs, conj=False, dtype=torch.float32):
+    """materialised fringe (Nbl, Nf, P) complex; blvecs (Nbl,3), sdir (3,P) float64 on the GPU"""
+    _require_cuda(blvecs, sdir)
+    b = blvecs.detach().to(torch.float64).contiguous()
+    s = sdir.detach().to(torch.float64).contiguous()
+    f = torch.as_tensor(freqs, dtype=torch.float64).to(b.device).contiguous()
+    cdt = torch.complex64 if dtype == torch.float32 else torch.complex128
+    out = torch.empty((b.shape[0], len(f), s.shape[1]), dtype=cdt, device=b.device)
+    rc = lib.rime_gen_fringe(RIME_F32 if dtype == torch.float32 else RIME_F64, _ptr(b), _ptr(s), _ptr(f),
+                             b.shape[0], len(f), s.shape[1], s.shape[1], -1 if conj else 1,
+                             _ptr(torch.view_as_real(out)), _stream())
+    check(rc, 'rime_gen_fringe')
+    return out
+
+
 # ---------------------------------------------------------------------------------------
 class InterpStencil:
     """(inds, wgts) of PixInterp plus the CSR inverse index the deterministic adjoint uses."""

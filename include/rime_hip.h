@@ -95,6 +95,15 @@ int rime_fringe_sum_bwd(int dtype,
                         void* gpsky, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Materialised fringe, for callers that want the tensor itself (imaging.VisMapper.build_A,
+ * tests):  out[b, f, p] = exp(sign * 2 pi i * freqs[f]/c * blvecs[b] . sdir[:, p])
+ * Replaces ArrayModel.gen_fringe (telescope_model.py:350-356).  RIME never calls it.
+ *   sdir f64 [3, sdir_stride];  out complex<T> [Nbl, Nf, P]
+ * ------------------------------------------------------------------------------------- */
+int rime_gen_fringe(int dtype, const double* blvecs, const double* sdir, const double* freqs,
+                    int Nbl, int Nf, int P, int sdir_stride, int sign, void* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Pixel-beam interpolation gather:  out[r, p] = sum_k wgts[p, k] * m[r, inds[p, k]]
  * Replaces PixInterp.interp (utils.py:815-861: index_select + einsum).
  *   m    T [R, Npb]   (R = product of leading dims: Npol*Nvec*Nmodel*Nf), or complex<T>
