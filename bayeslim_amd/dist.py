@@ -1,0 +1,149 @@
+"""
+Multi-GPU execution of the RIME path: one process per GPU, baselines sharded across ranks,
+`torch.distributed` collectives (backend 'nccl' == RCCL over xGMI on ROCm; 'gloo' in CPU tests).
+
+The reference has no collectives: its `DistributedLogProb` (optim.py:1391-1566) copies
+parameters to each device, runs the per-device closures one after another in a Python loop and
+sums gradients on device 0.  Here:
+  * visibilities are independent across baselines, so each rank simulates a CONTIGUOUS block of
+    `sim_bls` (order preserved: the gathered tensor equals the single-GPU layout) from
+    replicated sky / beam parameters -- no data-path collective inside the kernels;
+  * forward: optional all-gather of the (Npol, Npol, Nbl/W, Nt, Nf) visibility blocks
+    (differentiable: its backward hands each rank the slice of the upstream gradient that
+    belongs to its baselines -- no communication);
+  * backward: one all-reduce (sum) of the parameter gradients, bucketed into a single flat
+    buffer per dtype so the ring runs over few, large messages.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world_size):
+    """balanced contiguous partition of range(n): list of (start, stop) per rank"""
+    base, extra = divmod(int(n), int(world_size))
+    out, s = [], 0
+    for r in range(world_size):
+        e = s + base + (1 if r < extra else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+def shard_baselines(bls, rank=None, world_size=None):
+    """this rank's contiguous block of a baseline list"""
+    rank = dist.get_rank() if rank is None else rank
+    world_size = dist.get_world_size() if world_size is None else world_size
+    s, e = shard_bounds(len(bls), world_size)[rank]
+    return list(bls[s:e])
+
+
+class _AllGatherBl(torch.autograd.Function):
+    """all-gather along the baseline axis (dim 2) of ragged per-rank blocks"""
+    @staticmethod
+    def forward(ctx, vis, counts, group):
+        world = len(counts)
+        rank = dist.get_rank(group)
+        nmax = max(counts)
+        shape = list(vis.shape)
+        pad = vis
+        if shape[2] < nmax:
+            padshape = shape[:2] + [nmax - shape[2]] + shape[3:]
+            pad = torch.cat([vis, vis.new_zeros(padshape)], dim=2)
+        pad = pad.contiguous()
+        if pad.is_complex():
+            buf = torch.view_as_real(pad)
+            parts = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(parts, buf, group=group)
+            parts = [torch.view_as_complex(p) for p in parts]
+        else:
+            parts = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(parts, pad, group=group)
+        ctx.counts, ctx.rank = counts, rank
+        return torch.cat([p[:, :, :c] for p, c in zip(parts, counts)], dim=2)
+
+    @staticmethod
+    def backward(ctx, g):
+        s = sum(ctx.counts[:ctx.rank])
+        return g[:, :, s:s + ctx.counts[ctx.rank]].contiguous(), None, None
+
+
+def all_gather_vis(vis_local, counts=None, group=None):
+    """
+    Gather per-rank visibility blocks (Npol, Npol, Nbl_r, Nt, Nf) into the full
+    (Npol, Npol, Nbl, Nt, Nf) tensor on every rank, rank blocks in rank order.
+    `counts`: baselines per rank (default: exchanged with an all_gather of the local count).
+    """
+    world = dist.get_world_size(group)
+    if counts is None:
+        n = torch.tensor([vis_local.shape[2]], device=vis_local.device)
+        ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n, group=group)
+        counts = [int(x.item()) for x in ns]
+    return _AllGatherBl.apply(vis_local, tuple(counts), group)
+
+
+def all_reduce_grads(params, group=None, average=False):
+    """
+    Sum .grad of the given parameters over ranks, in place.  Gradients are flattened into one
+    bucket per dtype (complex viewed as real), reduced with a single all_reduce each and
+    scattered back.  Parameters without a .grad on this rank contribute zeros.
+    """
+    params = [p for p in params if p is not None]
+    by_dtype = {}
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        by_dtype.setdefault((p.grad.dtype, p.grad.device), []).append(p)
+    world = dist.get_world_size(group)
+    for (dt, dev), ps in by_dtype.items():
+        views = [torch.view_as_real(p.grad).reshape(-1) if p.grad.is_complex() else p.grad.reshape(-1)
+                 for p in ps]
+        flat = torch.cat(views)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= world
+        o = 0
+        for p, v in zip(ps, views):
+            n = v.numel()
+            v.copy_(flat[o:o + n])
+            o += n
+
+
+def reduce_scalar(x, group=None):
+    """sum of a scalar tensor (e.g. a shard-local chi^2) over ranks"""
+    y = x.detach().clone()
+    dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+    return y
+
+
+class ShardedRIME:
+    """
+    Baseline-sharded driver around a RIME factory.  `make_rime(sim_bls)` must build a RIME for the
+    given baseline list with this rank's replica of the sky / beam models.  forward() returns
+    this rank's VisData block, or the gathered visibilities with gather=True.
+    """
+    def __init__(self, make_rime, all_bls, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.all_bls = list(all_bls)
+        self.bounds = shard_bounds(len(self.all_bls), self.world)
+        self.counts = [e - s for s, e in self.bounds]
+        s, e = self.bounds[self.rank]
+        self.local_bls = self.all_bls[s:e]
+        self.rime = make_rime(self.local_bls)
+
+    def forward(self, gather=False, **kw):
+        vd = self.rime(**kw)
+        if gather:
+            vd.data = all_gather_vis(vd.data, self.counts, self.group)
+            vd._set_bls(self.all_bls)
+        return vd
+
+    __call__ = forward
+
+    def sync_grads(self, params=None):
+        if params is None:
+            params = [p for p in self.rime.parameters()]
+        all_reduce_grads(params, self.group)

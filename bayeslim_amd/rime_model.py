@@ -1,0 +1,293 @@
+"""
+`RIME`: the radio interferometric measurement equation V_pq = sum_pix A_p B A_q^dagger K_pq,
+with the reference's constructor, attributes and minibatch protocol (rime_model.py:13-482).
+
+What differs from the reference is HOW forward() computes:
+  * the reference loops over times in Python and, per time, materialises an (Nbl, Nf, P)
+    complex fringe and the (.., Nbl, Nf, P) product before summing (rime_model.py:334-365,
+    423-429).  Here every time step of the minibatch is prepared (FoV cut, beam interpolation,
+    beam x sky per beam-model pair) and ONE fused HIP kernel (ops.fringe_sum) produces
+    vis[pp, bl, t, f] for all baselines, times and channels; backward is one fused kernel too.
+  * per-time geometry (pointing vectors, FoV cut, interpolation stencil) is cached under the
+    same keys the reference uses: (sky name, Npix, time).
+Output: `VisData` with data (Npol, Npol, Nbl_data, Ntimes, Nfreqs), exactly as the reference.
+"""
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from . import utils, ops, beam_model, dataset, telescope_model
+from .dataset import VisData
+
+
+class RIME(utils.Module):
+    def __init__(self, sky, telescope, beam, array, sim_bls, times, freqs, data_bls=None,
+                 device=None, cache_eq2top=True, name=None, verbose=False):
+        super().__init__(name=name)
+        self.sky = sky
+        self.telescope = telescope
+        self.beam = beam
+        self.array = array
+        self.device = device
+        self.cache_eq2top = cache_eq2top
+        self.verbose = verbose
+        self.clear_geometry_cache()
+        self.setup_freqs(freqs)
+        self.setup_sim_bls(sim_bls, data_bls)
+        self.setup_sim_times(times=times)
+
+    # -- device / caches -----------------------------------------------------------------
+    def clear_geometry_cache(self):
+        self._zenaz_cache = {}      # key -> (zen, az) float64 on the compute device
+        self._npix_cache = {}       # key -> pixels surviving the FoV cut
+        self._geom_cache = {}       # (bl group, time group, sky name, Npix) -> FringeGeometry
+        self._mp_cache = {}         # bl group -> (modelpairs, pair index per baseline)
+
+    def push(self, device):
+        self.sim_blvec_groups = {k: v.to(device) for k, v in self.sim_blvec_groups.items()}
+        if not isinstance(device, torch.dtype):
+            self.device = device
+            for k, v in self._sim2data.items():
+                if v is not None:
+                    self._sim2data[k] = utils.push(v, device)
+        self.clear_geometry_cache()
+
+    @property
+    def Ntimes_all(self):
+        return len(self.all_sim_times)
+
+    @property
+    def Nbls_all(self):
+        return len(self.all_sim_bls)
+
+    def setup_freqs(self, freqs):
+        self.freqs = freqs
+        self.Nfreqs = len(freqs)
+        self._geom_cache = {}
+
+    # -- baseline groups (rime_model.py:148-226) -------------------------------------------
+    def setup_sim_bls(self, sim_bls, data_bls=None):
+        self.bl_group_id = 0
+        if isinstance(sim_bls, dict):
+            groups = {k: [tuple(b) for b in v] for k, v in sim_bls.items()}
+        else:
+            ints = (int, np.integer)
+            assert isinstance(sim_bls[0][0], ints) or isinstance(sim_bls[0][0][0], ints), \
+                "sim_bls must be list of 2-tuples or list of list of 2-tuples"
+            if isinstance(sim_bls[0][0], ints):
+                groups = {0: [tuple(b) for b in sim_bls]}
+            else:
+                groups = {i: [tuple(b) for b in g] for i, g in enumerate(sim_bls)}
+        if data_bls is not None:
+            data_bls = [tuple(b) for b in data_bls]
+        self.sim_bl_groups = groups
+        self.all_sim_bls = utils.flatten(groups.values())
+        self.Nbl_groups = len(groups)
+        self.sim_blvec_groups = {k: self.array.get_blvecs(v) for k, v in groups.items()}
+        if data_bls is None:
+            self.data_bl_groups = self.sim_bl_groups
+            self._sim2data = {k: None for k in groups}
+        else:
+            self._sim2data, self.data_bl_groups = {}, {}
+            b2r = self.array.bl2red
+            for k, blg in groups.items():
+                sim_red = [b2r[bl] for bl in blg]
+                keep = set(sim_red)
+                dbl = [bl for bl in data_bls if b2r[bl] in keep]
+                data_red = [b2r[bl] for bl in dbl]
+                assert set(sim_red) == set(data_red), "non-overlapping bl type(s) in data_bls and sim_bls"
+                # redundant baselines must be contiguous in data_bls
+                assert len(np.where(np.diff(data_red) != 0)[0]) == len(blg) - 1
+                self.data_bl_groups[k] = dbl
+                pos = {r: i for i, r in reversed(list(enumerate(sim_red)))}
+                self._sim2data[k] = torch.as_tensor([pos[r] for r in data_red], device=self.device)
+        self._geom_cache, self._mp_cache = {}, {}
+        self._set_group()
+
+    # -- time groups (rime_model.py:228-251) -------------------------------------------------
+    def setup_sim_times(self, times):
+        self.time_group_id = 0
+        if not isinstance(times, dict):
+            if isinstance(times, list) or (isinstance(times, (np.ndarray, torch.Tensor)) and times.ndim > 1):
+                times = {k: np.asarray(t) for k, t in enumerate(times)}
+            else:
+                times = {0: np.asarray(times)}
+        self.sim_time_groups = times
+        self.all_sim_times = np.asarray(utils.flatten(times.values()))
+        self.Ntime_groups = len(times)
+        self._geom_cache = {}
+        self._set_group()
+
+    @property
+    def Nbatch(self):
+        if hasattr(self, 'sim_bl_groups') and hasattr(self, 'sim_time_groups'):
+            return len(self.sim_bl_groups) * len(self.sim_time_groups)
+        return None
+
+    @property
+    def batch_idx(self):
+        """time_group_id * Nbl_groups + bl_group_id: baselines vary fastest (rime_model.py:55-57)"""
+        if hasattr(self, 'bl_group_id') and hasattr(self, 'time_group_id'):
+            return self.time_group_id * len(self.sim_bl_groups) + self.bl_group_id
+        return None
+
+    @batch_idx.setter
+    def batch_idx(self, val):
+        assert 0 <= val < self.Nbatch
+        self.time_group_id = int(val // len(self.sim_bl_groups))
+        self.bl_group_id = int(val % len(self.sim_bl_groups))
+        self._set_group()
+
+    def _set_group(self):
+        if hasattr(self, 'sim_bl_groups'):
+            self.sim_bls = self.sim_bl_groups[self.bl_group_id]
+            self.sim_blvecs = self.sim_blvec_groups[self.bl_group_id]
+            self.Nsim_bls = len(self.sim_bls)
+            self.data_bls = self.data_bl_groups[self.bl_group_id]
+            self.Ndata_bls = len(self.data_bls)
+        if hasattr(self, 'sim_time_groups'):
+            self.sim_times = self.sim_time_groups[self.time_group_id]
+            self.Ntimes = len(self.sim_times)
+
+    # -- forward ---------------------------------------------------------------------------
+    def _compute_device(self, sky):
+        dev = sky.device
+        if dev.type != 'cuda':
+            raise RuntimeError("RIME.forward: the sky model lives on '%s'; bayeslim_amd computes on the "
+                               "GPU only (push the models to 'cuda')" % dev)
+        return dev
+
+    def _zenaz(self, key, time, ra, dec, dev):
+        za = self._zenaz_cache.get(key)
+        if za is None:
+            angs = self.telescope.eq2top(time, ra, dec, store=self.cache_eq2top, key=key)
+            zen = torch.as_tensor(angs[0]).to(device=dev, dtype=torch.float64)
+            az = torch.as_tensor(angs[1]).to(device=dev, dtype=torch.float64)
+            za = (zen, az)
+            self._zenaz_cache[key] = za
+        return za
+
+    def forward(self, *args, prior_cache=None, **kwargs):
+        """sky -> beam -> fused fringe sum -> VisData (rime_model.py:291-389)"""
+        self._set_group()
+        comps = self.sky.forward(prior_cache=prior_cache)
+        if not isinstance(comps, list):
+            comps = [comps]
+        Npol = self.beam.Npol
+        pol = '{0}{0}'.format(self.beam.pol) if Npol == 1 else None
+        if hasattr(self.beam.R, 'clear_beam_cache'):
+            self.beam.R.clear_beam_cache()
+        self.beam.skycut_device = self.sky.device
+        if self.bl_group_id not in self._mp_cache:
+            self._mp_cache[self.bl_group_id] = self.beam.modelpairs(self.sim_bls)
+        pairs, bl_mp = self._mp_cache[self.bl_group_id]
+        start = datetime.now().timestamp()
+
+        vis = None
+        for i, comp in enumerate(comps):
+            sky = comp.data
+            dev = self._compute_device(sky)
+            ra, dec = comp.angs
+            Npix = len(ra)
+            keys = [(comp.name, Npix, float(t)) for t in self.sim_times]
+            # pass 1: angles and FoV-cut sizes -> common padded pixel stride
+            za = [self._zenaz(k, t, ra, dec, dev) for k, t in zip(keys, self.sim_times)]
+            for k, (zen, az) in zip(keys, za):
+                if k not in self._npix_cache:
+                    cut = self.beam.fov_cut(zen)
+                    self._npix_cache[k] = Npix if isinstance(cut, slice) else int(cut.numel())
+            Ps = ops.pad_to_tile(max(max(self._npix_cache[k] for k in keys), 1))
+            # sky with one trailing zero column: padded FoV-cut indices point at it
+            sky_ext = torch.cat([sky, sky.new_zeros(sky.shape[:-1] + (1,))], dim=-1)
+            psky_t, sdir_t = [], []
+            gkey = (self.bl_group_id, self.time_group_id, comp.name, Npix, Ps)
+            geom = self._geom_cache.get(gkey)
+            for j, (k, (zen, az)) in enumerate(zip(keys, za)):
+                if self.verbose:
+                    log('{}/{} times for {}/{} sky model | {} elapsed'.format(
+                        j + 1, len(keys), i + 1, len(comps), elapsed_time(start)), verbose=True)
+                zen._arr_hash = k                                   # rime_model.py:351
+                beam, cut, zc, ac = self.beam.gen_beam(zen, az, prior_cache=prior_cache, out_stride=Ps)
+                zc._arr_hash = k                                    # rime_model.py:357
+                P = zc.shape[0]
+                if beam.shape[-1] != Ps:
+                    beam = torch.nn.functional.pad(beam, (0, Ps - beam.shape[-1]))
+                if isinstance(cut, slice):
+                    cut = torch.arange(Npix, device=dev)
+                cutp = torch.full((Ps,), Npix, dtype=torch.int64, device=dev)
+                cutp[:P] = cut.to(dev)
+                cut_sky = sky_ext.index_select(-1, cutp)             # beam_model.cut_sky_fov + padding
+                psky_t.append(self.beam.apply_beam_mp(beam, cut_sky, pairs))
+                if geom is None:
+                    s = self.array.get_s(zc, ac).to(dev)
+                    sdir_t.append(torch.nn.functional.pad(s, (0, Ps - P)))
+            if geom is None:
+                geom = ops.FringeGeometry(self.sim_blvecs.to(dev), torch.stack(sdir_t), self.freqs,
+                                          bl_mp=bl_mp, Nmp=len(pairs))
+                self._geom_cache[gkey] = geom
+            # (Nt, Npol, Npol|1, Nmp, Nf, Ps) -> (Nt, Nmp, Npp, Nf, Ps)
+            ps = torch.stack(psky_t)
+            Nt, n1, n2, Nmp, Nf, _ = ps.shape
+            ps = ps.permute(0, 3, 1, 2, 4, 5).reshape(Nt, Nmp, n1 * n2, Nf, Ps)
+            v = ops.fringe_sum(ps, geom)                            # (Npp, Nbl, Nt, Nf)
+            v = v.reshape(n1, n2, v.shape[1], Nt, Nf)
+            vis = v if vis is None else vis + v
+
+        idx = self._sim2data[self.bl_group_id]
+        if idx is not None:
+            vis = vis.index_select(2, idx.to(vis.device))           # rime_model.py:436-437
+        if self.device is not None and not utils.check_devices(vis.device, self.device):
+            vis = vis.to(self.device)
+
+        vd = VisData()
+        tel = self.telescope.__class__(self.telescope.location, tloc=getattr(self.telescope, 'tloc', None),
+                                       device=self.telescope.device)
+        vd.setup_meta(tel, self.array.to_antpos())
+        vd.setup_data(self.data_bls, self.sim_times, self.freqs, pol=pol, data=vis, flags=None,
+                      cov=None, history=self.describe())
+        return vd
+
+    def describe(self):
+        """one-line model description stored as VisData.history (io.get_model_description analogue)"""
+        return 'RIME(sky={}, beam={}[{}], Nbls={}, Ntimes={}, Nfreqs={})'.format(
+            getattr(self.sky, 'name', type(self.sky).__name__), getattr(self.beam, 'name', 'beam'),
+            type(self.beam.R).__name__, self.Nsim_bls, self.Ntimes, self.Nfreqs)
+
+    def run_batches(self, concat=True):
+        """forward() over all minibatches, concatenated over baselines then times (rime_model.py:442-482)"""
+        per_time, per_bl = [], []
+        for i in range(self.Nbatch):
+            self.batch_idx = i
+            per_bl.append(self.forward())
+            if self.Nbatch == 1:
+                per_time.append(per_bl[-1])
+            elif self.bl_group_id == self.Nbl_groups - 1:
+                if concat:
+                    per_time.append(dataset.concat_VisData(per_bl, 'bl'))
+                else:
+                    per_time.extend(per_bl)
+                per_bl = []
+        out = dataset.concat_VisData(per_time, 'time') if concat else per_time
+        self.batch_idx = 0
+        return out
+
+
+def log(message, verbose=False, style=1):
+    if verbose:
+        if style == 1:
+            print(message)
+        elif style == 2:
+            print('{}\n{}'.format(message, '-' * 30))
+        else:
+            print('\n{}\n{}\n{}'.format('-' * 30, message, '-' * 30))
+
+
+def elapsed_time(start):
+    t = datetime.now().timestamp() - start
+    unit = 'sec'
+    if t > 60000:
+        t, unit = t / 3600, 'hrs'
+    elif t > 1000:
+        t, unit = t / 60, 'min'
+    return '{:.3f} {}'.format(t, unit)

@@ -564,8 +564,10 @@ class PixInterp:
         mode = self.interp_mode
         deg = [mode, mode] if ',' not in mode else [s.strip() for s in mode.split(',')]
         deg = [_S2D[d] for d in deg]
-        return bipoly_interp_weights(torch.as_tensor(self.phi_grid), torch.as_tensor(self.theta_grid),
-                                     torch.as_tensor(az), torch.as_tensor(zen), deg, wrapx=True)
+        az, zen = torch.as_tensor(az), torch.as_tensor(zen)
+        return bipoly_interp_weights(torch.as_tensor(self.phi_grid).to(az.device),
+                                     torch.as_tensor(self.theta_grid).to(az.device),
+                                     az, zen, deg, wrapx=True)
 
     def get_stencil(self, zen, az):
         """cached ops.InterpStencil for this angle set (keyed like the reference: arr_hash(zen))"""

@@ -1,0 +1,260 @@
+"""
+CPU tests of the host-side mirror of the reference interface (no kernels are launched):
+array / redundancy bookkeeping, minibatch protocol, interpolation stencils, HEALPix helpers,
+Ylm generation, module attribute protocol.  Values are checked against the golden vectors or
+against the assertions of the reference's own tests (cited).
+"""
+import copy
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+import bayeslim_amd as ba
+from bayeslim_amd import utils, telescope_model, beam_model, sky_model, sph_harm, healpix, rime_model
+from oracle import rime_oracle as orc
+
+
+@pytest.fixture(autouse=True)
+def _f64():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
+
+
+def hex_array(N, freqs=None, D=15):
+    ants, vecs = utils._make_hex(N, D=D)
+    return telescope_model.ArrayModel(utils.AntposDict(ants, vecs), freqs=freqs, cache_s=False, redtol=1.0)
+
+
+def test_make_hex_matches_reference_layout():
+    for name, N in [('rime_c1', 2), ('rime_c2_mini', 3)]:
+        g = load_golden(name)
+        ants, vecs = utils._make_hex(N, D=14.6)
+        assert ants == g['ants'].tolist()
+        assert np.abs(vecs - g['antvecs']).max() < 1e-12
+
+
+def test_array_redundancy_counts_and_blvecs():
+    """tests/test_telescope.py:41-51, 78-83"""
+    arr = hex_array(3)
+    assert len(arr.ants) == 19 and len(arr.reds) == 31
+    blv = arr.get_antpos(1) - arr.get_antpos(0)
+    assert (blv - torch.tensor([15., 0, 0])).norm() < 1e-10
+    sim = arr.get_bls(uniq_bls=True, keep_autos=True, min_len=1, max_len=29)
+    assert (0, 0) not in sim and (0, 2) not in sim and (1, 2) not in sim
+    assert len(arr.get_bls(uniq_bls=False, keep_autos=False)) == 171
+    assert len(arr.get_bls(uniq_bls=True, keep_autos=False)) == 30
+    g = load_golden('rime_c2_mini')
+    assert [tuple(b) for b in g['sim_bls']] == hex_array(3, D=14.6).get_bls(uniq_bls=False, keep_autos=False)
+    assert [tuple(b) for b in g['uniq_bls']] == hex_array(3, D=14.6).get_bls(uniq_bls=True, keep_autos=False)
+
+
+class _DummySky(utils.Module):
+    def __init__(self):
+        super().__init__(name='dummy')
+        self.params = torch.nn.Parameter(torch.ones(1, 1, 4, 3))
+        self.device = 'cpu'
+
+
+def _rime_cpu(times, sim_bls=None, data_bls=None, N=3):
+    freqs = torch.linspace(120e6, 130e6, 4)
+    arr = hex_array(N, freqs, D=14.6)
+    tel = telescope_model.TelescopeModel((21.42827, -30.72148))
+    beam = beam_model.PixelBeam(torch.ones(1, 1, 1, 4, 1), freqs, parameter=False, pol='e')
+    if sim_bls is None:
+        sim_bls = arr.get_bls(uniq_bls=True, keep_autos=False)
+    return rime_model.RIME(_DummySky(), tel, beam, arr, sim_bls, times, freqs, data_bls=data_bls), arr
+
+
+def test_rime_batch_protocol():
+    """rime_model.py:253-289 and tests/test_rime.py:41-47"""
+    times = torch.linspace(2459861, 2459862, 5)
+    rime, arr = _rime_cpu(times)
+    assert rime.Nbatch == 1 and rime.batch_idx == 0 and rime.Ntimes == 5
+    groups = utils.split_into_groups(times, Nelem=2)
+    rime.setup_sim_times(groups)
+    assert rime.Nbatch == int(np.ceil(5 / 2))
+    bls = arr.get_bls(uniq_bls=True, keep_autos=False)
+    rime.setup_sim_bls([bls[:10], bls[10:]])
+    assert rime.Nbatch == 6
+    order = []
+    for i in range(rime.Nbatch):
+        rime.batch_idx = i
+        order.append((rime.time_group_id, rime.bl_group_id))
+        assert rime.batch_idx == i
+    assert order == [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1)]    # baselines fastest
+    assert rime.Nsim_bls == 20 and rime.Ntimes == 1
+    with pytest.raises(AssertionError):
+        rime.batch_idx = 6
+    assert rime.Ntimes_all == 5 and rime.Nbls_all == 30
+
+
+def test_rime_sim2data_matches_reference():
+    g = load_golden('rime_c2_mini')
+    uniq = [tuple(b) for b in g['uniq_bls']]
+    rime, arr = _rime_cpu(np.array([2459861.0]), sim_bls=uniq,
+                          data_bls=arr_all_bls(g))
+    assert rime._sim2data[0].tolist() == g['sim2data'].tolist()
+    assert rime.data_bls == [tuple(b) for b in g['data_bls']]
+    assert rime.Ndata_bls == 171 and rime.Nsim_bls == 30
+
+
+def arr_all_bls(g):
+    return [tuple(b) for b in g['sim_bls']]
+
+
+def test_rime_refuses_cpu_forward():
+    rime, _ = _rime_cpu(np.array([2459861.0]))
+
+    class Sky(utils.Module):
+        device = 'cpu'
+        name_ = 's'
+
+        def forward(self, prior_cache=None):
+            from bayeslim_amd.dataset import MapData
+            m = MapData()
+            m.setup_meta(name='s')
+            m.setup_data(freqs=None, data=torch.ones(1, 1, 4, 3), angs=torch.zeros(2, 3))
+            return m
+    rime.sky = Sky()
+    with pytest.raises(RuntimeError, match='GPU only'):
+        rime()
+
+
+def test_bipoly_weights_match_golden():
+    g = load_golden('interp_rect')
+    tg, pg = torch.as_tensor(g['theta_grid']), torch.as_tensor(g['phi_grid'])
+    zen, az = torch.as_tensor(g['zen']), torch.as_tensor(g['az'])
+    Npb = len(tg) * len(pg)
+    for mode, deg in [('nearest', (0, 0)), ('linear', (1, 1)), ('quadratic', (2, 2)), ('cubic', (3, 3)),
+                      ('linear_quadratic', (1, 2))]:
+        inds, w = utils.bipoly_interp_weights(pg, tg, az, zen, deg)
+        for r in range(len(zen)):
+            d1, d2 = np.zeros(Npb), np.zeros(Npb)
+            np.add.at(d1, inds[r].numpy(), w[r].numpy())
+            np.add.at(d2, g[mode + '__inds'][r], g[mode + '__wgts'][r])
+            assert np.abs(d1 - d2).max() < 2e-9, (mode, r)
+        same = (inds.numpy() == g[mode + '__inds']).all(1)
+        assert same.sum() >= len(same) - 1
+
+
+def test_pixinterp_needs_gpu():
+    PI = utils.PixInterp('rect', interp_mode='linear', theta_grid=torch.arange(0, 91.0),
+                         phi_grid=torch.arange(0, 360.0))
+    with pytest.raises(RuntimeError, match='GPU'):
+        PI.get_interp(torch.tensor([10.0]), torch.tensor([20.0]))
+
+
+def test_healpix_self_consistency():
+    """parity unpinned (healpy absent): structural checks"""
+    for nside in (1, 2, 4, 16):
+        th, ph = healpix.pix2ang(nside)
+        th_o, ph_o = orc.healpix_pix2ang(nside)
+        assert np.abs(th - th_o).max() < 1e-14 and np.abs(ph - ph_o).max() < 1e-14
+        npix = healpix.nside2npix(nside)
+        assert abs(healpix.nside2pixarea(nside) * npix - 4 * np.pi) < 1e-12
+        # interpolation: weights sum to one, are non-negative, and are exact at pixel centres
+        pix, w = healpix.get_interp_weights(nside, th, ph)
+        assert pix.shape == (4, npix) and np.abs(w.sum(0) - 1).max() < 1e-12 and w.min() > -1e-12
+        got = (w * (pix == np.arange(npix)[None])).sum(0)
+        assert np.abs(got - 1).max() < 1e-9
+        rng = np.random.default_rng(nside)
+        t, p = np.arccos(rng.uniform(-1, 1, 500)), rng.uniform(0, 2 * np.pi, 500)
+        pix, w = healpix.get_interp_weights(nside, t, p)
+        assert pix.min() >= 0 and pix.max() < npix and np.abs(w.sum(0) - 1).max() < 1e-12
+    # a smooth function is reproduced to O(pixel size^2)
+    nside = 32
+    th, ph = healpix.pix2ang(nside)
+    f = lambda a, b: np.cos(a) + 0.3 * np.sin(a) * np.cos(b)
+    pix, w = healpix.get_interp_weights(nside, t, p)
+    assert np.abs((w * f(th, ph)[pix]).sum(0) - f(t, p)).max() < 3e-3
+
+
+def test_gen_sph2pix_matches_golden():
+    g = load_golden('sph_harm')
+    lm = sph_harm.gen_lm(int(g['lmax']))
+    assert (lm[0] == g['l']).all() and (lm[1] == g['m']).all()
+    for real, key in [(False, 'comp'), (True, 'real')]:
+        Y, norm, mult = sph_harm.gen_sph2pix(g['theta'] * utils.D2R, g['phi'] * utils.D2R, lm[0], lm[1],
+                                             real=real)
+        assert np.abs(Y.numpy() - g['Ylm_' + key]).max() < 1e-13
+        assert (mult.numpy() == g['alm_mult_' + key]).all()
+    (T, P), _, mult = sph_harm.gen_sph2pix(g['theta_grid'] * utils.D2R, g['phi_grid'] * utils.D2R,
+                                           lm[0], lm[1], separable=True)
+    assert np.abs(T.numpy() - g['Theta']).max() < 1e-13 and np.abs(P.numpy() - g['Phi']).max() < 1e-13
+    full = sph_harm.inflate_Ylm((T, P))
+    assert full.shape == (len(lm[0]), len(g['theta_grid']) * len(g['phi_grid']))
+
+
+def test_module_attr_protocol_and_pickle():
+    """utils.py:1159-1167, 1453-1545 (what optim.LogProb.set_main_params relies on)"""
+    freqs = torch.linspace(120e6, 130e6, 4)
+    sky = sky_model.PointSky(torch.ones(1, 1, 2, 5), torch.zeros(2, 5),
+                             R=sky_model.PointSkyResponse(freqs, freq_mode='powerlaw', f0=freqs[0]))
+    top = utils.Sequential({'sky': sky})
+    assert isinstance(top['sky.params'], torch.nn.Parameter)
+    top['sky.params'] = torch.full((1, 1, 2, 5), 2.0)
+    assert isinstance(sky.params, torch.nn.Parameter) and float(sky.params.detach().sum()) == 20.0
+    # replace by a non-leaf graph tensor, as LogProb.set_main_params does
+    main = torch.nn.Parameter(torch.ones(10))
+    utils.set_model_attr(top, 'sky.params', (main * 3).reshape(1, 1, 2, 5), clobber_param=True, no_grad=False)
+    assert not sky.params.is_leaf and type(sky.params) is torch.Tensor
+    out = sky()
+    out.data.sum().backward()
+    assert main.grad is not None
+    del top['sky.params']
+    assert not hasattr(sky, 'params')
+    sky.params = torch.nn.Parameter(torch.ones(1, 1, 2, 5))
+    sky2 = pickle.loads(pickle.dumps(sky))
+    assert torch.equal(sky2.params, sky.params)
+    copy.deepcopy(sky)
+
+
+def test_sky_and_beam_responses_cpu_pieces():
+    """elementwise responses are plain torch ops and may be evaluated anywhere"""
+    g = load_golden('responses')
+    freqs, zen, az = torch.as_tensor(g['freqs']), torch.as_tensor(g['zen']), torch.as_tensor(g['az'])
+    R = sky_model.PointSkyResponse(freqs, freq_mode='powerlaw', f0=freqs[0])
+    assert np.abs(R(torch.as_tensor(g['point_params'])).numpy() - g['point_powerlaw']).max() < 1e-12
+    RA = beam_model.AiryResponse(powerbeam=True)
+    b = RA(torch.ones(1, 1, 1, 1, 1) * 14.0, zen, az, freqs)
+    assert np.abs(b.numpy() - g['airy_D14']).max() < 1e-13
+    RG = beam_model.GaussResponse()
+    assert np.abs(RG(torch.as_tensor(g['gauss_params']), zen, az, freqs).numpy() - g['gauss']).max() < 1e-14
+    tg, pg = torch.as_tensor(g['pr_theta_grid']), torch.as_tensor(g['pr_phi_grid'])
+    p = torch.as_tensor(g['pr_params'])
+    for tag, kw in [('abs', {}), ('log', dict(log=True)), ('beam0', dict(beam0=torch.as_tensor(g['pr_beam0']))),
+                    ('normpix', dict(norm_pix=3)), ('nonpower', dict(powerbeam=False))]:
+        Rp = beam_model.PixelResponse(freqs, 'rect', interp_mode='linear', theta_grid=tg, phi_grid=pg, **kw)
+        assert np.abs(Rp.forward(p.clone()).numpy() - g['pr_fwd_' + tag]).max() < 1e-14, tag
+
+
+def test_apply_beam_layout_matches_reference():
+    """apply_beam is pure torch: check all polarisation modes against the golden psky"""
+    g = load_golden('apply_beam')
+    bls = [tuple(b) for b in g['bls']]
+    freqs = torch.linspace(120e6, 130e6, 4)
+    for k in sorted({n.split('__')[0] for n in g if '__' in n}):
+        beam = torch.as_tensor(g[k + '__beam'])
+        a2b = g[k + '__ant2beam']
+        pb = beam_model.PixelBeam(beam.clone(), freqs, parameter=False, powerbeam=bool(g[k + '__powerbeam']),
+                                  ant2beam=None if a2b[0] < 0 else {i: int(a2b[i]) for i in range(3)}, pol='e')
+        psky = pb.apply_beam(beam, bls, torch.as_tensor(g[k + '__sky']))
+        assert psky.shape == g[k + '__psky'].shape, k
+        assert np.abs(psky.numpy() - g[k + '__psky']).max() < 1e-12 * np.abs(g[k + '__psky']).max(), k
+
+
+def test_eq2top_basic_geometry():
+    """own LST rotation (parity unpinned vs astropy): a source at dec = lat transits at zenith"""
+    tel = telescope_model.TelescopeModel((21.42827, -30.72148))
+    jd = 2459861.3
+    lst = telescope_model.JD2LST(jd, 21.42827)
+    zen, az = telescope_model.eq2top(tel.location, jd, np.array([lst, lst, lst + 90]), np.array([-30.72148, 0.0, 0.0]))
+    assert zen[0] < 1e-6 and abs(zen[1] - 30.72148) < 1e-6 and abs(az[1] - 0.0) < 1e-6
+    assert abs(zen[2] - 90.0) < 1e-6 and abs(az[2] - 90.0) < 1e-6       # RA = LST + 6h: rising due east
+    angs = tel.eq2top(jd, torch.tensor([0.0]), torch.tensor([0.0]), store=True)
+    assert tel.hash(jd, torch.tensor([0.0])) in tel.conv_cache and angs.shape == (2, 1)   # tests/test_telescope.py:27-38
