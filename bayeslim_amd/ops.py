@@ -19,6 +19,10 @@ from ._lib import lib, check, RIME_F32, RIME_F64
 
 TILE = 64        # pixel-axis padding granule required by the fringe kernels (rime::TP)
 
+# bench.py sets this to a list to collect (kernel name, start event, end event, fringe elements)
+# around every fringe-sum launch; None (default) records nothing.
+PROFILE = None
+
 
 def _require_cuda(*tensors):
     for t in tensors:
@@ -56,7 +60,7 @@ class FringeGeometry:
     blvecs (Nbl, 3) [m]; sdir (Nt, 3, Pstride) unit vectors, zero-padded past each time's
     pixel count; freqs (Nf,) [Hz]; bl_models: optional list of model-pair index per baseline.
     """
-    def __init__(self, blvecs, sdir, freqs, bl_mp=None, Nmp=1, conj=False):
+    def __init__(self, blvecs, sdir, freqs, bl_mp=None, Nmp=1, conj=False, npix=None):
         _require_cuda(blvecs, sdir)
         dev = blvecs.device
         self.blvecs = blvecs.detach().to(torch.float64).contiguous()
@@ -68,6 +72,9 @@ class FringeGeometry:
         self.Pstride = self.sdir.shape[2]
         assert self.sdir.shape[1] == 3 and self.Pstride % TILE == 0
         self.sign = -1 if conj else 1
+        # algorithmic fringe elements per launch: Nbl x Nf x (valid pixels summed over times)
+        nvalid = int(sum(npix)) if npix is not None else self.Nt * self.Pstride
+        self.elements = self.Nbl * self.Nf * nvalid
         # uniform channel spacing enables the rotation recurrence
         if len(fh) > 1:
             d = np.diff(fh)
@@ -98,11 +105,18 @@ def _fringe_call(geom, backward, inp, out, Npp, cplx):
     nbytes = lib.rime_fringe_sum_workspace(code, geom.Nbl, geom.Nt, geom.Nf, geom.Pstride,
                                            geom.Nmp, Npp, int(cplx), int(backward))
     ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=inp.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = fn(code, _ptr(geom.blvecs), _ptr(geom.sdir), _ptr(geom.freqs), _ptr(inp),
             geom.mp_offsets, _ptr(geom.bl_order), geom.Nbl, geom.Nt, geom.Nf, geom.Pstride,
             geom.Nmp, Npp, int(cplx), geom.sign, int(geom.uniform), geom.f0, geom.df,
             geom.max_blen, _ptr(out), _ptr(ws), ws.numel(), _stream())
     check(rc, 'rime_fringe_sum_bwd' if backward else 'rime_fringe_sum_fwd')
+    if prof is not None:
+        e1.record()
+        prof.append(('fringe_bwd_kernel' if backward else 'fringe_fwd_kernel', e0, e1, geom.elements))
 
 
 class _FringeSum(torch.autograd.Function):

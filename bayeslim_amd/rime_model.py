@@ -200,7 +200,7 @@ class RIME(utils.Module):
             Ps = ops.pad_to_tile(max(max(self._npix_cache[k] for k in keys), 1))
             # sky with one trailing zero column: padded FoV-cut indices point at it
             sky_ext = torch.cat([sky, sky.new_zeros(sky.shape[:-1] + (1,))], dim=-1)
-            psky_t, sdir_t = [], []
+            psky_t, sdir_t, npix_t = [], [], []
             gkey = (self.bl_group_id, self.time_group_id, comp.name, Npix, Ps)
             geom = self._geom_cache.get(gkey)
             for j, (k, (zen, az)) in enumerate(zip(keys, za)):
@@ -222,9 +222,10 @@ class RIME(utils.Module):
                 if geom is None:
                     s = self.array.get_s(zc, ac).to(dev)
                     sdir_t.append(torch.nn.functional.pad(s, (0, Ps - P)))
+                    npix_t.append(P)
             if geom is None:
                 geom = ops.FringeGeometry(self.sim_blvecs.to(dev), torch.stack(sdir_t), self.freqs,
-                                          bl_mp=bl_mp, Nmp=len(pairs))
+                                          bl_mp=bl_mp, Nmp=len(pairs), npix=npix_t)
                 self._geom_cache[gkey] = geom
             # (Nt, Npol, Npol|1, Nmp, Nf, Ps) -> (Nt, Nmp, Npp, Nf, Ps)
             ps = torch.stack(psky_t)
