@@ -141,7 +141,10 @@ def build_model(inp, dev, bls, seed=0):
                                  freq_mode='channel', powerbeam=True, device=dev)
     beam = beam_model.PixelBeam(airy[None, None, None].contiguous(), freqs, R=R, pol='e', powerbeam=True,
                                 fov=180, parameter=True)
-    rime = rime_model.RIME(sky, tel, beam, arr, bls, inp['times'], freqs)
+    # geometry frequencies stay float64: an exactly uniform grid lets the fringe kernel use its
+    # rotation recurrence (float32-rounded channel centres are not uniform to better than ~8 Hz)
+    rime = rime_model.RIME(sky, tel, beam, arr, bls, inp['times'],
+                           torch.as_tensor(inp['freqs'], dtype=torch.float64, device=dev))
     return rime
 
 
@@ -161,7 +164,7 @@ def cpu_baseline(inp, nbl_sample=16, bl_batch=8):
     (diffuse component), minibatched over baselines as the reference must be to fit host RAM.
     """
     from oracle import rime_oracle as orc
-    ncores = os.cpu_count() or 1
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     torch.set_num_threads(ncores)
     f32 = torch.float32
     freqs = torch.as_tensor(inp['freqs'], dtype=f32)
