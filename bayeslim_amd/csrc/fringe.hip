@@ -51,30 +51,15 @@ struct FringeArgs {
 };
 
 // ---------------------------------------------------------------------------------------
-// sin / cos of an angle given in TURNS, |r| <= 1/2.  Quadrant reduction to |t| <= 1/8 then
-// two short polynomials (max abs error 9e-8, i.e. f32 rounding level).
+// sin / cos of an angle given in TURNS, |r| <= 1/2: the hardware v_sin_f32 / v_cos_f32 take
+// their argument in revolutions; measured max abs error on gfx950 over [-1/2, 1/2] is 1.24e-7
+// (profiles/r01_microbench_gfx950.txt) at ~3.2 FMA issue slots each -- versus ~20 slots for a
+// quadrant-reduced polynomial of the same accuracy.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void sincos_turns(float r, float& s, float& c)
 {
-    float q = rintf(4.0f * r);
-    float t = fmaf(q, -0.25f, r);
-    float u = t * t;
-    float ps = fmaf(u, -75.40161269908938f, 81.59254287120774f);
-    ps = fmaf(u, ps, -41.34166257054729f);
-    ps = fmaf(u, ps, 6.283185287812946f);
-    float s0 = ps * t;
-    float pc = fmaf(u, 59.220168979635126f, -85.44284467368314f);
-    pc = fmaf(u, pc, 64.93931613571324f);
-    pc = fmaf(u, pc, -19.7392086501306f);
-    float c0 = fmaf(u, pc, 1.0f);
-    int qi = (int)q;
-    bool swap = qi & 1;
-    float cc = swap ? s0 : c0;
-    float ss = swap ? c0 : s0;
-    uint32_t sgn_c = ((uint32_t)(qi + 1) & 2u) << 30;   // q mod 4 in {1,2} -> negate cos
-    uint32_t sgn_s = ((uint32_t)qi & 2u) << 30;         // q mod 4 in {2,3} -> negate sin
-    c = __uint_as_float(__float_as_uint(cc) ^ sgn_c);
-    s = __uint_as_float(__float_as_uint(ss) ^ sgn_s);
+    s = __builtin_amdgcn_sinf(r);
+    c = __builtin_amdgcn_cosf(r);
 }
 
 __device__ __forceinline__ void sincos_turns(double r, double& s, double& c)
@@ -107,11 +92,16 @@ __device__ __forceinline__ void fringe_chunk(double tau, double nu_c, double dnu
     } else {
         T zs, zc, ws, wc;
         sincos_turns(reduce_turns<T>(tau * nu_c), zs, zc);
-        sincos_turns(reduce_turns<T>(tau * dnu), ws, wc);
+        if constexpr (MODE == MODE_LIFT) {
+            // the host guarantees |step| < 0.3 turn here: no range reduction needed
+            sincos_turns((T)(tau * dnu), ws, wc);
+        } else {
+            sincos_turns(reduce_turns<T>(tau * dnu), ws, wc);
+        }
         sink(KC, zc, zs);
         if constexpr (MODE == MODE_LIFT) {
             // rotation by +-theta as three shears
-            T a = -ws * __frcp_rn(T(1) + wc);
+            T a = -ws * __builtin_amdgcn_rcpf(T(1) + wc);
             T x = zc, y = zs;
 #pragma unroll
             for (int k = KC + 1; k < CH; ++k) {
@@ -281,7 +271,7 @@ fringe_fwd_kernel(FringeArgs A)
 // backward (gradient w.r.t. psky)
 // ---------------------------------------------------------------------------------------
 template <typename T, int NPP, bool CPLX, int CH, int MODE, int PIX>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (sizeof(T) == 4 && MODE != MODE_DIRECT && NPP * (CPLX ? 2 : 1) * CH <= 32) ? 4 : 1)
 fringe_bwd_kernel(FringeArgs A)
 {
     using G = Geom<T, NPP, CPLX, CH>;
@@ -538,7 +528,7 @@ static int launch_bwd_t(const FringeArgs& base, const int* mp_off, int mode, hip
                         size_t ws_bytes)
 {
     using G = Geom<T, NPP, CPLX, CH>;
-    constexpr int PIX = (sizeof(T) == 4 && NPP * (CPLX ? 2 : 1) * CH <= 32) ? 2 : 1;
+    constexpr int PIX = 1;
     for (int g = 0; g < base.Nmp; ++g) {
         FringeArgs A = base;
         A.bl_off = mp_off[g];
@@ -609,7 +599,7 @@ extern "C" size_t rime_fringe_sum_workspace(int dtype, int Nbl, int Nt, int Nf, 
         Plan pl = plan_fwd(Nbl, Nt, Nf, Pstride, CH);
         return pl.S <= 1 ? 0 : (size_t)pl.S * Npp * Nbl * Nt * Nf * 2 * tsz;
     }
-    const int PIX = (dtype == RIME_F32 && Npp * (psky_complex ? 2 : 1) * CH <= 32) ? 2 : 1;
+    const int PIX = 1;
     int S = 1;
     for (int n : {1, Nbl}) { Plan pl = plan_bwd(n, Nt, Nf, Pstride, CH, PIX); if (pl.S > S) S = pl.S; }
     return S <= 1 ? 0 : (size_t)S * Nt * Npp * Nf * Pstride * (psky_complex ? 2 : 1) * tsz;
