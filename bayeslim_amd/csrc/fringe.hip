@@ -77,11 +77,18 @@ __device__ __forceinline__ T reduce_turns(double ph)
 // One (baseline, pixel) pair: generate the CH fringe values of the chunk and hand each to
 // `sink(k, x, y)` (x = Re F, y = Im F).  `tau` = sign * b.s [m]; nu_c = anchor freq / c;
 // dnu = channel spacing / c; fk_c = per-channel freq / c table (MODE_DIRECT only).
-template <typename T, int CH, int MODE, typename Sink>
+template <typename T, int CH, int MODE, bool NOROT = false, typename Sink>
 __device__ __forceinline__ void fringe_chunk(double tau, double nu_c, double dnu,
                                              const double* __restrict__ fk_c, Sink&& sink)
 {
     constexpr int KC = CH / 2;
+    if constexpr (NOROT) {       // lab ablation: anchor only, every channel gets the same phasor
+        T zs, zc;
+        sincos_turns(reduce_turns<T>(tau * nu_c), zs, zc);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) sink(k, zc, zs);
+        return;
+    }
     if constexpr (MODE == MODE_DIRECT) {
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
@@ -152,8 +159,11 @@ struct Geom {
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <typename T, int NPP, bool CPLX, int CH, int MODE>
-__global__ void __launch_bounds__(256)
+// ABL (tools/fringe_lab.hip only; the library always instantiates ABL = 0): timing ablations
+//   1: no LDS reads of psky (lane-constant instead)   2: delay tau from f32 (no f64 math)
+//   4: skip the accumulate FMAs                        8: skip the rotation chain
+template <typename T, int NPP, bool CPLX, int CH, int MODE, int ABL = 0, int WPS = 1>
+__global__ void __launch_bounds__(256, WPS)
 fringe_fwd_kernel(FringeArgs A)
 {
     using G = Geom<T, NPP, CPLX, CH>;
@@ -242,9 +252,14 @@ fringe_fwd_kernel(FringeArgs A)
 
         if (active) {
             for (int pp = 0; pp < TP; ++pp) {
-                const double tau = bx * s_lds[pp] + by * s_lds[TP + pp] + bz * s_lds[2 * TP + pp];
-                const T* arow = a_lds + pp * G::ASTRIDE;
-                fringe_chunk<T, CH, MODE>(tau, nu_c, dnu, f_lds, [&](int k, T x, T y) {
+                double tau;
+                if constexpr (ABL & 2)
+                    tau = (double)((float)bx * (float)s_lds[pp] + (float)by * (float)s_lds[TP + pp]);
+                else
+                    tau = bx * s_lds[pp] + by * s_lds[TP + pp] + bz * s_lds[2 * TP + pp];
+                const T* arow = (ABL & 1) ? a_lds + (tid & 3) * G::ASTRIDE : a_lds + pp * G::ASTRIDE;
+                fringe_chunk<T, CH, MODE, (ABL & 8) != 0>(tau, nu_c, dnu, f_lds, [&](int k, T x, T y) {
+                    if constexpr (ABL & 4) { asm volatile("" :: "v"(x), "v"(y)); return; }
 #pragma unroll
                     for (int q = 0; q < NPP; ++q) {
                         if constexpr (CPLX) {
@@ -270,8 +285,8 @@ fringe_fwd_kernel(FringeArgs A)
 // ---------------------------------------------------------------------------------------
 // backward (gradient w.r.t. psky)
 // ---------------------------------------------------------------------------------------
-template <typename T, int NPP, bool CPLX, int CH, int MODE, int PIX>
-__global__ void __launch_bounds__(256, (sizeof(T) == 4 && MODE != MODE_DIRECT && NPP * (CPLX ? 2 : 1) * CH <= 32) ? 4 : 1)
+template <typename T, int NPP, bool CPLX, int CH, int MODE, int PIX, int WPS = 1>
+__global__ void __launch_bounds__(256, WPS)
 fringe_bwd_kernel(FringeArgs A)
 {
     using G = Geom<T, NPP, CPLX, CH>;
@@ -447,7 +462,10 @@ template <> struct ChunkOf<double> { static constexpr int real1 = 16, real2 = 8,
 
 static int pick_splits(long waves_unsplit, int max_splits)
 {
-    const long target = 4096;      // >= 4 waves per SIMD over 1024 SIMDs
+    // 16 waves per SIMD over 1024 SIMDs = 4 rounds at the 4-waves/SIMD residency of the float
+    // kernels: measured on MI355X (tools/fringe_lab.hip, C4 shape) 66.5 / 60.4 / 57.3 / 55.6 ms
+    // for 2048 / 4096 / 8192 / 16384 waves -- extra rounds smooth the end-of-grid tail
+    const long target = 16384;
     if (waves_unsplit >= target || max_splits <= 1) return 1;
     long s = (target + waves_unsplit - 1) / waves_unsplit;
     if (s > max_splits) s = max_splits;
@@ -464,7 +482,7 @@ static Plan plan_fwd(int bl_cnt, int Nt, int Nf, int Pstride, int CH)
     const long nblk = (bl_cnt + pl.block - 1) / pl.block;
     const long waves = nblk * (pl.block / 64) * (long)nchunk * Nt;
     const int ntiles = Pstride / TP;
-    pl.S = pick_splits(waves, ntiles);
+    pl.S = pick_splits(waves, std::max(1, ntiles / 4));      // keep >= 4 tiles (256 pixels) per split
     pl.tiles_per_split = (ntiles + pl.S - 1) / pl.S;
     pl.S = (ntiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
     return pl;
@@ -540,13 +558,15 @@ static int launch_bwd_t(const FringeArgs& base, const int* mp_off, int mode, hip
         if (A.S > 1 && ws_bytes < (size_t)A.S * A.Nt * plane * sizeof(T)) return RIME_EWORKSPACE;
         dim3 grid((A.Pstride + pl.block * PIX - 1) / (pl.block * PIX), (A.Nf + CH - 1) / CH, A.Nt * A.S);
         size_t lds = (3 * TB + CH) * sizeof(double) + (size_t)TB * G::GSTRIDE * sizeof(T);
+        // 4 waves/SIMD (<=128 VGPRs, a few spilled dwords) beat 3 at 136 VGPRs: 66.4 vs 71.9 ms (lab)
+        constexpr int WPS = (sizeof(T) == 4 && NPP * (CPLX ? 2 : 1) * CH <= 32) ? 4 : 1;
         if (mode == MODE_LIFT && sizeof(T) == 4) {
             if constexpr (sizeof(T) == 4)
-                hipLaunchKernelGGL((fringe_bwd_kernel<T, NPP, CPLX, CH, MODE_LIFT, PIX>), grid, dim3(pl.block), lds, st, A);
+                hipLaunchKernelGGL((fringe_bwd_kernel<T, NPP, CPLX, CH, MODE_LIFT, PIX, WPS>), grid, dim3(pl.block), lds, st, A);
         } else if (mode == MODE_DIRECT) {
             hipLaunchKernelGGL((fringe_bwd_kernel<T, NPP, CPLX, CH, MODE_DIRECT, PIX>), grid, dim3(pl.block), lds, st, A);
         } else {
-            hipLaunchKernelGGL((fringe_bwd_kernel<T, NPP, CPLX, CH, MODE_ROT, PIX>), grid, dim3(pl.block), lds, st, A);
+            hipLaunchKernelGGL((fringe_bwd_kernel<T, NPP, CPLX, CH, MODE_ROT, PIX, WPS>), grid, dim3(pl.block), lds, st, A);
         }
         if (A.S > 1) {
             int nb = (int)std::min<size_t>((plane * A.Nt + 255) / 256, 4096);

@@ -59,5 +59,9 @@ def test_bad_arguments_are_rejected_without_launching():
     assert rc == -1                # Npp = 3
     rc = lib.rime_interp_gather_fwd(0, 0, one, one, one, 2, 10, 5, 4, one, 3, None)
     assert rc == -1                # out_stride < P
-    assert lib.rime_fringe_sum_workspace(0, 8128, 4, 256, 108032, 1, 1, 0, 0) == 0
+    # workspace = S partial slabs of the vis tensor (forward) -- 0 when the grid is already large
+    vis_bytes = 8128 * 64 * 256 * 8
+    assert lib.rime_fringe_sum_workspace(0, 8128, 64, 256, 108032, 1, 1, 0, 0) == 0
+    ws = lib.rime_fringe_sum_workspace(0, 8128, 4, 256, 108032, 1, 1, 0, 0)
+    assert ws % (8128 * 4 * 256 * 8) == 0 and ws > 0
     assert lib.rime_fringe_sum_workspace(0, 3, 2, 33, 9024, 1, 1, 0, 0) > 0
