@@ -114,6 +114,31 @@ class PixelBeam(utils.Module):
         self.eval_prior(prior_cache)
         return beam, cut, zen, az
 
+    def eval_response(self, zen, az, prior_cache=None):
+        """
+        The part of gen_beam() after the FoV cut (beam_model.py:238-269): params (+p0) ->
+        pointing offset -> R(p, zen, az, freqs) -> gradient hooks -> prior.  RIME calls it once
+        per forward on the concatenated, already-cut angles of all time steps of the minibatch,
+        so one interpolation launch serves every time step.
+        """
+        p = self.params if self.p0 is None else self.params + self.p0
+        tx, ty = getattr(self, 'theta_x', 0), getattr(self, 'theta_y', 0)
+        if tx > 0 or ty > 0:
+            h = getattr(zen, '_arr_hash', None)
+            nz, na = pointing_offset(utils.tensor2numpy(zen) * D2R, utils.tensor2numpy(az) * D2R, tx, ty)
+            zen = torch.as_tensor(nz, device=zen.device) / D2R
+            az = torch.as_tensor(na, device=zen.device) / D2R
+            if h is not None:
+                zen._arr_hash = h
+        beam = self.R(p, zen, az, self.freqs)
+        if getattr(self, '_hook_registry', None) is not None:
+            bc = getattr(self.R, 'beam_cache', None)
+            if bc is not None and bc.requires_grad:
+                for r in self._hook_registry:
+                    bc.register_hook(r)
+        self.eval_prior(prior_cache)
+        return beam
+
     # -- beam x sky ----------------------------------------------------------------------
     def modelpairs(self, bls):
         """sorted unique (model1, model2) pairs and the pair index per baseline (beam_model.py:303-305)"""

@@ -46,6 +46,7 @@ struct FringeArgs {
     int bl_off, bl_cnt, mp;
     int Nbl, Nt, Nf, Pstride, Nmp;
     int S, tiles_per_split;
+    long long st_t, st_mp, st_pp, st_f;   // psky / gpsky strides [elements] of (time, model pair, pol product, channel)
     double sign;
     double freq0_c, dfreq_c;      // freq0 / c, dfreq / c   [turns per metre]
 };
@@ -202,8 +203,7 @@ fringe_fwd_kernel(FringeArgs A)
     const int tile_begin = split * A.tiles_per_split;
     const int tile_end = min(ntiles, tile_begin + A.tiles_per_split);
 
-    const T* psky = reinterpret_cast<const T*>(A.in)
-                    + ((size_t)t * A.Nmp + A.mp) * (size_t)NPP * A.Nf * A.Pstride * G::NC;
+    const T* psky = reinterpret_cast<const T*>(A.in) + ((size_t)t * A.st_t + (size_t)A.mp * A.st_mp) * G::NC;
     const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
 
     // destination: vis itself, or this split's partial slab in the workspace
@@ -245,7 +245,7 @@ fringe_fwd_kernel(FringeArgs A)
             int q = i / (G::NC * TP * CH);
             T v = T(0);
             if (k < nk)
-                v = psky[(((size_t)q * A.Nf + k0 + k) * A.Pstride + p0 + pp) * G::NC + c];
+                v = psky[((size_t)q * A.st_pp + (size_t)(k0 + k) * A.st_f + p0 + pp) * G::NC + c];
             a_lds[pp * G::ASTRIDE + (q * CH + k) * G::NC + c] = v;
         }
         __syncthreads();
@@ -327,9 +327,13 @@ fringe_bwd_kernel(FringeArgs A)
             for (int k = 0; k < CH * G::NC; ++k) acc[j][q][k] = T(0);
 
     const T* gvis = reinterpret_cast<const T*>(A.in);
-    const size_t plane = (size_t)NPP * A.Nf * A.Pstride * G::NC;     // one (t, mp) slab
-    T* dst = (A.S == 1) ? reinterpret_cast<T*>(A.out) + ((size_t)t * A.Nmp + A.mp) * plane
-                        : reinterpret_cast<T*>(A.ws) + ((size_t)split * A.Nt + t) * plane;
+    // S == 1: write gpsky in place (caller strides); S > 1: dense partial slab [split][t][q][f][p]
+    const size_t plane = (size_t)NPP * A.Nf * A.Pstride * G::NC;
+    const bool direct = (A.S == 1);
+    T* dst = direct ? reinterpret_cast<T*>(A.out) + ((size_t)t * A.st_t + (size_t)A.mp * A.st_mp) * G::NC
+                    : reinterpret_cast<T*>(A.ws) + ((size_t)split * A.Nt + t) * plane;
+    const size_t d_pp = direct ? (size_t)A.st_pp : (size_t)A.Nf * A.Pstride;
+    const size_t d_f = direct ? (size_t)A.st_f : (size_t)A.Pstride;
     bool first = true;
     auto flush = [&]() {
 #pragma unroll
@@ -342,7 +346,7 @@ fringe_bwd_kernel(FringeArgs A)
 #pragma unroll
                         for (int c = 0; c < G::NC; ++c) {
                             if (k < nk) {
-                                T* o = dst + (((size_t)q * A.Nf + k0 + k) * A.Pstride + p[j]) * G::NC + c;
+                                T* o = dst + ((size_t)q * d_pp + (size_t)(k0 + k) * d_f + p[j]) * G::NC + c;
                                 T v = acc[j][q][k * G::NC + c];
                                 if (!first) v += *o;
                                 *o = v;
@@ -450,6 +454,24 @@ __global__ void reduce_partials_kernel(const T* __restrict__ ws, T* __restrict__
         T v = T(0);
         for (int s = 0; s < S; ++s) v += ws[((size_t)s * nblk + blk) * len + e];
         out[out_offset + blk * out_blk_stride + e] = v;
+    }
+}
+
+// backward partial slabs [S][Nt][NPP][Nf][Pstride*NC] (dense) -> gpsky with caller strides
+template <typename T>
+__global__ void reduce_bwd_kernel(const T* __restrict__ ws, T* __restrict__ out, int S, int Nt, int NPP,
+                                  int Nf, int PNC, int NC, long long st_t, long long st_pp,
+                                  long long st_f, long long base)
+{
+    const size_t total = (size_t)Nt * NPP * Nf * PNC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        size_t e = i % PNC, r = i / PNC;
+        int f = r % Nf; r /= Nf;
+        int q = r % NPP; int t = r / NPP;
+        T v = T(0);
+        for (int s = 0; s < S; ++s) v += ws[(size_t)s * total + i];
+        out[(base + (size_t)t * st_t + (size_t)q * st_pp + (size_t)f * st_f) * NC + e] = v;
     }
 }
 
@@ -570,9 +592,10 @@ static int launch_bwd_t(const FringeArgs& base, const int* mp_off, int mode, hip
         }
         if (A.S > 1) {
             int nb = (int)std::min<size_t>((plane * A.Nt + 255) / 256, 4096);
-            hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3(nb), dim3(256), 0, st,
+            hipLaunchKernelGGL((reduce_bwd_kernel<T>), dim3(nb), dim3(256), 0, st,
                                reinterpret_cast<const T*>(A.ws), reinterpret_cast<T*>(A.out),
-                               plane, A.S, A.Nt, plane * A.Nmp, plane * (size_t)g);
+                               A.S, A.Nt, NPP, A.Nf, A.Pstride * G::NC, G::NC,
+                               A.st_t, A.st_pp, A.st_f, (long long)g * A.st_mp);
         }
     }
     return check_launch();
@@ -629,7 +652,7 @@ static int fringe_common(bool backward, int dtype, const double* blvecs, const d
                          const double* freqs, const void* in, const int* mp_off, const int* bl_order,
                          int Nbl, int Nt, int Nf, int Pstride, int Nmp, int Npp, int cplx, int sign,
                          int uniform, double freq0, double dfreq, double max_blen,
-                         void* out, void* ws, size_t ws_bytes, void* stream)
+                         const long long* strides, void* out, void* ws, size_t ws_bytes, void* stream)
 {
     if (!blvecs || !sdir || !freqs || !in || !out || !mp_off) return RIME_EINVAL;
     if (Nbl <= 0 || Nt <= 0 || Nf <= 0 || Pstride <= 0 || Nmp <= 0) return RIME_EINVAL;
@@ -643,6 +666,13 @@ static int fringe_common(bool backward, int dtype, const double* blvecs, const d
     A.blvecs = blvecs; A.sdir = sdir; A.freqs = freqs; A.in = in; A.out = out; A.ws = ws;
     A.bl_order = bl_order;
     A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride; A.Nmp = Nmp;
+    if (strides) {
+        A.st_t = strides[0]; A.st_mp = strides[1]; A.st_pp = strides[2]; A.st_f = strides[3];
+        if ((Nf > 1 && A.st_f < Pstride) || (Nt > 1 && A.st_t <= 0) || (Npp > 1 && A.st_pp <= 0) ||
+            (Nmp > 1 && A.st_mp <= 0)) return RIME_EINVAL;
+    } else {
+        A.st_f = Pstride; A.st_pp = (long long)Nf * Pstride; A.st_mp = A.st_pp * Npp; A.st_t = A.st_mp * Nmp;
+    }
     A.sign = (double)sign;
     A.freq0_c = freq0 / 2.99792458e8;
     A.dfreq_c = dfreq / 2.99792458e8;
@@ -663,11 +693,12 @@ extern "C" int rime_fringe_sum_fwd(int dtype, const double* blvecs, const double
                                    int Nbl, int Nt, int Nf, int Pstride, int Nmp, int Npp,
                                    int psky_complex, int sign, int freq_uniform_host,
                                    double freq0_host, double dfreq_host, double max_blen_host,
+                                   const long long* psky_strides_host,
                                    void* vis, void* workspace, size_t workspace_bytes, void* stream)
 {
     return fringe_common(false, dtype, blvecs, sdir, freqs, psky, mp_offsets_host, bl_order, Nbl, Nt,
                          Nf, Pstride, Nmp, Npp, psky_complex, sign, freq_uniform_host, freq0_host,
-                         dfreq_host, max_blen_host, vis, workspace, workspace_bytes, stream);
+                         dfreq_host, max_blen_host, psky_strides_host, vis, workspace, workspace_bytes, stream);
 }
 
 extern "C" int rime_fringe_sum_bwd(int dtype, const double* blvecs, const double* sdir,
@@ -676,11 +707,12 @@ extern "C" int rime_fringe_sum_bwd(int dtype, const double* blvecs, const double
                                    int Nbl, int Nt, int Nf, int Pstride, int Nmp, int Npp,
                                    int psky_complex, int sign, int freq_uniform_host,
                                    double freq0_host, double dfreq_host, double max_blen_host,
+                                   const long long* gpsky_strides_host,
                                    void* gpsky, void* workspace, size_t workspace_bytes, void* stream)
 {
     return fringe_common(true, dtype, blvecs, sdir, freqs, gvis, mp_offsets_host, bl_order, Nbl, Nt,
                          Nf, Pstride, Nmp, Npp, psky_complex, sign, freq_uniform_host, freq0_host,
-                         dfreq_host, max_blen_host, gpsky, workspace, workspace_bytes, stream);
+                         dfreq_host, max_blen_host, gpsky_strides_host, gpsky, workspace, workspace_bytes, stream);
 }
 
 extern "C" int rime_gen_fringe(int dtype, const double* blvecs, const double* sdir,

@@ -99,7 +99,21 @@ class FringeGeometry:
             self.bl_order = torch.as_tensor(order, dtype=torch.int32, device=dev)
 
 
-def _fringe_call(geom, backward, inp, out, Npp, cplx):
+def _dense_strides(t):
+    """element strides (time, model pair, pol product, channel) of a (Nt,Nmp,Npp,Nf,P) tensor whose
+    pixel axis is contiguous, or None when the tensor cannot be passed as is"""
+    if t.stride(-1) != 1:
+        return None
+    st = t.stride()
+    P = t.shape[-1]
+    if t.shape[3] > 1 and st[3] < P:
+        return None
+    if any(s <= 0 and n > 1 for s, n in zip(st[:4], t.shape[:4])):
+        return None
+    return (ctypes.c_longlong * 4)(*[int(max(s, 1)) for s in st[:4]])
+
+
+def _fringe_call(geom, backward, inp, out, Npp, cplx, strides=None):
     code, rdt = _real_dtype(inp)
     fn = lib.rime_fringe_sum_bwd if backward else lib.rime_fringe_sum_fwd
     nbytes = lib.rime_fringe_sum_workspace(code, geom.Nbl, geom.Nt, geom.Nf, geom.Pstride,
@@ -112,7 +126,7 @@ def _fringe_call(geom, backward, inp, out, Npp, cplx):
     rc = fn(code, _ptr(geom.blvecs), _ptr(geom.sdir), _ptr(geom.freqs), _ptr(inp),
             geom.mp_offsets, _ptr(geom.bl_order), geom.Nbl, geom.Nt, geom.Nf, geom.Pstride,
             geom.Nmp, Npp, int(cplx), geom.sign, int(geom.uniform), geom.f0, geom.df,
-            geom.max_blen, _ptr(out), _ptr(ws), ws.numel(), _stream())
+            geom.max_blen, strides, _ptr(out), _ptr(ws), ws.numel(), _stream())
     check(rc, 'rime_fringe_sum_bwd' if backward else 'rime_fringe_sum_fwd')
     if prof is not None:
         e1.record()
@@ -129,22 +143,28 @@ class _FringeSum(torch.autograd.Function):
             'psky %s does not match geometry (Nt=%d, Nmp=%d, Nf=%d, Pstride=%d)' % (
                 tuple(psky.shape), geom.Nt, geom.Nmp, geom.Nf, geom.Pstride)
         cplx = psky.is_complex()
-        p = psky.detach().contiguous()
+        p = psky.detach()
+        strides = _dense_strides(p)          # permuted (e.g. time-inner) layouts are read in place
+        if strides is None:
+            p = p.contiguous()
+            strides = _dense_strides(p)
         _, rdt = _real_dtype(p)
         cdt = torch.complex64 if rdt == torch.float32 else torch.complex128
         vis = torch.empty((Npp, geom.Nbl, Nt, Nf), dtype=cdt, device=p.device)
         _fringe_call(geom, False, torch.view_as_real(p) if cplx else p, torch.view_as_real(vis),
-                     Npp, cplx)
-        ctx.geom, ctx.cplx, ctx.shape, ctx.dtype = geom, cplx, tuple(psky.shape), psky.dtype
+                     Npp, cplx, strides)
+        ctx.geom, ctx.cplx, ctx.dtype = geom, cplx, psky.dtype
+        ctx.pshape, ctx.pstride = tuple(p.shape), tuple(p.stride())   # gradient buffer template only
         return vis
 
     @staticmethod
     def backward(ctx, gvis):
         geom = ctx.geom
         g = gvis.contiguous()
-        gp = torch.empty(ctx.shape, dtype=ctx.dtype, device=g.device)
+        gp = torch.empty_strided(ctx.pshape, ctx.pstride, dtype=ctx.dtype, device=g.device)
         _fringe_call(geom, True, torch.view_as_real(g),
-                     torch.view_as_real(gp) if ctx.cplx else gp, ctx.shape[2], ctx.cplx)
+                     torch.view_as_real(gp) if ctx.cplx else gp, ctx.pshape[2], ctx.cplx,
+                     _dense_strides(gp))
         return gp, None
 
 

@@ -168,6 +168,46 @@ class RIME(utils.Module):
             self._zenaz_cache[key] = za
         return za
 
+    def _batch_geometry(self, name, ra, dec, Npix, dev, pairs, bl_mp):
+        """
+        Geometry of one (baseline group, time group, sky component), built once and cached:
+        per time step the FoV cut (strict zen < fov/2, beam_model.py:221-224), the cut angles and
+        the float64 pointing vectors (telescope_model.py:337-343), padded to a common stride Ps
+        (multiple of 64) and concatenated over the Nt time steps of the minibatch.
+        """
+        gkey = (self.bl_group_id, self.time_group_id, name, Npix)
+        bg = self._geom_cache.get(gkey)
+        if bg is not None:
+            return bg
+        keys = [(name, Npix, float(t)) for t in self.sim_times]
+        za = [self._zenaz(k, t, ra, dec, dev) for k, t in zip(keys, self.sim_times)]
+        cuts = []
+        for k, (zen, az) in zip(keys, za):
+            cut = self.beam.fov_cut(zen)
+            cuts.append(torch.arange(Npix, device=dev) if isinstance(cut, slice) else cut.to(dev))
+            self._npix_cache[k] = int(cuts[-1].numel())
+        Nt = len(keys)
+        Ps = ops.pad_to_tile(max(max(c.numel() for c in cuts), 1))
+        zen_all = torch.zeros(Nt * Ps, dtype=torch.float64, device=dev)
+        az_all = torch.zeros(Nt * Ps, dtype=torch.float64, device=dev)
+        cut_all = torch.full((Nt * Ps,), Npix, dtype=torch.int64, device=dev)
+        sdir = torch.zeros(Nt, 3, Ps, dtype=torch.float64, device=dev)
+        for j, ((zen, az), cut) in enumerate(zip(za, cuts)):
+            P = cut.numel()
+            zc, ac = zen[cut], az[cut]
+            zen_all[j * Ps:j * Ps + P] = zc
+            az_all[j * Ps:j * Ps + P] = ac
+            cut_all[j * Ps:j * Ps + P] = cut
+            sdir[j, :, :P] = telescope_model.pointing_vectors(zc, ac)
+        # cache key for the interpolation stencil / Ylm of this angle set (rime_model.py:345-357
+        # uses (sky name, Npix, time) per time step; here the whole time group is one set)
+        zen_all._arr_hash = ('rime-batch', name, Npix, tuple(float(t) for t in self.sim_times), Ps)
+        geom = ops.FringeGeometry(self.sim_blvecs.to(dev), sdir, self.freqs, bl_mp=bl_mp,
+                                  Nmp=len(pairs), npix=[c.numel() for c in cuts])
+        bg = dict(zen=zen_all, az=az_all, cut=cut_all, geom=geom, Nt=Nt, Ps=Ps)
+        self._geom_cache[gkey] = bg
+        return bg
+
     def forward(self, *args, prior_cache=None, **kwargs):
         """sky -> beam -> fused fringe sum -> VisData (rime_model.py:291-389)"""
         self._set_group()
@@ -190,48 +230,21 @@ class RIME(utils.Module):
             dev = self._compute_device(sky)
             ra, dec = comp.angs
             Npix = len(ra)
-            keys = [(comp.name, Npix, float(t)) for t in self.sim_times]
-            # pass 1: angles and FoV-cut sizes -> common padded pixel stride
-            za = [self._zenaz(k, t, ra, dec, dev) for k, t in zip(keys, self.sim_times)]
-            for k, (zen, az) in zip(keys, za):
-                if k not in self._npix_cache:
-                    cut = self.beam.fov_cut(zen)
-                    self._npix_cache[k] = Npix if isinstance(cut, slice) else int(cut.numel())
-            Ps = ops.pad_to_tile(max(max(self._npix_cache[k] for k in keys), 1))
-            # sky with one trailing zero column: padded FoV-cut indices point at it
+            bg = self._batch_geometry(comp.name, ra, dec, Npix, dev, pairs, bl_mp)
+            if self.verbose:
+                log('{} times for {}/{} sky model | {} elapsed'.format(
+                    len(self.sim_times), i + 1, len(comps), elapsed_time(start)), verbose=True)
+            # beam at the FoV-cut angles of ALL time steps: one response evaluation / gather launch
+            beam = self.beam.eval_response(bg['zen'], bg['az'], prior_cache=prior_cache)
+            # sky with one trailing zero column: padded cut indices point at it
             sky_ext = torch.cat([sky, sky.new_zeros(sky.shape[:-1] + (1,))], dim=-1)
-            psky_t, sdir_t, npix_t = [], [], []
-            gkey = (self.bl_group_id, self.time_group_id, comp.name, Npix, Ps)
-            geom = self._geom_cache.get(gkey)
-            for j, (k, (zen, az)) in enumerate(zip(keys, za)):
-                if self.verbose:
-                    log('{}/{} times for {}/{} sky model | {} elapsed'.format(
-                        j + 1, len(keys), i + 1, len(comps), elapsed_time(start)), verbose=True)
-                zen._arr_hash = k                                   # rime_model.py:351
-                beam, cut, zc, ac = self.beam.gen_beam(zen, az, prior_cache=prior_cache, out_stride=Ps)
-                zc._arr_hash = k                                    # rime_model.py:357
-                P = zc.shape[0]
-                if beam.shape[-1] != Ps:
-                    beam = torch.nn.functional.pad(beam, (0, Ps - beam.shape[-1]))
-                if isinstance(cut, slice):
-                    cut = torch.arange(Npix, device=dev)
-                cutp = torch.full((Ps,), Npix, dtype=torch.int64, device=dev)
-                cutp[:P] = cut.to(dev)
-                cut_sky = sky_ext.index_select(-1, cutp)             # beam_model.cut_sky_fov + padding
-                psky_t.append(self.beam.apply_beam_mp(beam, cut_sky, pairs))
-                if geom is None:
-                    s = self.array.get_s(zc, ac).to(dev)
-                    sdir_t.append(torch.nn.functional.pad(s, (0, Ps - P)))
-                    npix_t.append(P)
-            if geom is None:
-                geom = ops.FringeGeometry(self.sim_blvecs.to(dev), torch.stack(sdir_t), self.freqs,
-                                          bl_mp=bl_mp, Nmp=len(pairs), npix=npix_t)
-                self._geom_cache[gkey] = geom
-            # (Nt, Npol, Npol|1, Nmp, Nf, Ps) -> (Nt, Nmp, Npp, Nf, Ps)
-            ps = torch.stack(psky_t)
-            Nt, n1, n2, Nmp, Nf, _ = ps.shape
-            ps = ps.permute(0, 3, 1, 2, 4, 5).reshape(Nt, Nmp, n1 * n2, Nf, Ps)
-            v = ops.fringe_sum(ps, geom)                            # (Npp, Nbl, Nt, Nf)
+            cut_sky = sky_ext.index_select(-1, bg['cut'])            # beam_model.cut_sky_fov, all times
+            ps = self.beam.apply_beam_mp(beam, cut_sky, pairs)       # (n1, n2, Nmp, Nf, Nt*Ps)
+            n1, n2, Nmp, Nf = ps.shape[:4]
+            Nt, Ps = bg['Nt'], bg['Ps']
+            # -> (Nt, Nmp, Npp, Nf, Ps) as a strided VIEW: the fringe kernels take the strides
+            ps = ps.reshape(n1 * n2, Nmp, Nf, Nt, Ps).permute(3, 1, 0, 2, 4)
+            v = ops.fringe_sum(ps, bg['geom'])                       # (Npp, Nbl, Nt, Nf)
             v = v.reshape(n1, n2, v.shape[1], Nt, Nf)
             vis = v if vis is None else vis + v
 

@@ -54,7 +54,10 @@ const char* rime_last_error(void);
  *   freqs    f64 [Nf]                Hz
  *   psky     T   [Nt, Nmp, Npp, Nf, Pstride]      (real)   or
  *            T   [Nt, Nmp, Npp, Nf, Pstride, 2]   (complex, interleaved) perceived sky =
- *                                    apply_beam output per beam-model pair; padded columns 0
+ *                                    apply_beam output per beam-model pair; padded columns 0.
+ *            psky_strides_host: NULL for that dense layout, or 4 element strides (HOST)
+ *                                    {time, model pair, pol product, channel} of a permuted /
+ *                                    strided buffer; the pixel axis is always contiguous.
  *   mp_offsets_host  int[Nmp+1] (HOST) baselines of model pair g are bl_order[off[g] .. off[g+1])
  *   bl_order int [Nbl] or NULL       baseline index per slot (NULL: identity; needs Nmp == 1
  *                                    or baselines already grouped by model pair)
@@ -74,7 +77,7 @@ int rime_fringe_sum_fwd(int dtype,
                         int Nbl, int Nt, int Nf, int Pstride, int Nmp, int Npp,
                         int psky_complex, int sign,
                         int freq_uniform_host, double freq0_host, double dfreq_host,
-                        double max_blen_host,
+                        double max_blen_host, const long long* psky_strides_host,
                         void* vis, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -91,7 +94,7 @@ int rime_fringe_sum_bwd(int dtype,
                         int Nbl, int Nt, int Nf, int Pstride, int Nmp, int Npp,
                         int psky_complex, int sign,
                         int freq_uniform_host, double freq0_host, double dfreq_host,
-                        double max_blen_host,
+                        double max_blen_host, const long long* gpsky_strides_host,
                         void* gpsky, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -52,10 +52,10 @@ def test_bad_arguments_are_rejected_without_launching():
     off = (ctypes.c_int * 2)(0, 4)
     one = ctypes.c_void_p(8)      # non-null dummy; never dereferenced on a rejected call
     rc = lib.rime_fringe_sum_fwd(0, one, one, one, one, off, None, 4, 1, 8, 100, 1, 1, 0, 1,
-                                 1, 1e8, 1e6, 10.0, one, one, 0, None)
+                                 1, 1e8, 1e6, 10.0, None, one, one, 0, None)
     assert rc == -1                # Pstride not a multiple of 64
     rc = lib.rime_fringe_sum_fwd(0, one, one, one, one, off, None, 4, 1, 8, 128, 1, 3, 0, 1,
-                                 1, 1e8, 1e6, 10.0, one, one, 0, None)
+                                 1, 1e8, 1e6, 10.0, None, one, one, 0, None)
     assert rc == -1                # Npp = 3
     rc = lib.rime_interp_gather_fwd(0, 0, one, one, one, 2, 10, 5, 4, one, 3, None)
     assert rc == -1                # out_stride < P

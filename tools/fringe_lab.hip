@@ -91,6 +91,7 @@ int main()
     FringeArgs A{};
     A.blvecs = dbl; A.sdir = dsd; A.freqs = dfr; A.in = dps; A.out = dvis; A.ws = dws; A.bl_order = nullptr;
     A.bl_off = 0; A.bl_cnt = pr.Nbl; A.mp = 0; A.Nbl = pr.Nbl; A.Nt = pr.Nt; A.Nf = pr.Nf; A.Pstride = pr.P; A.Nmp = 1;
+    A.st_f = pr.P; A.st_pp = (long long)pr.Nf * pr.P; A.st_mp = A.st_pp; A.st_t = A.st_mp;
     A.sign = 1.0; A.freq0_c = fr[0] / 2.99792458e8; A.dfreq_c = (fr[1] - fr[0]) / 2.99792458e8;
 
     {   // backward: in = gvis [1,Nbl,Nt,Nf] complex, out = gpsky
