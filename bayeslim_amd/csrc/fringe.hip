@@ -33,7 +33,14 @@ constexpr int TP = 64;            // pixels per LDS tile (forward)
 constexpr int TB = 64;            // baselines per LDS tile (backward)
 constexpr int FLUSH_TILES = 32;   // flush accumulators every 32 tiles = 2048 terms
 
-enum { MODE_DIRECT = 0, MODE_ROT = 1, MODE_LIFT = 2 };
+// MODE_*_NU ("near uniform"): channel centres deviate from a uniform grid by tiny residuals
+// (e.g. a float32-rounded linspace: +-8 Hz at 180 MHz).  The rotation recurrence runs on the
+// fitted uniform grid and each channel gets the first-order phase correction
+// (x, y) -> (x - phi y, y + phi x), phi = 2 pi tau eps_k / c; the caller guarantees |phi| < 2e-3
+// so the neglected phi^2/2 stays below 2e-6.
+enum { MODE_DIRECT = 0, MODE_ROT = 1, MODE_LIFT = 2, MODE_ROT_NU = 3, MODE_LIFT_NU = 4 };
+constexpr bool mode_is_lift(int m) { return m == MODE_LIFT || m == MODE_LIFT_NU; }
+constexpr bool mode_is_nu(int m) { return m == MODE_ROT_NU || m == MODE_LIFT_NU; }
 
 struct FringeArgs {
     const double* blvecs;
@@ -78,11 +85,22 @@ __device__ __forceinline__ T reduce_turns(double ph)
 // One (baseline, pixel) pair: generate the CH fringe values of the chunk and hand each to
 // `sink(k, x, y)` (x = Re F, y = Im F).  `tau` = sign * b.s [m]; nu_c = anchor freq / c;
 // dnu = channel spacing / c; fk_c = per-channel freq / c table (MODE_DIRECT only).
-template <typename T, int CH, int MODE, bool NOROT = false, typename Sink>
+template <typename T, int CH, int MODE, bool NOROT = false, typename Sink0>
 __device__ __forceinline__ void fringe_chunk(double tau, double nu_c, double dnu,
-                                             const double* __restrict__ fk_c, Sink&& sink)
+                                             const double* __restrict__ fk_c, Sink0&& sink0)
 {
     constexpr int KC = CH / 2;
+    // near-uniform grids: first-order per-channel phase correction in front of the consumer
+    const T* e_tab = reinterpret_cast<const T*>(fk_c);
+    const T tauf = (T)tau;
+    auto sink = [&](int k, T x, T y) {
+        if constexpr (mode_is_nu(MODE)) {
+            const T ph = tauf * e_tab[k];
+            sink0(k, tfma<T>(-ph, y, x), tfma<T>(ph, x, y));
+        } else {
+            sink0(k, x, y);
+        }
+    };
     if constexpr (NOROT) {       // lab ablation: anchor only, every channel gets the same phasor
         T zs, zc;
         sincos_turns(reduce_turns<T>(tau * nu_c), zs, zc);
@@ -100,14 +118,14 @@ __device__ __forceinline__ void fringe_chunk(double tau, double nu_c, double dnu
     } else {
         T zs, zc, ws, wc;
         sincos_turns(reduce_turns<T>(tau * nu_c), zs, zc);
-        if constexpr (MODE == MODE_LIFT) {
+        if constexpr (mode_is_lift(MODE)) {
             // the host guarantees |step| < 0.3 turn here: no range reduction needed
             sincos_turns((T)(tau * dnu), ws, wc);
         } else {
             sincos_turns(reduce_turns<T>(tau * dnu), ws, wc);
         }
         sink(KC, zc, zs);
-        if constexpr (MODE == MODE_LIFT) {
+        if constexpr (mode_is_lift(MODE)) {
             // rotation by +-theta as three shears
             T a = -ws * __builtin_amdgcn_rcpf(T(1) + wc);
             T x = zc, y = zs;
@@ -191,6 +209,11 @@ fringe_fwd_kernel(FringeArgs A)
     if constexpr (MODE == MODE_DIRECT) {
         for (int i = tid; i < CH; i += blockDim.x)
             f_lds[i] = (i < nk) ? A.freqs[k0 + i] * (1.0 / 2.99792458e8) : 0.0;
+    } else if constexpr (mode_is_nu(MODE)) {
+        T* e_lds = reinterpret_cast<T*>(f_lds);
+        for (int i = tid; i < CH; i += blockDim.x)
+            e_lds[i] = (i < nk) ? (T)(6.283185307179586 * (A.freqs[k0 + i] * (1.0 / 2.99792458e8)
+                                      - (A.freq0_c + (double)(k0 + i) * A.dfreq_c))) : T(0);
     }
 
     T accr[NPP][CH], acci[NPP][CH];
@@ -306,6 +329,11 @@ fringe_bwd_kernel(FringeArgs A)
     if constexpr (MODE == MODE_DIRECT) {
         for (int i = tid; i < CH; i += blockDim.x)
             f_lds[i] = (i < nk) ? A.freqs[k0 + i] * (1.0 / 2.99792458e8) : 0.0;
+    } else if constexpr (mode_is_nu(MODE)) {
+        T* e_lds = reinterpret_cast<T*>(f_lds);
+        for (int i = tid; i < CH; i += blockDim.x)
+            e_lds[i] = (i < nk) ? (T)(6.283185307179586 * (A.freqs[k0 + i] * (1.0 / 2.99792458e8)
+                                      - (A.freq0_c + (double)(k0 + i) * A.dfreq_c))) : T(0);
     }
 
     int p[PIX];
@@ -545,14 +573,23 @@ static int launch_fwd_t(const FringeArgs& base, const int* mp_off, int mode, hip
         const int block = A.bl_cnt >= 256 ? 256 : ((A.bl_cnt + 63) / 64) * 64;
         dim3 grid((A.bl_cnt + block - 1) / block, (A.Nf + CH - 1) / CH, A.Nt * A.S);
         size_t lds = (3 * TP + CH) * sizeof(double) + (size_t)TP * G::ASTRIDE * sizeof(T);
-        if (mode == MODE_LIFT && sizeof(T) == 4) {
-            if constexpr (sizeof(T) == 4)
-                hipLaunchKernelGGL((fringe_fwd_kernel<T, NPP, CPLX, CH, MODE_LIFT>), grid, dim3(block), lds, st, A);
-        } else if (mode == MODE_DIRECT) {
-            hipLaunchKernelGGL((fringe_fwd_kernel<T, NPP, CPLX, CH, MODE_DIRECT>), grid, dim3(block), lds, st, A);
+#define RIME_FWD(M) hipLaunchKernelGGL((fringe_fwd_kernel<T, NPP, CPLX, CH, M>), grid, dim3(block), lds, st, A)
+        if constexpr (sizeof(T) == 4) {
+            switch (mode) {
+                case MODE_LIFT: RIME_FWD(MODE_LIFT); break;
+                case MODE_LIFT_NU: RIME_FWD(MODE_LIFT_NU); break;
+                case MODE_ROT_NU: RIME_FWD(MODE_ROT_NU); break;
+                case MODE_DIRECT: RIME_FWD(MODE_DIRECT); break;
+                default: RIME_FWD(MODE_ROT); break;
+            }
         } else {
-            hipLaunchKernelGGL((fringe_fwd_kernel<T, NPP, CPLX, CH, MODE_ROT>), grid, dim3(block), lds, st, A);
+            switch (mode) {          // f64: the shear rotation is an f32 device (hardware rcp)
+                case MODE_LIFT_NU: case MODE_ROT_NU: RIME_FWD(MODE_ROT_NU); break;
+                case MODE_DIRECT: RIME_FWD(MODE_DIRECT); break;
+                default: RIME_FWD(MODE_ROT); break;
+            }
         }
+#undef RIME_FWD
     }
     if (pl.S > 1) {
         int nb = (int)std::min<size_t>((vis_elems + 255) / 256, 4096);
@@ -582,14 +619,23 @@ static int launch_bwd_t(const FringeArgs& base, const int* mp_off, int mode, hip
         size_t lds = (3 * TB + CH) * sizeof(double) + (size_t)TB * G::GSTRIDE * sizeof(T);
         // 4 waves/SIMD (<=128 VGPRs, a few spilled dwords) beat 3 at 136 VGPRs: 66.4 vs 71.9 ms (lab)
         constexpr int WPS = (sizeof(T) == 4 && NPP * (CPLX ? 2 : 1) * CH <= 32) ? 4 : 1;
-        if (mode == MODE_LIFT && sizeof(T) == 4) {
-            if constexpr (sizeof(T) == 4)
-                hipLaunchKernelGGL((fringe_bwd_kernel<T, NPP, CPLX, CH, MODE_LIFT, PIX, WPS>), grid, dim3(pl.block), lds, st, A);
-        } else if (mode == MODE_DIRECT) {
-            hipLaunchKernelGGL((fringe_bwd_kernel<T, NPP, CPLX, CH, MODE_DIRECT, PIX>), grid, dim3(pl.block), lds, st, A);
+#define RIME_BWD(M, W) hipLaunchKernelGGL((fringe_bwd_kernel<T, NPP, CPLX, CH, M, PIX, W>), grid, dim3(pl.block), lds, st, A)
+        if constexpr (sizeof(T) == 4) {
+            switch (mode) {
+                case MODE_LIFT: RIME_BWD(MODE_LIFT, WPS); break;
+                case MODE_LIFT_NU: RIME_BWD(MODE_LIFT_NU, WPS); break;
+                case MODE_ROT_NU: RIME_BWD(MODE_ROT_NU, WPS); break;
+                case MODE_DIRECT: RIME_BWD(MODE_DIRECT, 1); break;
+                default: RIME_BWD(MODE_ROT, WPS); break;
+            }
         } else {
-            hipLaunchKernelGGL((fringe_bwd_kernel<T, NPP, CPLX, CH, MODE_ROT, PIX, WPS>), grid, dim3(pl.block), lds, st, A);
+            switch (mode) {
+                case MODE_LIFT_NU: case MODE_ROT_NU: RIME_BWD(MODE_ROT_NU, 1); break;
+                case MODE_DIRECT: RIME_BWD(MODE_DIRECT, 1); break;
+                default: RIME_BWD(MODE_ROT, 1); break;
+            }
         }
+#undef RIME_BWD
         if (A.S > 1) {
             int nb = (int)std::min<size_t>((plane * A.Nt + 255) / 256, 4096);
             hipLaunchKernelGGL((reduce_bwd_kernel<T>), dim3(nb), dim3(256), 0, st,
@@ -677,10 +723,11 @@ static int fringe_common(bool backward, int dtype, const double* blvecs, const d
     A.freq0_c = freq0 / 2.99792458e8;
     A.dfreq_c = dfreq / 2.99792458e8;
     int mode = MODE_DIRECT;
-    if (uniform) {
-        mode = MODE_ROT;
+    if (uniform == 1 || uniform == 2) {
+        const bool nu = (uniform == 2);
+        mode = nu ? MODE_ROT_NU : MODE_ROT;
         // lifting needs |step| comfortably below half a turn: tan(pi*step) stays O(1)
-        if (max_blen > 0 && max_blen * fabs(A.dfreq_c) < 0.3) mode = MODE_LIFT;
+        if (max_blen > 0 && max_blen * fabs(A.dfreq_c) < 0.3) mode = nu ? MODE_LIFT_NU : MODE_LIFT;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == RIME_F32) return dispatch<float>(backward, A, mp_off, Npp, cplx, mode, st, ws_bytes);

@@ -75,15 +75,21 @@ class FringeGeometry:
         # algorithmic fringe elements per launch: Nbl x Nf x (valid pixels summed over times)
         nvalid = int(sum(npix)) if npix is not None else self.Nt * self.Pstride
         self.elements = self.Nbl * self.Nf * nvalid
-        # uniform channel spacing enables the rotation recurrence
-        if len(fh) > 1:
-            d = np.diff(fh)
-            self.uniform = bool(np.all(np.abs(d - d[0]) <= 1e-9 * max(abs(d[0]), 1.0)))
-            self.df = float((fh[-1] - fh[0]) / (len(fh) - 1))
-        else:
-            self.uniform, self.df = True, 0.0
-        self.f0 = float(fh[0])
         self.max_blen = float(torch.linalg.norm(self.blvecs, dim=1).max().item())
+        # channel grid: 1 = exactly uniform (rotation recurrence), 2 = uniform up to tiny residuals
+        # (float32-rounded linspace: recurrence + first-order correction), 0 = arbitrary
+        self.f0 = float(fh[0])
+        if len(fh) > 1:
+            self.df = float((fh[-1] - fh[0]) / (len(fh) - 1))
+            eps = np.abs(fh - (self.f0 + self.df * np.arange(len(fh)))).max()
+            if eps <= 1e-9 * max(abs(self.df), 1.0):
+                self.uniform = 1
+            elif 2 * np.pi * eps * max(self.max_blen, 1.0) / 2.99792458e8 < 2e-3 and self.df != 0:
+                self.uniform = 2
+            else:
+                self.uniform = 0
+        else:
+            self.uniform, self.df = 1, 0.0
         # model-pair grouping
         self.Nmp = int(Nmp)
         if bl_mp is None or self.Nmp == 1:

@@ -62,8 +62,11 @@ const char* rime_last_error(void);
  *   bl_order int [Nbl] or NULL       baseline index per slot (NULL: identity; needs Nmp == 1
  *                                    or baselines already grouped by model pair)
  *   vis      complex<T> [Npp, Nbl, Nt, Nf]  (interleaved re, im)
- *   freq_uniform_host: 1 if freqs are uniformly spaced (enables the rotation recurrence);
- *                    freq0_host / dfreq_host give the first channel and spacing [Hz].
+ *   freq_uniform_host: 0 = arbitrary channel centres (one sincos per element);
+ *                    1 = exactly uniform grid freq0_host + k * dfreq_host (rotation recurrence);
+ *                    2 = near-uniform: freqs[k] = freq0 + k * dfreq + eps_k with
+ *                        2 pi max|eps_k| max_blen / c < 2e-3 (e.g. a float32-rounded linspace):
+ *                        recurrence on the fitted grid + first-order per-channel correction.
  *   max_blen_host: upper bound on |blvecs[b]| [m] (<= 0: unknown).  Lets the library pick the
  *                    3-FMA shear rotation when max_blen * |dfreq| / c < 0.3 turn per channel.
  *   workspace: at least rime_fringe_sum_workspace(...) bytes.
