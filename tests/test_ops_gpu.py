@@ -125,7 +125,6 @@ def test_fringe_sum_long_baselines_and_conj(ops, dtype):
     assert relmax(vis, ref) < (1e-10 if dtype == 'f64' else 1e-5)
 
 
-@pytest.mark.parametrize('dtype', ['f64', 'f32'])
 def test_fringe_sum_strided_psky(ops):
     """time-inner (Npp, Nmp, Nf, Nt, P) storage passed as a permuted view: read in place"""
     blvecs, freqs, zenaz, psky, bl_mp = make_case(21, Nbl=40, Nt=3, Nf=20, P=150, Nmp=2, Npp=1,
