@@ -291,8 +291,10 @@ class _Alm2Pix(torch.autograd.Function):
         Nc, Npix = Y.shape
         ga = torch.empty(ctx.shape, dtype=ctx.dtype, device=g.device)
         R = int(np.prod(ctx.shape[:-1])) if len(ctx.shape) > 1 else 1
+        nbytes = lib.rime_alm2pix_bwd_workspace(code, R, Nc, Npix)
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=g.device)
         rc = lib.rime_alm2pix_bwd(code, _ptr(g), _ptr(torch.view_as_real(Y)), R, Nc, Npix,
-                                  _ptr(torch.view_as_real(ga)), _stream())
+                                  _ptr(torch.view_as_real(ga)), _ptr(ws), ws.numel(), _stream())
         check(rc, 'rime_alm2pix_bwd')
         return ga, None
 

@@ -292,8 +292,18 @@ def main():
         n, ms, elems = kstat[dom]
         flop_per_elem = 10.0                 # 6 (phase rotation) + 4 (real psky accumulate), SURVEY 8(d)
         achieved = elems * flop_per_elem / (ms * 1e-3) / 1e12
+        # HBM traffic of that kernel per launch: PMC counters cannot be read from inside the
+        # process; the committed summary of the separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`
+        # passes over this same command is used when it matches the workload (else null)
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01', 'traffic.json')
+        if args.workload == 'c4' and world == 1 and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
         roof = dict(bound='mfma', kernel=dom, achieved=round(achieved, 2), peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=round(achieved / FP32_PEAK_TFLOPS, 4), traffic=None,
+                    frac=round(achieved / FP32_PEAK_TFLOPS, 4), traffic=traffic,
                     launches=n, avg_launch_ms=round(ms / n, 4), elements_per_launch=elems // n,
                     flop_per_element=flop_per_elem,
                     hbm_equiv_frac=round(elems * 16.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),

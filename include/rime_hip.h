@@ -133,12 +133,16 @@ int rime_interp_scatter_bwd(int dtype, int is_complex, const void* gout, int out
  *   (an elementwise torch op, kept in autograd).
  * Replaces AlmModel.forward_alm (sph_harm.py:1342-1372), real_output=True branch.
  *   alm  T [R, Ncoeff, 2] (interleaved complex);  Ylm T [Ncoeff, Npix, 2];  out T [R, Npix]
- * Backward: galm[r, c] = sum_j gout[r, j] * conj(Ylm[c, j])   (complex, interleaved)
+ * Backward: galm[r, c] = sum_j gout[r, j] * conj(Ylm[c, j])   (complex, interleaved); the pixel
+ *   axis may be split over blocks, partial sums go to a caller-owned workspace
+ *   (rime_alm2pix_bwd_workspace bytes) and are reduced deterministically.
+ * float32 runs on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32); float64 on the VALU.
  * ------------------------------------------------------------------------------------- */
 int rime_alm2pix_fwd(int dtype, const void* alm, const void* Ylm, int R, int Ncoeff, int Npix,
                      void* out, void* stream);
+size_t rime_alm2pix_bwd_workspace(int dtype, int R, int Ncoeff, int Npix);
 int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, int R, int Ncoeff, int Npix,
-                     void* galm, void* stream);
+                     void* galm, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -286,6 +286,31 @@ def test_alm2pix_larger_random(ops):
         assert relmax(x.grad, ar.grad) < tol
 
 
+@pytest.mark.parametrize('R,lmax,Npix', [(128, 24, 3000), (40, 12, 1111), (3, 40, 5000)])
+def test_alm2pix_mfma_shapes(ops, R, lmax, Npix):
+    """float32 path = f32 matrix cores: row-tile counts 4 / 2 / 1, ragged pixel and coefficient tails,
+    pixel-split backward"""
+    rng = np.random.default_rng(R)
+    l, m = orc.gen_lm(lmax)
+    th, ph = np.arccos(rng.uniform(-1, 1, Npix)), rng.uniform(0, 2 * np.pi, Npix)
+    Y = torch.as_tensor(orc.sph_Ylm(th, ph, l, m))
+    a = torch.as_tensor(rng.normal(size=(R, len(l))) + 1j * rng.normal(size=(R, len(l))))
+    ar = a.clone().requires_grad_(True)
+    ref = orc.forward_alm(ar, Y)
+    gv = T64(rng.normal(size=tuple(ref.shape)))
+    (ref * gv).sum().backward()
+    x = a.to(torch.complex64).cuda().requires_grad_(True)
+    y = ops.alm2pix(x, Y.to(torch.complex64).cuda())
+    assert relmax(y, ref) < 1e-5
+    (y * gv.float().cuda()).sum().backward()
+    assert relmax(x.grad, ar.grad) < 1e-5
+    g1 = x.grad.clone()
+    x.grad = None
+    y = ops.alm2pix(x, Y.to(torch.complex64).cuda())
+    (y * gv.float().cuda()).sum().backward()
+    assert torch.equal(g1, x.grad)                      # deterministic
+
+
 def test_ops_refuse_cpu_tensors(ops):
     with pytest.raises(RuntimeError):
         ops.alm2pix(torch.zeros(2, 3, dtype=torch.complex64), torch.zeros(3, 4, dtype=torch.complex64))
