@@ -139,9 +139,21 @@ alm2pix_fwd_mfma_kernel(const float* __restrict__ alm, const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
+    // Ylm fragments of one chunk live in registers and are fetched one chunk ahead, so the
+    // 32 independent 256-B reads of chunk k+1 are in flight under the MFMAs of chunk k
+    float bcur[CT], bnxt[CT];
+    auto load_b = [&](int c0, float (&b)[CT]) {
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) {
+            const int c = min(c0 + cc, Ncoeff - 1);
+            b[cc] = Ylm[((size_t)c * Npix + jl) * 2 + ri];
+        }
+    };
+    load_b(0, bcur);
     for (int c0 = 0; c0 < Ncoeff; c0 += CT) {
         __syncthreads();
         // stage alm[r0 .. r0+ROWS, c0 .. c0+CT] -> a_lds[(cc*2+q)*RP + row], imaginary part negated
+        // (coefficients past Ncoeff are zero-filled, so the clamped Ylm prefetch contributes 0)
         for (int i = tid; i < ROWS * CT * 2; i += 256) {
             const int e = i % (CT * 2), row = i / (CT * 2);
             const int c = c0 + (e >> 1), r = r0 + row;
@@ -149,17 +161,18 @@ alm2pix_fwd_mfma_kernel(const float* __restrict__ alm, const float* __restrict__
             if (c < Ncoeff && r < R) v = alm[((size_t)r * Ncoeff + c) * 2 + (e & 1)];
             a_lds[e * RP + row] = (e & 1) ? -v : v;
         }
+        if (c0 + CT < Ncoeff) load_b(c0 + CT, bnxt);
         __syncthreads();
-        const int nc = min(CT, Ncoeff - c0);
-#pragma unroll 4
-        for (int cc = 0; cc < nc; ++cc) {
-            const float b = Ylm[((size_t)(c0 + cc) * Npix + jl) * 2 + ri];
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const float a = a_lds[(cc * 2 + ri) * RP + m * 32 + (lane & 31)];
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bcur[cc], acc[m], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) bcur[cc] = bnxt[cc];
     }
     const int col = j0 + (lane & 31);
     if (col < Npix) {
@@ -199,20 +212,46 @@ alm2pix_bwd_mfma_kernel(const float* __restrict__ gout, const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const int n = lane & 31, kk = lane >> 5;
-    for (int jt = jbeg; jt < jend; jt += KT) {
-        __syncthreads();
-        for (int i = tid; i < ROWS * KT; i += nthr) {
+    // global -> registers -> LDS, one tile ahead: the loads of tile t+1 are issued before the
+    // MFMAs of tile t and written to LDS after them (single LDS buffer, two barriers per tile)
+    constexpr int NG = (ROWS * KT) / (64 * MT);        // gout values per thread per tile (= 32)
+    constexpr int NY = (16 * KT * 2) / (64 * MT);      // Ylm values per thread per tile
+    float gq[NG], yq[NY];
+    auto fetch = [&](int jt) {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int i = tid + u * nthr;
             const int jj = i % KT, row = i / KT;
             const int r = r0 + row, j = jt + jj;
-            g_lds[row * GP + jj] = (r < R && j < jend) ? gout[(size_t)r * Npix + j] : 0.f;
+            gq[u] = (r < R && j < jend) ? gout[(size_t)r * Npix + j] : 0.f;
         }
-        for (int i = tid; i < 16 * KT * 2; i += nthr) {
+#pragma unroll
+        for (int u = 0; u < NY; ++u) {
+            const int i = tid + u * nthr;
             const int e = i % (KT * 2), cc = i / (KT * 2);
             const int c = c0 + cc, j = jt + (e >> 1);
-            float v = (c < Ncoeff && j < jend) ? Ylm[((size_t)c * Npix + jt) * 2 + e] : 0.f;
-            y_lds[cc * YP + e] = (e & 1) ? -v : v;
+            const float v = (c < Ncoeff && j < jend) ? Ylm[((size_t)c * Npix + jt) * 2 + e] : 0.f;
+            yq[u] = (e & 1) ? -v : v;
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int i = tid + u * nthr;
+            g_lds[(i / KT) * GP + (i % KT)] = gq[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NY; ++u) {
+            const int i = tid + u * nthr;
+            y_lds[(i / (KT * 2)) * YP + (i % (KT * 2))] = yq[u];
+        }
+    };
+    if (jbeg < jend) fetch(jbeg);
+    for (int jt = jbeg; jt < jend; jt += KT) {
+        __syncthreads();                     // previous tile fully consumed
+        commit();
         __syncthreads();
+        if (jt + KT < jend) fetch(jt + KT);
 #pragma unroll 8
         for (int jj = 0; jj < KT; jj += 2) {
             const float a = g_lds[(wave * 32 + n) * GP + jj + kk];
