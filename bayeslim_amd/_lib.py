@@ -18,6 +18,7 @@ ERRORS = {-1: 'RIME_EINVAL (bad shape/flag/null pointer)', -2: 'RIME_EWORKSPACE 
 _vp, _i, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
 _ip = ctypes.POINTER(ctypes.c_int)
 _llp = ctypes.POINTER(ctypes.c_longlong)
+_ll = ctypes.c_longlong
 
 # symbol -> (restype, argtypes); mirrors include/rime_hip.h one to one
 SIGNATURES = {
@@ -28,6 +29,9 @@ SIGNATURES = {
                                  _i, _d, _d, _d, _llp, _vp, _vp, _sz, _vp]),
     'rime_fringe_sum_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _ip, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                  _i, _d, _d, _d, _llp, _vp, _vp, _sz, _vp]),
+    'rime_fringe_ant_workspace': (_sz, [_i, _i, _i, _i]),
+    'rime_fringe_ant_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _i, _vp, _vp, _sz, _vp]),
+    'rime_fringe_ant_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _i, _vp, _vp]),
     'rime_gen_fringe': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rime_interp_gather_fwd': (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'rime_interp_scatter_bwd': (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

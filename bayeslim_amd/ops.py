@@ -60,7 +60,8 @@ class FringeGeometry:
     blvecs (Nbl, 3) [m]; sdir (Nt, 3, Pstride) unit vectors, zero-padded past each time's
     pixel count; freqs (Nf,) [Hz]; bl_models: optional list of model-pair index per baseline.
     """
-    def __init__(self, blvecs, sdir, freqs, bl_mp=None, Nmp=1, conj=False, npix=None):
+    def __init__(self, blvecs, sdir, freqs, bl_mp=None, Nmp=1, conj=False, npix=None,
+                 antpos=None, bl_ants=None, mfma='auto'):
         _require_cuda(blvecs, sdir)
         dev = blvecs.device
         self.blvecs = blvecs.detach().to(torch.float64).contiguous()
@@ -90,6 +91,10 @@ class FringeGeometry:
                 self.uniform = 0
         else:
             self.uniform, self.df = 1, 0.0
+        # antenna factorisation (matrix-core path): baselines given as antenna-index pairs
+        self.ant = None
+        if antpos is not None and bl_ants is not None and mfma in ('auto', True):
+            self._setup_antenna_path(antpos, bl_ants, force=(mfma is True))
         # model-pair grouping
         self.Nmp = int(Nmp)
         if bl_mp is None or self.Nmp == 1:
@@ -103,6 +108,22 @@ class FringeGeometry:
             offs = np.concatenate([[0], np.cumsum(counts)])
             self.mp_offsets = (ctypes.c_int * (self.Nmp + 1))(*[int(o) for o in offs])
             self.bl_order = torch.as_tensor(order, dtype=torch.int32, device=dev)
+
+
+def _antenna_tables(bl_ants, Nant):
+    """pair_direct / pair_conj tables of the matrix-core path (see include/rime_hip.h)"""
+    direct = np.full((MFMA_MAX_ANTS, MFMA_MAX_ANTS), -1, dtype=np.int32)
+    conj = np.full((MFMA_MAX_ANTS, MFMA_MAX_ANTS), -1, dtype=np.int32)
+    for b, (a1, a2) in enumerate(bl_ants):
+        if a1 // 32 <= a2 // 32:
+            if direct[a1, a2] >= 0:
+                return None                       # duplicate pair: not representable
+            direct[a1, a2] = b
+        else:
+            if conj[a2, a1] >= 0:
+                return None
+            conj[a2, a1] = b
+    return direct, conj
 
 
 def _dense_strides(t):
@@ -119,7 +140,77 @@ def _dense_strides(t):
     return (ctypes.c_longlong * 4)(*[int(max(s, 1)) for s in st[:4]])
 
 
+MFMA_MAX_ANTS = 128
+
+
+def _pow2_scale(amax):
+    """power of two s with amax * s in [2^13, 2^14]; 1 where amax == 0 (exact to apply and undo)"""
+    safe = torch.where(amax > 0, amax, torch.ones_like(amax))
+    return torch.where(amax > 0, torch.exp2(torch.floor(torch.log2(16384.0 / safe))), torch.ones_like(amax))
+
+
+def _fringe_ant_call(geom, backward, inp, out, strides):
+    a = geom.ant
+    st_t, st_f = int(strides[0]), int(strides[3])
+    if not backward:
+        # inp: psky (Nt, 1, 1, Nf, Ps) float32 view; out: vis (1, Nbl, Nt, Nf) complex64
+        scale = _pow2_scale(inp.abs().amax(dim=-1).reshape(geom.Nt, geom.Nf)).contiguous()
+        nbytes = lib.rime_fringe_ant_workspace(geom.Nbl, geom.Nt, geom.Nf, geom.Pstride)
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=inp.device)
+        rc = lib.rime_fringe_ant_fwd(_ptr(a['pos']), _ptr(geom.sdir), _ptr(geom.freqs), _ptr(inp), _ptr(scale),
+                                     _ptr(a['direct']), _ptr(a['conj']), a['Nant'], geom.Nbl, geom.Nt, geom.Nf,
+                                     geom.Pstride, st_t, st_f, geom.sign, _ptr(out), _ptr(ws), ws.numel(), _stream())
+        check(rc, 'rime_fringe_ant_fwd')
+    else:
+        # inp: gvis viewed as real (1, Nbl, Nt, Nf, 2); out: gpsky float32 with psky's strides
+        g = inp.reshape(geom.Nbl, geom.Nt, geom.Nf, 2)
+        scale = _pow2_scale(g.abs().amax(dim=(0, 3))).contiguous()
+        rc = lib.rime_fringe_ant_bwd(_ptr(a['pos']), _ptr(geom.sdir), _ptr(geom.freqs), _ptr(inp), _ptr(scale),
+                                     _ptr(a['direct']), _ptr(a['conj']), a['Nant'], geom.Nbl, geom.Nt, geom.Nf,
+                                     geom.Pstride, st_t, st_f, geom.sign, _ptr(out), _stream())
+        check(rc, 'rime_fringe_ant_bwd')
+
+
+def _setup_antenna_path(self, antpos, bl_ants, force=False):
+    """enable the antenna-factored matrix-core kernels when the baseline set suits them"""
+    Nant = int(antpos.shape[0])
+    bl_ants = [(int(a), int(b)) for a, b in bl_ants]
+    if Nant > MFMA_MAX_ANTS or len(bl_ants) != self.Nbl:
+        return
+    # worth it when the array is big enough to fill 32x32 tiles and most pairs are requested
+    # (measured: 128 antennas / 8128 baselines 3.7x (fwd) and 5.3x (bwd) faster than the
+    # baseline-formulation kernels; 19 antennas 3x slower)
+    if not force and (Nant < 48 or self.Nbl < Nant * Nant // 8):
+        return
+    tabs = _antenna_tables(bl_ants, Nant)
+    if tabs is None:
+        return
+    # the factorisation must reproduce the baseline vectors it replaces
+    pos = antpos.detach().to(torch.float64).to(self.blvecs.device).contiguous()
+    i1 = torch.as_tensor([a for a, _ in bl_ants], device=pos.device)
+    i2 = torch.as_tensor([b for _, b in bl_ants], device=pos.device)
+    if not torch.allclose(pos[i2] - pos[i1], self.blvecs, rtol=0, atol=1e-9):
+        return
+    dev = self.blvecs.device
+    self.ant = dict(pos=pos, Nant=Nant, direct=torch.as_tensor(tabs[0].reshape(-1), device=dev),
+                    conj=torch.as_tensor(tabs[1].reshape(-1), device=dev))
+
+
+FringeGeometry._setup_antenna_path = _setup_antenna_path
+
+
 def _fringe_call(geom, backward, inp, out, Npp, cplx, strides=None):
+    if geom.ant is not None and Npp == 1 and not cplx and geom.Nmp == 1 and inp.dtype == torch.float32 \
+            and strides is not None:
+        prof = PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _fringe_ant_call(geom, backward, inp, out, strides)
+        if prof is not None:
+            e1.record()
+            prof.append(('fringe_ant_bwd_kernel' if backward else 'fringe_ant_fwd_kernel', e0, e1, geom.elements))
+        return
     code, rdt = _real_dtype(inp)
     fn = lib.rime_fringe_sum_bwd if backward else lib.rime_fringe_sum_fwd
     nbytes = lib.rime_fringe_sum_workspace(code, geom.Nbl, geom.Nt, geom.Nf, geom.Pstride,

@@ -202,8 +202,12 @@ class RIME(utils.Module):
         # cache key for the interpolation stencil / Ylm of this angle set (rime_model.py:345-357
         # uses (sky name, Npix, time) per time step; here the whole time group is one set)
         zen_all._arr_hash = ('rime-batch', name, Npix, tuple(float(t) for t in self.sim_times), Ps)
+        # antenna positions + antenna-index pairs let the fringe op take its matrix-core path
+        idx = self.array._ant_idx
+        bl_ants = [(idx[b[0]], idx[b[1]]) for b in self.sim_bls]
         geom = ops.FringeGeometry(self.sim_blvecs.to(dev), sdir, self.freqs, bl_mp=bl_mp,
-                                  Nmp=len(pairs), npix=[c.numel() for c in cuts])
+                                  Nmp=len(pairs), npix=[c.numel() for c in cuts],
+                                  antpos=self.array.antvecs, bl_ants=bl_ants)
         bg = dict(zen=zen_all, az=az_all, cut=cut_all, geom=geom, Nt=Nt, Ps=Ps)
         self._geom_cache[gkey] = bg
         return bg

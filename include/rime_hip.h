@@ -101,6 +101,33 @@ int rime_fringe_sum_bwd(int dtype,
                         void* gpsky, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Antenna-factored fringe sum on the matrix cores (float32, 1-pol real psky, one beam-model
+ * pair, Nant <= 128).  Same result as rime_fringe_sum_fwd/bwd for baselines that are antenna
+ * pairs: with E_a = exp(sign 2 pi i nu r_a.s / c) the fringe of baseline (a1 -> a2) is
+ * E_a2 conj(E_a1), so per (time, channel) all visibilities are one Hermitian rank-P update
+ * V = E^H diag(psky) E, computed on v_mfma_f32_32x32x16_f16 with an f16 hi/lo split of the f32
+ * operands (three cross products, f32 accumulation).  Replaces the same reference lines as
+ * rime_fringe_sum_fwd/bwd.
+ *   antpos f64 [Nant, 3] ENU metres; psky / gpsky T [t][f][p] with element strides st_t, st_f
+ *   scale / gscale f32 [Nt, Nf]: power-of-two factors that bring max|psky[t,f,:]| (resp.
+ *       max|gvis[:,t,f]|) to ~2^14 -- computed by the caller (a torch amax), exact to undo
+ *   pair_direct / pair_conj int32 [128*128]: for antenna indices (i, j) with tile(i) <= tile(j)
+ *       (tile = index / 32) the baseline slot that receives V[i,j] (pair stored as i -> j) and the
+ *       slot that receives conj(V[i,j]) (pair stored as j -> i, only when tile(j) > tile(i)), or -1
+ *   vis / gvis complex64 [Nbl, Nt, Nf]
+ * ------------------------------------------------------------------------------------- */
+size_t rime_fringe_ant_workspace(int Nbl, int Nt, int Nf, int Pstride);
+int rime_fringe_ant_fwd(const double* antpos, const double* sdir, const double* freqs,
+                        const float* psky, const float* scale, const int* pair_direct,
+                        const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
+                        long long st_t, long long st_f, int sign, float* vis,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* freqs,
+                        const float* gvis, const float* gscale, const int* pair_direct,
+                        const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
+                        long long st_t, long long st_f, int sign, float* gpsky, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Materialised fringe, for callers that want the tensor itself (imaging.VisMapper.build_A,
  * tests):  out[b, f, p] = exp(sign * 2 pi i * freqs[f]/c * blvecs[b] . sdir[:, p])
  * Replaces ArrayModel.gen_fringe (telescope_model.py:350-356).  RIME never calls it.
