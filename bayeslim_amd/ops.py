@@ -192,8 +192,12 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False):
     if not torch.allclose(pos[i2] - pos[i1], self.blvecs, rtol=0, atol=1e-9):
         return
     dev = self.blvecs.device
+    # executed matrix-core work per launch (forward == backward): per 8 pixels, 6 MFMAs of
+    # 2*32*32*16 flop on each upper-triangular 32x32 antenna tile
+    TA = (Nant + 31) // 32
+    mfma_flops = self.Nt * self.Nf * (self.Pstride // 8) * (TA * (TA + 1) // 2) * 6 * 32768
     self.ant = dict(pos=pos, Nant=Nant, direct=torch.as_tensor(tabs[0].reshape(-1), device=dev),
-                    conj=torch.as_tensor(tabs[1].reshape(-1), device=dev))
+                    conj=torch.as_tensor(tabs[1].reshape(-1), device=dev), mfma_flops=mfma_flops)
 
 
 FringeGeometry._setup_antenna_path = _setup_antenna_path
@@ -209,7 +213,8 @@ def _fringe_call(geom, backward, inp, out, Npp, cplx, strides=None):
         _fringe_ant_call(geom, backward, inp, out, strides)
         if prof is not None:
             e1.record()
-            prof.append(('fringe_ant_bwd_kernel' if backward else 'fringe_ant_fwd_kernel', e0, e1, geom.elements))
+            prof.append(('fringe_ant_bwd_kernel' if backward else 'fringe_ant_fwd_kernel', e0, e1, geom.elements,
+                         geom.ant['mfma_flops']))
         return
     code, rdt = _real_dtype(inp)
     fn = lib.rime_fringe_sum_bwd if backward else lib.rime_fringe_sum_fwd
@@ -227,7 +232,7 @@ def _fringe_call(geom, backward, inp, out, Npp, cplx, strides=None):
     check(rc, 'rime_fringe_sum_bwd' if backward else 'rime_fringe_sum_fwd')
     if prof is not None:
         e1.record()
-        prof.append(('fringe_bwd_kernel' if backward else 'fringe_fwd_kernel', e0, e1, geom.elements))
+        prof.append(('fringe_bwd_kernel' if backward else 'fringe_fwd_kernel', e0, e1, geom.elements, 0))
 
 
 class _FringeSum(torch.autograd.Function):

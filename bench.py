@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3          # MI355X fp32 vector == fp32 MFMA dense peak (MI355X_MICROARCH.md)
+F16_MFMA_PEAK_TFLOPS = 2500.0     # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 LAT, LON = -30.72148, 21.42827
 
@@ -280,18 +281,26 @@ def main():
 
     # kernel-level roofline from the HIP events recorded around each C-ABI launch
     kstat = {}
-    for name, e0, e1, elems in prof:
+    for name, e0, e1, elems, mflops in prof:
         ms = e0.elapsed_time(e1)
-        k = kstat.setdefault(name, [0, 0.0, 0])
+        k = kstat.setdefault(name, [0, 0.0, 0, 0])
         k[0] += 1
         k[1] += ms
         k[2] += elems
+        k[3] += mflops
     roof = None
     if kstat:
         dom = max(kstat, key=lambda n: kstat[n][1])
-        n, ms, elems = kstat[dom]
+        n, ms, elems, mflops = kstat[dom]
         flop_per_elem = 10.0                 # 6 (phase rotation) + 4 (real psky accumulate), SURVEY 8(d)
-        achieved = elems * flop_per_elem / (ms * 1e-3) / 1e12
+        algorithmic = elems * flop_per_elem / (ms * 1e-3) / 1e12
+        if mflops > 0:
+            # antenna-factored kernels: bounded by the f16 matrix cores; count the MFMA flops they
+            # execute (3 hi/lo cross products on the upper-triangular antenna tiles)
+            achieved, peak, pipe = mflops / (ms * 1e-3) / 1e12, F16_MFMA_PEAK_TFLOPS, 'f16 MFMA (v_mfma_f32_32x32x16_f16), executed flops'
+        else:
+            achieved, peak, pipe = algorithmic, FP32_PEAK_TFLOPS, 'fp32 vector ALU (== fp32 MFMA dense peak), algorithmic flops'
+        FP32 = FP32_PEAK_TFLOPS
         # HBM traffic of that kernel per launch: PMC counters cannot be read from inside the
         # process; the committed summary of the separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`
         # passes over this same command is used when it matches the workload (else null)
@@ -302,12 +311,13 @@ def main():
                 traffic = json.load(open(tpath)).get(dom, {}).get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
-        roof = dict(bound='mfma', kernel=dom, achieved=round(achieved, 2), peak=FP32_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=round(achieved / FP32_PEAK_TFLOPS, 4), traffic=traffic,
+        roof = dict(bound='mfma', kernel=dom, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
+                    frac=round(achieved / peak, 4), traffic=traffic, pipe=pipe,
+                    algorithmic_tflops=round(algorithmic, 2), algorithmic_frac_of_fp32_peak=round(algorithmic / FP32, 4),
                     launches=n, avg_launch_ms=round(ms / n, 4), elements_per_launch=elems // n,
                     flop_per_element=flop_per_elem,
                     hbm_equiv_frac=round(elems * 16.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
-                    note='fp32 vector-ALU kernel; fp32 MFMA dense peak is the same 157.3 TFLOP/s. '
+                    note='algorithmic = 10 flop per fringe element (SURVEY 8d) of the baseline formulation; '
                          'hbm_equiv_frac = 16 B per fringe element of the unfused formulation / 8 TB/s',
                     kernels={k: dict(launches=v[0], total_ms=round(v[1], 3)) for k, v in kstat.items()})
 
