@@ -340,17 +340,18 @@ class _InterpGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         st = ctx.st
-        g = gout.contiguous()
-        code, rdt = _real_dtype(g)
-        gm = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+        code, rdt = _real_dtype(gout)
         R = int(np.prod(ctx.shape[:-1])) if len(ctx.shape) > 1 else 1
+        # transposed working layout [pixel][row]: every read / write of the kernel is coalesced
+        gT = gout.reshape(R, ctx.out_stride)[:, :st.P].t().contiguous()
+        gmT = torch.empty((st.Npb, R), dtype=gout.dtype, device=gout.device)
         rc = lib.rime_interp_scatter_bwd(code, int(ctx.cplx),
-                                         _ptr(torch.view_as_real(g) if ctx.cplx else g), ctx.out_stride,
+                                         _ptr(torch.view_as_real(gT) if ctx.cplx else gT),
                                          _ptr(st.csr_ptr), _ptr(st.csr_src), _ptr(st.weights(rdt)),
                                          R, st.Npb, st.P, st.Nnn,
-                                         _ptr(torch.view_as_real(gm) if ctx.cplx else gm), _stream())
+                                         _ptr(torch.view_as_real(gmT) if ctx.cplx else gmT), _stream())
         check(rc, 'rime_interp_scatter_bwd')
-        return gm, None, None
+        return gmT.t().reshape(ctx.shape), None, None
 
 
 def interp_gather(m, stencil, out_stride=None):

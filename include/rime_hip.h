@@ -149,10 +149,13 @@ int rime_interp_gather_fwd(int dtype, int is_complex, const void* m, const int* 
 /* Adjoint of the gather, deterministic: gm[r, j] = sum over (p,k) with inds[p,k]==j of
  * wgts[p,k] * gout[r, p], driven by a CSR inverse index built once per (inds, wgts):
  *   csr_ptr int32 [Npb+1], csr_src int32 [nnz] (flat p*Nnn+k positions, ascending per row).
+ * Both tensors are passed TRANSPOSED so that every access is coalesced:
+ *   goutT T [P, R] (complex: [P, R, 2]) -- all map rows of one sky pixel contiguous
+ *   gmT   T [Npb, R] (complex: [Npb, R, 2])
  * Replaces the index_select/einsum backward (scatter-add) of utils.py:833-841. */
-int rime_interp_scatter_bwd(int dtype, int is_complex, const void* gout, int out_stride,
+int rime_interp_scatter_bwd(int dtype, int is_complex, const void* goutT,
                             const int* csr_ptr, const int* csr_src, const void* wgts,
-                            int R, int Npb, int P, int Nnn, void* gm, void* stream);
+                            int R, int Npb, int P, int Nnn, void* gmT, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a_lm -> pixel transform:  out[r, j] = sum_c ( are[r,c] * Yre[c,j] - aim[r,c] * Yim[c,j] )

@@ -91,30 +91,6 @@ int main(int argc, char** argv)
         if (rc) { printf("mfma rc=%d (%s)\n", rc, rime_last_error()); return 1; }
         CHK(hipEventElapsedTime(&ms2, e0, e1));
     }
-    {   // ablations of the MFMA kernel (direct launches)
-        AntArgs A{};
-        A.antpos = dant; A.sdir = dsd; A.freqs = dfr; A.psky = dps; A.scale = dsc; A.pair_direct = dpd; A.pair_conj = dpc;
-        A.vis = dv2; A.ws = dws; A.Nant = Nant; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = P; A.S = (P + 8191) / 8192;
-        A.panels_per_split = (P / 16 + A.S - 1) / A.S; A.st_t = (long long)Nf * P; A.st_f = P; A.sign = 1.0;
-        const size_t lds = 4 * (size_t)128 * (16 * 4 + 16) + 128 * 3 * 8;
-        dim3 grid(1, Nf, Nt * A.S);
-        auto timeit = [&](const char* name, auto launch) {
-            float best = 1e30f;
-            for (int r = 0; r < 2; ++r) {
-                CHK(hipEventRecord(e0)); launch(); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
-                float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); best = fminf(best, ms);
-            }
-            CHK(hipGetLastError());
-            printf("  %-28s %8.3f ms\n", name, best);
-        };
-        timeit("full", [&] { hipLaunchKernelGGL((fringe_ant_fwd_kernel<16, 0>), grid, dim3(256), lds, 0, A); });
-        timeit("no generate", [&] { hipLaunchKernelGGL((fringe_ant_fwd_kernel<16, 1>), grid, dim3(256), lds, 0, A); });
-        timeit("no mfma", [&] { hipLaunchKernelGGL((fringe_ant_fwd_kernel<16, 2>), grid, dim3(256), lds, 0, A); });
-        timeit("neither (loop+sync+flush)", [&] { hipLaunchKernelGGL((fringe_ant_fwd_kernel<16, 3>), grid, dim3(256), lds, 0, A); });
-        CHK(hipDeviceSynchronize());
-        rime_fringe_ant_fwd(dant, dsd, dfr, dps, dsc, dpd, dpc, Nant, Nbl, Nt, Nf, P, (long long)Nf * P, (long long)P, 1, dv2, dws, nvis * 4 * 64, 0);
-        CHK(hipDeviceSynchronize());
-    }
     std::vector<float> v1(nvis), v2(nvis);
     CHK(hipMemcpy(v1.data(), dv1, nvis * 4, hipMemcpyDeviceToHost));
     CHK(hipMemcpy(v2.data(), dv2, nvis * 4, hipMemcpyDeviceToHost));
