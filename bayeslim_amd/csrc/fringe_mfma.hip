@@ -81,34 +81,32 @@ __device__ __forceinline__ uint4 rot90(const uint4& v)
 
 // KP = pixels per panel (16 = two MFMA K-steps of 8 pixels).  LDS rows are KP*4 + 16 bytes, an odd
 // number of 16-B granules, so the 16 lanes of a ds_read_b128 group hit 16 distinct granules.
-//
-// Wave specialisation: a block has 8 waves -- waves 0-3 only issue MFMAs (and the LDS fragment
-// reads feeding them), waves 4-7 only generate the operand images of the NEXT panel into the other
-// LDS buffer.  Waves w and w+4 share a SIMD, so every SIMD runs one matrix-pipe wave beside one
-// VALU wave and the two pipes overlap (measured on the one-role kernel: 8.9 ms of MFMA work and
-// 6.1 ms of generation ran back to back, 13.7 ms); one barrier per panel.
+// One LDS buffer (4 images, 40 KB) and two barriers per panel: several blocks are resident per CU,
+// so one block's operand generation (VALU) runs under another block's MFMAs.
 // Every block covers at most MF_SPLIT_PIX pixels and STORES its result (no read-modify-write):
 // f32 accumulation inside the MFMA chain stays below eps*sqrt(512/2), and the pixel splits are
 // summed by reduce_vis_kernel in a fixed order (deterministic).
+// (A wave-specialised variant -- 4 MFMA-only waves + 4 generator waves per block, double-buffered
+// images, one block per CU -- measured SLOWER: 15.8 vs 13.7 ms at C4; cross-block overlap at 3
+// blocks per CU hides more latency than one matrix-pipe wave per SIMD can.)
 template <int MF_KP>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(256, 2)
 fringe_ant_fwd_kernel(AntArgs A)
 {
     constexpr int MF_ROWB = MF_KP * 4 + 16;
     constexpr int MF_IMG = MF_NA * MF_ROWB;
     constexpr int GPL = MF_KP;                  // lanes per pixel group in the generation mapping
-    constexpr int APT = MF_NA * MF_KP / 256;    // antennas per generator thread per panel
+    constexpr int APT = MF_NA * MF_KP / 256;    // antennas per thread per panel
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* img = smem;                                         // 2 buffers x 4 images (L hi, L lo, B hi, B lo)
-    double* ant_lds = reinterpret_cast<double*>(smem + 8 * MF_IMG);    // [128][3]
+    unsigned char* img = smem;                                         // 4 images: L hi, L lo, B hi, B lo
+    double* ant_lds = reinterpret_cast<double*>(smem + 4 * MF_IMG);    // [128][3]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool producer = wave >= 4;
     const int f = blockIdx.y;
     const int t = blockIdx.z / A.S, split = blockIdx.z % A.S;
     const int TA = (A.Nant + 31) / 32;
 
-    for (int i = tid; i < MF_NA * 3; i += 512)
+    for (int i = tid; i < MF_NA * 3; i += 256)
         ant_lds[i] = (i < A.Nant * 3) ? A.sign * A.antpos[i] : 0.0;
 
     const double nu_c = A.freqs[f] * (1.0 / 2.99792458e8);
@@ -116,39 +114,9 @@ fringe_ant_fwd_kernel(AntArgs A)
     const float* arow = A.psky + (size_t)t * A.st_t + (size_t)f * A.st_f;
     const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
 
-    const int npanel = A.Pstride / MF_KP;
-    const int pbeg = split * A.panels_per_split;
-    const int pend = min(npanel, pbeg + A.panels_per_split);
-
-    // ---- producer state: 16 consecutive lanes = the 16 pixels of a panel; a thread handles its
-    // pixel for APT consecutive antennas
-    const int gt = tid & 255;
-    const int gp = gt & (GPL - 1), ga0 = (gt / GPL) * APT;
-    auto generate = [&](int panel, int buf) {
-        unsigned char* gbase = img + buf * 4 * MF_IMG + gp * 4 + ga0 * MF_ROWB;
-        const int p = panel * MF_KP + gp;
-        // pointing vector pre-multiplied by nu/c: the antenna dot product is the phase in turns
-        const double ux = sd[p] * nu_c, uy = sd[A.Pstride + p] * nu_c, uz = sd[2 * (size_t)A.Pstride + p] * nu_c;
-        const float a = arow[p] * scl;
-#pragma unroll 4
-        for (int u = 0; u < APT; ++u) {
-            const int an = ga0 + u;
-            const double ph = ant_lds[3 * an] * ux + ant_lds[3 * an + 1] * uy + ant_lds[3 * an + 2] * uz;
-            const float r = (float)(ph - rint(ph));
-            const float s = __builtin_amdgcn_sinf(r), c = __builtin_amdgcn_cosf(r);
-            uint32_t hi, lo;
-            split2(c, s, hi, lo);
-            *reinterpret_cast<uint32_t*>(gbase + 0 * MF_IMG + u * MF_ROWB) = hi;
-            *reinterpret_cast<uint32_t*>(gbase + 1 * MF_IMG + u * MF_ROWB) = lo;
-            split2(a * c, a * s, hi, lo);
-            *reinterpret_cast<uint32_t*>(gbase + 2 * MF_IMG + u * MF_ROWB) = hi;
-            *reinterpret_cast<uint32_t*>(gbase + 3 * MF_IMG + u * MF_ROWB) = lo;
-        }
-    };
-
-    // ---- consumer state: this wave's tiles: w, w+4, w+8 of the row-major upper-triangle enumeration
-    int ti[3] = {0, 0, 0}, tj[3] = {0, 0, 0}, nt = 0;
-    if (!producer) {
+    // this wave's tiles: w, w+4, w+8 of the row-major upper-triangle enumeration
+    int ti[3], tj[3], nt = 0;
+    {
         int idx = 0;
         for (int a = 0; a < TA; ++a)
             for (int b = a; b < TA; ++b, ++idx)
@@ -159,32 +127,56 @@ fringe_ant_fwd_kernel(AntArgs A)
     for (int q = 0; q < 3; ++q)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { accR[q][e] = 0.f; accI[q][e] = 0.f; }
+
+    const int npanel = A.Pstride / MF_KP;
+    const int pbeg = split * A.panels_per_split;
+    const int pend = min(npanel, pbeg + A.panels_per_split);
+
+    // generation mapping: 16 consecutive lanes = the 16 pixels of the panel; a thread handles its
+    // pixel for APT consecutive antennas
+    const int gp = tid & (GPL - 1), ga0 = (tid / GPL) * APT;
+    unsigned char* gbase = img + gp * 4 + ga0 * MF_ROWB;
     const int koff = 4 * (lane >> 5) * 4;                              // this lane half's 4 pixels
     int roff[3], coff[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        roff[q] = (ti[q] * 32 + (lane & 31)) * MF_ROWB + koff;
-        coff[q] = (tj[q] * 32 + (lane & 31)) * MF_ROWB + koff + 2 * MF_IMG;
+        roff[q] = (ti[q < nt ? q : 0] * 32 + (lane & 31)) * MF_ROWB + koff;
+        coff[q] = (tj[q < nt ? q : 0] * 32 + (lane & 31)) * MF_ROWB + koff + 2 * MF_IMG;
     }
 
-    __syncthreads();                                   // antenna positions visible
-    if (producer && pbeg < pend) generate(pbeg, 0);
-    __syncthreads();
     for (int panel = pbeg; panel < pend; ++panel) {
-        const int buf = (panel - pbeg) & 1;
-        if (producer) {
-            if (panel + 1 < pend) generate(panel + 1, buf ^ 1);
-        } else {
-            const unsigned char* b0 = img + buf * 4 * MF_IMG;
+        __syncthreads();                               // previous panel's fragments consumed
+        {
+            const int p = panel * MF_KP + gp;
+            // pointing vector pre-multiplied by nu/c: the antenna dot product is the phase in turns
+            const double ux = sd[p] * nu_c, uy = sd[A.Pstride + p] * nu_c, uz = sd[2 * (size_t)A.Pstride + p] * nu_c;
+            const float a = arow[p] * scl;
+#pragma unroll 2
+            for (int u = 0; u < APT; ++u) {
+                const int an = ga0 + u;
+                const double ph = ant_lds[3 * an] * ux + ant_lds[3 * an + 1] * uy + ant_lds[3 * an + 2] * uz;
+                const float r = (float)(ph - rint(ph));
+                const float s = __builtin_amdgcn_sinf(r), c = __builtin_amdgcn_cosf(r);
+                uint32_t hi, lo;
+                split2(c, s, hi, lo);
+                *reinterpret_cast<uint32_t*>(gbase + 0 * MF_IMG + u * MF_ROWB) = hi;
+                *reinterpret_cast<uint32_t*>(gbase + 1 * MF_IMG + u * MF_ROWB) = lo;
+                split2(a * c, a * s, hi, lo);
+                *reinterpret_cast<uint32_t*>(gbase + 2 * MF_IMG + u * MF_ROWB) = hi;
+                *reinterpret_cast<uint32_t*>(gbase + 3 * MF_IMG + u * MF_ROWB) = lo;
+            }
+        }
+        __syncthreads();
+        {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 if (q < nt) {
 #pragma unroll
                     for (int ks = 0; ks < MF_KP / 8; ++ks) {
-                        const uint4 Lh = *reinterpret_cast<const uint4*>(b0 + roff[q] + ks * 32);
-                        const uint4 Ll = *reinterpret_cast<const uint4*>(b0 + roff[q] + ks * 32 + MF_IMG);
-                        const uint4 Bh = *reinterpret_cast<const uint4*>(b0 + coff[q] + ks * 32);
-                        const uint4 Bl = *reinterpret_cast<const uint4*>(b0 + coff[q] + ks * 32 + MF_IMG);
+                        const uint4 Lh = *reinterpret_cast<const uint4*>(img + roff[q] + ks * 32);
+                        const uint4 Ll = *reinterpret_cast<const uint4*>(img + roff[q] + ks * 32 + MF_IMG);
+                        const uint4 Bh = *reinterpret_cast<const uint4*>(img + coff[q] + ks * 32);
+                        const uint4 Bl = *reinterpret_cast<const uint4*>(img + coff[q] + ks * 32 + MF_IMG);
                         const f16x8 lh = as_frag(Lh), ll = as_frag(Ll), bh = as_frag(Bh), bl = as_frag(Bl);
                         const f16x8 lh2 = as_frag(rot90(Lh)), ll2 = as_frag(rot90(Ll));
                         accR[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh, bh, accR[q], 0, 0, 0);
@@ -197,11 +189,9 @@ fringe_ant_fwd_kernel(AntArgs A)
                 }
             }
         }
-        __syncthreads();                               // panel consumed, next panel complete
     }
 
-    // epilogue (consumer waves): V[i,j] / scale -> the baseline slot(s) of pair (i,j); one store each
-    if (producer) return;
+    // epilogue: V[i,j] / scale -> the baseline slot(s) of pair (i,j); one store per element
     const size_t vis_elems = (size_t)A.Nbl * A.Nt * A.Nf * 2;
     float* dst = (A.S == 1) ? A.vis : A.ws + (size_t)split * vis_elems;
     const float inv = 1.0f / scl;
@@ -228,6 +218,7 @@ fringe_ant_fwd_kernel(AntArgs A)
         }
     }
 }
+
 
 // ---------------------------------------------------------------------------------------
 // backward:  gpsky[t,f,p] = Re sum_{i,j} E_i(p) conj(E_j(p)) G[i,j]
@@ -312,7 +303,7 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
 
     for (int pt = tbeg + wave; pt < tend; pt += 8) {
         const int p = pt * 32 + (lane & 31);
-        const double sx = sd[p], sy = sd[A.Pstride + p], sz = sd[2 * (size_t)A.Pstride + p];
+        const double sx = sd[p] * nu_c, sy = sd[A.Pstride + p] * nu_c, sz = sd[2 * (size_t)A.Pstride + p] * nu_c;
         f32x16 accR[4], accI[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -332,8 +323,7 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int an = 32 * tj + 8 * ks + 4 * h + r;
-                        const double tau = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
-                        const double ph = tau * nu_c;
+                        const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
                         const float rr = (float)(ph - rint(ph));
                         const float s = __builtin_amdgcn_sinf(rr), c = __builtin_amdgcn_cosf(rr);
                         ec[ks][r] = c; es[ks][r] = s;
@@ -424,9 +414,9 @@ extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, con
     const size_t vis_elems = (size_t)Nbl * Nt * Nf * 2;
     if (A.S > 1 && workspace_bytes < (size_t)A.S * vis_elems * sizeof(float)) return RIME_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t lds = 8 * (size_t)MF_NA * (KP * 4 + 16) + MF_NA * 3 * sizeof(double);
+    const size_t lds = 4 * (size_t)MF_NA * (KP * 4 + 16) + MF_NA * 3 * sizeof(double);
     dim3 grid(1, Nf, Nt * A.S);
-    hipLaunchKernelGGL((fringe_ant_fwd_kernel<KP>), grid, dim3(512), lds, st, A);
+    hipLaunchKernelGGL((fringe_ant_fwd_kernel<KP>), grid, dim3(256), lds, st, A);
     if (A.S > 1) {
         int nb = (int)std::min<size_t>((vis_elems + 255) / 256, 4096);
         hipLaunchKernelGGL((reduce_vis_kernel<float>), dim3(nb), dim3(256), 0, st, A.ws, vis, vis_elems, A.S);

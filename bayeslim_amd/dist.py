@@ -5,9 +5,12 @@ Multi-GPU execution of the RIME path: one process per GPU, baselines sharded acr
 The reference has no collectives: its `DistributedLogProb` (optim.py:1391-1566) copies
 parameters to each device, runs the per-device closures one after another in a Python loop and
 sums gradients on device 0.  Here:
-  * visibilities are independent across baselines, so each rank simulates a CONTIGUOUS block of
-    `sim_bls` (order preserved: the gathered tensor equals the single-GPU layout) from
-    replicated sky / beam parameters -- no data-path collective inside the kernels;
+  * visibilities are independent across baselines AND across channels.  Either axis can be
+    sharded in contiguous blocks (order preserved: the gathered tensor equals the single-GPU
+    layout) from replicated sky / beam parameters -- no data-path collective inside the kernels.
+    Baseline blocks suit the baseline-formulation kernels; CHANNEL blocks suit the antenna-factored
+    matrix-core kernels, whose cost does not depend on how many of the antenna pairs are requested
+    (and channel blocks also shard the per-channel sky / beam preparation and their gradients);
   * forward: optional all-gather of the (Npol, Npol, Nbl/W, Nt, Nf) visibility blocks
     (differentiable: its backward hands each rank the slice of the upstream gradient that
     belongs to its baselines -- no communication);
@@ -38,18 +41,19 @@ def shard_baselines(bls, rank=None, world_size=None):
     return list(bls[s:e])
 
 
-class _AllGatherBl(torch.autograd.Function):
-    """all-gather along the baseline axis (dim 2) of ragged per-rank blocks"""
+class _AllGatherCat(torch.autograd.Function):
+    """all-gather of ragged per-rank blocks concatenated along `dim` (differentiable: the
+    backward hands every rank the slice of the upstream gradient that belongs to its block)"""
     @staticmethod
-    def forward(ctx, vis, counts, group):
+    def forward(ctx, x, counts, dim, group):
         world = len(counts)
         rank = dist.get_rank(group)
         nmax = max(counts)
-        shape = list(vis.shape)
-        pad = vis
-        if shape[2] < nmax:
-            padshape = shape[:2] + [nmax - shape[2]] + shape[3:]
-            pad = torch.cat([vis, vis.new_zeros(padshape)], dim=2)
+        pad = x
+        if x.shape[dim] < nmax:
+            padshape = list(x.shape)
+            padshape[dim] = nmax - x.shape[dim]
+            pad = torch.cat([x, x.new_zeros(padshape)], dim=dim)
         pad = pad.contiguous()
         if pad.is_complex():
             buf = torch.view_as_real(pad)
@@ -59,28 +63,53 @@ class _AllGatherBl(torch.autograd.Function):
         else:
             parts = [torch.empty_like(pad) for _ in range(world)]
             dist.all_gather(parts, pad, group=group)
-        ctx.counts, ctx.rank = counts, rank
-        return torch.cat([p[:, :, :c] for p, c in zip(parts, counts)], dim=2)
+        ctx.counts, ctx.rank, ctx.dim = counts, rank, dim
+        return torch.cat([p.narrow(dim, 0, c) for p, c in zip(parts, counts)], dim=dim)
 
     @staticmethod
     def backward(ctx, g):
         s = sum(ctx.counts[:ctx.rank])
-        return g[:, :, s:s + ctx.counts[ctx.rank]].contiguous(), None, None
+        return g.narrow(ctx.dim, s, ctx.counts[ctx.rank]).contiguous(), None, None, None
 
 
-def all_gather_vis(vis_local, counts=None, group=None):
+def all_gather_vis(vis_local, counts=None, group=None, dim=2):
     """
-    Gather per-rank visibility blocks (Npol, Npol, Nbl_r, Nt, Nf) into the full
-    (Npol, Npol, Nbl, Nt, Nf) tensor on every rank, rank blocks in rank order.
-    `counts`: baselines per rank (default: exchanged with an all_gather of the local count).
+    Gather per-rank visibility blocks into the full (Npol, Npol, Nbl, Nt, Nf) tensor on every
+    rank, rank blocks in rank order along `dim` (2 = baseline-sharded, 4 = frequency-sharded).
+    `counts`: block sizes per rank (default: exchanged with an all_gather of the local size).
     """
     world = dist.get_world_size(group)
     if counts is None:
-        n = torch.tensor([vis_local.shape[2]], device=vis_local.device)
+        n = torch.tensor([vis_local.shape[dim]], device=vis_local.device)
         ns = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(ns, n, group=group)
         counts = [int(x.item()) for x in ns]
-    return _AllGatherBl.apply(vis_local, tuple(counts), group)
+    return _AllGatherCat.apply(vis_local, tuple(counts), dim, group)
+
+
+def all_gather_block_grads(param, dim, bounds, group=None):
+    """
+    Gradient exchange for a replicated parameter whose slices along `dim` are each used by exactly
+    one rank (frequency sharding of per-channel sky / beam parameters): the local .grad is non-zero
+    only inside this rank's (start, stop) block, so an all-gather of the blocks rebuilds the full
+    gradient with half the bytes of an all-reduce.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    s, e = bounds[rank]
+    if param.grad is None:
+        param.grad = torch.zeros_like(param)
+    nmax = max(b - a for a, b in bounds)
+    blk = param.grad.narrow(dim, s, e - s)
+    if e - s < nmax:
+        padshape = list(blk.shape)
+        padshape[dim] = nmax - (e - s)
+        blk = torch.cat([blk, blk.new_zeros(padshape)], dim=dim)
+    blk = blk.contiguous()
+    parts = [torch.empty_like(blk) for _ in range(world)]
+    dist.all_gather(parts, blk, group=group)
+    for (a, b), part in zip(bounds, parts):
+        param.grad.narrow(dim, a, b - a).copy_(part.narrow(dim, 0, b - a))
 
 
 def all_reduce_grads(params, group=None, average=False):
@@ -137,7 +166,7 @@ class ShardedRIME:
     def forward(self, gather=False, **kw):
         vd = self.rime(**kw)
         if gather:
-            vd.data = all_gather_vis(vd.data, self.counts, self.group)
+            vd.data = all_gather_vis(vd.data, self.counts, self.group, dim=2)
             vd._set_bls(self.all_bls)
         return vd
 

@@ -13,9 +13,13 @@ target on and which fits one GPU: HERA-128 (hex-127 + 1 outrigger, 8128 baseline
 HEALPix diffuse sky + 1e4 point sources, 256 channels, interpolated Airy PixelBeam.
 A "step" = one RIME forward + backward over a minibatch of NT time steps.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): baselines are sharded in
-contiguous blocks, visibilities all-gathered, parameter gradients all-reduced; total work is
-fixed, so scaling is "strong".
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): visibilities are independent
+across baselines and across channels; the work is sharded in contiguous CHANNEL blocks when the
+antenna-factored matrix-core kernels apply (their cost does not depend on how many antenna pairs
+are requested, and channel blocks also shard the per-channel sky/beam preparation), otherwise in
+contiguous BASELINE blocks (--shard).  Visibilities are all-gathered (RCCL), gradients of
+replicated parameters are all-reduced (shared) or all-gathered by block (per-channel); total work
+is fixed, so scaling is "strong".
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields), including
   roofline     -- dominant kernel (fused fringe sum): algorithmic flops / measured kernel time
@@ -105,31 +109,44 @@ def build_inputs(wl, nt, seed=0):
     return inp
 
 
-def build_model(inp, dev, bls, seed=0):
-    """the drop-in modules on the GPU for the baseline list `bls` (this rank's shard)"""
+def build_model(inp, dev, bls, seed=0, fblock=None):
+    """
+    The drop-in modules on the GPU for this rank's shard: the baseline list `bls` and, when
+    `fblock = (f0, f1)` is given, the channel block [f0, f1).  Parameters are created FULL-SIZE
+    and identical on every rank (same seed); a channel-sharded rank feeds its modules views of
+    them, re-attached before every forward by the returned `attach()` (the reference's own
+    parameter protocol: params may be non-leaf graph tensors that are re-set each forward).
+    Returns (rime, leaf parameters, attach, per-channel parameter descriptors).
+    """
     from bayeslim_amd import utils, telescope_model, beam_model, sky_model, rime_model
     cfg = inp['cfg']
     f32 = torch.float32
-    freqs = torch.as_tensor(inp['freqs'], dtype=f32, device=dev)
+    f0, f1 = (0, cfg['Nf']) if fblock is None else fblock
+    freqs_full = torch.as_tensor(inp['freqs'], dtype=f32, device=dev)
+    freqs = freqs_full[f0:f1]
     arr = telescope_model.ArrayModel(utils.AntposDict(inp['ants'], torch.as_tensor(inp['antvecs'])),
                                      freqs=freqs, device=dev, skip_reds=True)
     tel = telescope_model.TelescopeModel((LON, LAT))
     gen = torch.Generator(device='cpu').manual_seed(seed)
     Npix = len(inp['ra'])
-    skyp = torch.randn(1, 1, cfg['Nf'], Npix, generator=gen, dtype=f32).to(dev)
+    skyp = torch.nn.Parameter(torch.randn(1, 1, cfg['Nf'], Npix, generator=gen, dtype=f32).to(dev))
     angs = torch.as_tensor(np.stack([inp['ra'], inp['dec']]), device=dev)
-    diffuse = sky_model.PixelSky(skyp, angs, inp['px_area'], R=sky_model.PixelSkyResponse(freqs, device=dev),
-                                 parameter=True, name='diffuse')
+    diffuse = sky_model.PixelSky(skyp.detach()[:, :, f0:f1], angs, inp['px_area'],
+                                 R=sky_model.PixelSkyResponse(freqs, device=dev),
+                                 parameter=False, name='diffuse')
+    leaves = [skyp]
+    per_channel = [(skyp, 2)]                      # (parameter, channel axis)
     models = {'diffuse': diffuse}
     for t, za in zip(inp['times'], inp['zenaz']):
         tel.conv_cache[('diffuse', Npix, float(t))] = torch.as_tensor(za)
     if cfg['Npt'] > 0:
         pp = torch.ones(1, 1, 2, cfg['Npt'], dtype=f32)
         pp[..., 1, :] = -2.2
-        R = sky_model.PointSkyResponse(freqs, freq_mode='powerlaw', f0=freqs[0], device=dev)
+        R = sky_model.PointSkyResponse(freqs, freq_mode='powerlaw', f0=freqs_full[0], device=dev)
         pts = sky_model.PointSky(pp.to(dev), torch.as_tensor(np.stack([inp['pt_ra'], inp['pt_dec']]), device=dev),
                                  R=R, parameter=True, name='points')
         models['points'] = pts
+        leaves.append(pts.params)                  # power-law params are shared by all channels
         for t, za in zip(inp['times'], inp['pt_zenaz']):
             tel.conv_cache[('points', cfg['Npt'], float(t))] = torch.as_tensor(za)
     sky = sky_model.CompositeModel(models) if len(models) > 1 else diffuse
@@ -137,16 +154,25 @@ def build_model(inp, dev, bls, seed=0):
     pg = torch.as_tensor(inp['phi_grid'], device=dev)
     b_phi, b_theta = torch.meshgrid(pg, tg, indexing='xy')
     airy = beam_model.airy_disk(b_theta.ravel() * utils.D2R, b_phi.ravel() * utils.D2R, 14.0,
-                                freqs.double(), square=True).to(f32)
+                                freqs_full.double(), square=True).to(f32)
+    beamp = torch.nn.Parameter(airy[None, None, None].contiguous())
     R = beam_model.PixelResponse(freqs, 'rect', interp_mode='linear', theta_grid=tg, phi_grid=pg,
                                  freq_mode='channel', powerbeam=True, device=dev)
-    beam = beam_model.PixelBeam(airy[None, None, None].contiguous(), freqs, R=R, pol='e', powerbeam=True,
-                                fov=180, parameter=True)
+    beam = beam_model.PixelBeam(beamp.detach()[..., f0:f1, :], freqs, R=R, pol='e', powerbeam=True,
+                                fov=180, parameter=False)
+    leaves.append(beamp)
+    per_channel.append((beamp, 3))
     # geometry frequencies stay float64: an exactly uniform grid lets the fringe kernel use its
     # rotation recurrence (float32-rounded channel centres are not uniform to better than ~8 Hz)
     rime = rime_model.RIME(sky, tel, beam, arr, bls, inp['times'],
-                           torch.as_tensor(inp['freqs'], dtype=torch.float64, device=dev))
-    return rime
+                           torch.as_tensor(inp['freqs'][f0:f1], dtype=torch.float64, device=dev))
+
+    def attach():
+        """(re-)attach this rank's views of the replicated leaf parameters (new graph each step)"""
+        diffuse.params = skyp[:, :, f0:f1]
+        beam.params = beamp[..., f0:f1, :]
+
+    return rime, leaves, attach, per_channel
 
 
 def all_baselines(inp):
@@ -215,6 +241,9 @@ def main():
     ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
     ap.add_argument('--nt', type=int, default=None, help='time steps per step (minibatch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shard', default='auto', choices=['auto', 'freq', 'bl'],
+                    help='multi-GPU partition: channel blocks or baseline blocks (auto: channels when the '
+                         'antenna-factored matrix-core kernels apply, i.e. workload c4; else baselines)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -234,11 +263,17 @@ def main():
     nt = args.nt or cfg['nt']
     inp = build_inputs(args.workload, nt)
     bls = all_baselines(inp)
-    bounds = rdist.shard_bounds(len(bls), world)
+    shard = args.shard
+    if shard == 'auto':
+        shard = 'freq' if args.workload == 'c4' else 'bl'
+    if shard == 'freq':
+        bounds = rdist.shard_bounds(cfg['Nf'], world)
+        my_bls, fblock, gdim = bls, bounds[rank], 4
+    else:
+        bounds = rdist.shard_bounds(len(bls), world)
+        my_bls, fblock, gdim = bls[bounds[rank][0]:bounds[rank][1]], None, 2
     counts = [e - s for s, e in bounds]
-    my_bls = bls[bounds[rank][0]:bounds[rank][1]]
-    rime = build_model(inp, dev, my_bls)
-    params = [p for p in rime.parameters()]
+    rime, params, attach, per_channel = build_model(inp, dev, my_bls, fblock=fblock)
 
     prof = []
     ops.PROFILE = prof
@@ -246,14 +281,23 @@ def main():
     def step():
         for p in params:
             p.grad = None
+        attach()
         vd = rime()
         vis = vd.data
         if world > 1:
-            vis = rdist.all_gather_vis(vis, counts)
+            vis = rdist.all_gather_vis(vis, counts, dim=gdim)       # RCCL all-gather (differentiable)
         loss = (vis.real ** 2 + vis.imag ** 2).sum()
         loss.backward()
         if world > 1:
-            rdist.all_reduce_grads(params)
+            if shard == 'freq':
+                # per-channel parameters: every block is produced by exactly one rank -> all-gather
+                # of the blocks; parameters shared by all channels -> all-reduce
+                pc = {id(p) for p, _ in per_channel}
+                for p, ax in per_channel:
+                    rdist.all_gather_block_grads(p, ax, bounds)
+                rdist.all_reduce_grads([p for p in params if id(p) not in pc])
+            else:
+                rdist.all_reduce_grads(params)
         return loss
 
     def sync():
@@ -330,7 +374,7 @@ def main():
                    config=dict(workload=cfg['desc'], Nbl=len(bls), Ntimes_per_step=nt, Nfreqs=cfg['Nf'],
                                Npix_sky=int(len(inp['ra'])), Npix_visible=int((inp['zenaz'][0, 0] < 90).sum()),
                                Npoint=cfg['Npt'], beam='Airy D=14m on 1deg rect grid, linear PixelBeam interp',
-                               parallelism='baseline-sharded x%d' % world),
+                               parallelism=('channel-sharded x%d' if shard == 'freq' else 'baseline-sharded x%d') % world),
                    roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(inp)

@@ -96,6 +96,50 @@ def test_sharded_forward_backward_equals_single_process():
         assert tot == 3.0
 
 
+def _worker_freq(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        blvecs, freqs, zen, az, sky, beam = _problem()
+        sky = sky.clone().requires_grad_(True)          # replicated full parameters
+        beam = beam.clone().requires_grad_(True)
+        bounds = rdist.shard_bounds(len(freqs), world)  # 5 channels over 2 ranks: 3 + 2
+        s, e = bounds[rank]
+        local = _simulate(blvecs, freqs[s:e], zen, az, sky[:, :, s:e], beam[:, :, :, s:e])
+        full = rdist.all_gather_vis(local, [b - a for a, b in bounds], dim=4)
+        w = torch.as_tensor(np.random.default_rng(9).normal(size=tuple(full.shape)))
+        (w * (full.real ** 2 + full.imag ** 2)).sum().backward()
+        rdist.all_gather_block_grads(sky, 2, bounds)
+        rdist.all_gather_block_grads(beam, 3, bounds)
+        q.put((rank, full.detach().numpy(), sky.grad.numpy(), beam.grad.numpy(), 3.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frequency_sharded_forward_backward_equals_single_process():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_freq, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    blvecs, freqs, zen, az, sky, beam = _problem()
+    sky = sky.clone().requires_grad_(True)
+    beam = beam.clone().requires_grad_(True)
+    full = _simulate(blvecs, freqs, zen, az, sky, beam)
+    w = torch.as_tensor(np.random.default_rng(9).normal(size=tuple(full.shape)))
+    (w * (full.real ** 2 + full.imag ** 2)).sum().backward()
+    for rank, v, gs, gb, _ in res:
+        assert np.abs(v - full.detach().numpy()).max() < 1e-12
+        assert np.abs(gs - sky.grad.numpy()).max() < 1e-9 * np.abs(sky.grad.numpy()).max()
+        assert np.abs(gb - beam.grad.numpy()).max() < 1e-9 * np.abs(beam.grad.numpy()).max()
+
+
 def test_shard_bounds():
     assert rdist.shard_bounds(8128, 8) == [(i * 1016, (i + 1) * 1016) for i in range(8)]
     b = rdist.shard_bounds(171, 4)
