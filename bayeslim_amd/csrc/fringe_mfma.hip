@@ -86,9 +86,13 @@ __device__ __forceinline__ uint4 rot90(const uint4& v)
 // Every block covers at most MF_SPLIT_PIX pixels and STORES its result (no read-modify-write):
 // f32 accumulation inside the MFMA chain stays below eps*sqrt(512/2), and the pixel splits are
 // summed by reduce_vis_kernel in a fixed order (deterministic).
-// (A wave-specialised variant -- 4 MFMA-only waves + 4 generator waves per block, double-buffered
-// images, one block per CU -- measured SLOWER: 15.8 vs 13.7 ms at C4; cross-block overlap at 3
-// blocks per CU hides more latency than one matrix-pipe wave per SIMD can.)
+// Measured at C4 (profiles/r01): 13.7 ms = 8.9 ms with the generator disabled (matrix pipe ~94 %
+// busy) + 6.1 ms of generation -- the two phases do not overlap: co-resident blocks run the loop in
+// lockstep.  Variants tried and measured NOT faster (kept out of the tree for simplicity):
+// 4 MFMA-only + 4 generator waves per block with double-buffered images (15.8 ms); symmetric
+// sqrt|psky| weighting with one image pair + sign masks, double-buffered (14.1 ms); generator
+// pieces interleaved with the MFMA groups in program order (13.8 ms); f32 instead of f64 phase
+// arithmetic (13.5 ms, numerically wrong: shows the f64 ops are not the limiter).
 template <int MF_KP>
 __global__ void __launch_bounds__(256, 2)
 fringe_ant_fwd_kernel(AntArgs A)
