@@ -251,11 +251,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: bayeslim_amd has no CPU path')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # BENCH_DEVICE / BENCH_BACKEND exist only to rehearse the N > 1 code path on a one-GPU box
+    # (all ranks on device 0 over gloo); the driver's runs use one rank per GPU over RCCL
+    devidx = int(os.environ.get('BENCH_DEVICE', local_rank))
+    torch.cuda.set_device(devidx)
+    dev = torch.device('cuda', devidx)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, 'launch N ranks with torch.distributed.run for --gpus N'
 
     from bayeslim_amd import ops, dist as rdist
