@@ -259,10 +259,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get('BENCH_BACKEND', 'nccl')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group(backend)          # 'nccl' == RCCL on ROCm; device chosen by set_device above
     assert world == args.gpus or world == 1, 'launch N ranks with torch.distributed.run for --gpus N'
 
     from bayeslim_amd import ops, dist as rdist
