@@ -65,7 +65,7 @@ def hera_array(kind):
 
 WORKLOADS = {
     # name: array, nside, Nfreqs, Npoint, default Ntimes per step
-    'c4': dict(array='hera128', nside=128, Nf=256, Npt=10000, nt=2,
+    'c4': dict(array='hera128', nside=128, Nf=256, Npt=10000, nt=8,
                desc='HERA-128 (8128 bl), nside=128 diffuse + 1e4 point sources, 256 freqs'),
     'c2': dict(array='hera19', nside=32, Nf=64, Npt=0, nt=30,
                desc='HERA-19 hex (171 bl), nside=32 diffuse sky, 64 freqs, 30 times'),
