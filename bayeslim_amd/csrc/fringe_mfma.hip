@@ -9,20 +9,18 @@
 // baseline formulation.  (Reference arithmetic replaced: the same lines as fringe.hip,
 // telescope_model.py:310-358 + rime_model.py:423-429.)
 //
-// Precision: f32 inputs are split into two f16 halves (hi + lo, 21 significant bits); the three
+// Precision: f32 operands are split into two f16 halves (hi + lo, 21 significant bits); the three
 // cross products hi*hi + hi*lo + lo*hi run on v_mfma_f32_32x32x16_f16 with f32 accumulation
 // (the dropped lo*lo term is 2^-22 relative).  psky rows are pre-scaled by a power of two per
-// (t, f) so that the f16 range is used (`scale` input); accumulators are flushed to memory every
-// 2048 pixels so f32 accumulation error stays ~eps*sqrt(128) per flush.
+// (t, f) so that the f16 range is used (`scale` input).
 //
-// Work decomposition: block = one (t, f [, pixel split]); 4 waves; the upper-triangular 32x32
-// tiles of the Nant x Nant (<= 128 x 128) output are dealt to the waves.  Per panel of 16
-// pixels the block generates E for all antennas once (f64 delay + phase reduction, hardware
-// sin/cos), writes the f16 hi/lo operand images to LDS ([antenna][pixel][re,im], 16-B fragment
-// granules, rows padded to 80 B: conflict-free ds_read_b128), and every wave runs its MFMAs from
-// LDS fragments while the next panel is generated into the other buffer.
+// Work decomposition: block = one (t, f, pixel split); 4 waves; the upper-triangular 32x32 tiles
+// of the Nant x Nant (<= 128 x 128) output are dealt to the waves; per panel of 16 pixels the
+// block generates the operand images once into LDS and every wave runs its MFMAs from LDS
+// fragments (details at the kernels).
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <type_traits>
 #include "rime_common.h"
 
 namespace rime {
@@ -79,147 +77,222 @@ __device__ __forceinline__ uint4 rot90(const uint4& v)
     return r;
 }
 
-// KP = pixels per panel (16 = two MFMA K-steps of 8 pixels).  LDS rows are KP*4 + 16 bytes, an odd
-// number of 16-B granules, so the 16 lanes of a ds_read_b128 group hit 16 distinct granules.
-// One LDS buffer (4 images, 40 KB) and two barriers per panel: several blocks are resident per CU,
-// so one block's operand generation (VALU) runs under another block's MFMAs.
+// ---------------------------------------------------------------------------------------
+// forward kernel
+//
+// Measured on gfx950 (tools/overlap_lab.hip, profiles/r01/overlap_lab.txt): VALU instructions and
+// MFMAs issued on one SIMD do NOT overlap -- a wave streaming v_mfma_f32_32x32x16_f16 starves the
+// VALU work of every other wave on its SIMD (s_setprio, s_nop padding and de-phasing co-resident
+// blocks change nothing), and inside one wave only ~3 VALU ops hide under each MFMA.  Kernel time
+// is therefore (MFMA issue time) + (VALU issue time), and the design minimises both:
+//   * symmetric weighting: L = B = sqrt(|psky| scale) E, so ONE operand image pair (f16 hi, lo) is
+//     generated per (antenna, pixel) instead of two; the sign of psky is applied as an XOR mask on
+//     the row-tile fragments (per wave: 16 v_xor per distinct row tile and panel);
+//   * re and im live in separate K-planes ([antenna][16 px re | 16 px im]), K = 16 pixels per
+//     MFMA.  Vr = Lr.Br + Li.Bi,  Vi = Lr.Bi - Li.Br with the two Vi products kept in separate
+//     accumulators and subtracted in the epilogue: no operand rotation / negation work at all;
+//   * the 10 upper-triangular 32x32 tiles are dealt to the 4 waves as 20 (tile, re|im) units,
+//     5 each (30 MFMAs per wave and panel; a 3/3/2/2 deal of whole tiles idles 17 % of the pipe);
+//   * a thread generates 2 adjacent pixels x TA antennas whose coordinates (pre-multiplied by
+//     sign nu/c) stay in registers: per pair 3 f64 FMA + fract + cvt + sin + cos + mul and half
+//     a hi/lo split; packed (p, p+1) f16 pairs go out as conflict-free ds_write_b32;
+//   * LDS images are double buffered: one barrier per 16-pixel panel.
 // Every block covers at most MF_SPLIT_PIX pixels and STORES its result (no read-modify-write):
-// f32 accumulation inside the MFMA chain stays below eps*sqrt(512/2), and the pixel splits are
+// f32 accumulation inside the MFMA chain stays below eps*sqrt(512), and the pixel splits are
 // summed by reduce_vis_kernel in a fixed order (deterministic).
-// Measured at C4 (profiles/r01): 13.7 ms = 8.9 ms with the generator disabled (matrix pipe ~94 %
-// busy) + 6.1 ms of generation -- the two phases do not overlap: co-resident blocks run the loop in
-// lockstep.  Variants tried and measured NOT faster (kept out of the tree for simplicity):
-// 4 MFMA-only + 4 generator waves per block with double-buffered images (15.8 ms); symmetric
-// sqrt|psky| weighting with one image pair + sign masks, double-buffered (14.1 ms); generator
-// pieces interleaved with the MFMA groups in program order (13.8 ms); f32 instead of f64 phase
-// arithmetic (13.5 ms, numerically wrong: shows the f64 ops are not the limiter).
-template <int MF_KP>
-__global__ void __launch_bounds__(256, 2)
-fringe_ant_fwd_kernel(AntArgs A)
-{
-    constexpr int MF_ROWB = MF_KP * 4 + 16;
-    constexpr int MF_IMG = MF_NA * MF_ROWB;
-    constexpr int GPL = MF_KP;                  // lanes per pixel group in the generation mapping
-    constexpr int APT = MF_NA * MF_KP / 256;    // antennas per thread per panel
-    extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* img = smem;                                         // 4 images: L hi, L lo, B hi, B lo
-    double* ant_lds = reinterpret_cast<double*>(smem + 4 * MF_IMG);    // [128][3]
+// History (C4 shape, 128 antennas, 256 channels x 2 times, 98304 px): interleaved (re,im) K layout
+// with separate L/B images, rot90 on the fly and whole-tile deal: 13.4 ms.
+// ---------------------------------------------------------------------------------------
+constexpr int MF_KP = 16;                       // pixels per panel = K of one MFMA
+constexpr int MF_ROWB = 4 * MF_KP + 16;         // [re 16 x f16][im 16 x f16][pad]: 5 granules (odd)
+constexpr int MF_IMG = MF_NA * MF_ROWB;         // one image (hi or lo)
+constexpr int MF_BUF = 2 * MF_IMG + 64;         // hi + lo + sign dwords of the panel
+constexpr size_t MF_LDS = 2 * (size_t)MF_BUF;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__host__ __device__ constexpr int tri_row(int TA, int idx) { int ti = 0; while (idx >= TA - ti) { idx -= TA - ti; ++ti; } return ti; }
+__host__ __device__ constexpr int tri_col(int TA, int idx) { int ti = 0; while (idx >= TA - ti) { idx -= TA - ti; ++ti; } return ti + idx; }
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+#define RIME_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag(a), as_frag(b), c, 0, 0, 0)
+
+template <int TA, int W>
+__device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* smem)
+{
+    constexpr int NT = TA * (TA + 1) / 2, NU = 2 * NT, UPW = (NU + 3) / 4, U0 = UPW * W;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int f = blockIdx.y;
     const int t = blockIdx.z / A.S, split = blockIdx.z % A.S;
-    const int TA = (A.Nant + 31) / 32;
 
-    for (int i = tid; i < MF_NA * 3; i += 256)
-        ant_lds[i] = (i < A.Nant * 3) ? A.sign * A.antpos[i] : 0.0;
-
-    const double nu_c = A.freqs[f] * (1.0 / 2.99792458e8);
+    const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
     const float scl = A.scale[t * A.Nf + f];
     const float* arow = A.psky + (size_t)t * A.st_t + (size_t)f * A.st_f;
     const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
 
-    // this wave's tiles: w, w+4, w+8 of the row-major upper-triangle enumeration
-    int ti[3], tj[3], nt = 0;
-    {
-        int idx = 0;
-        for (int a = 0; a < TA; ++a)
-            for (int b = a; b < TA; ++b, ++idx)
-                if ((idx & 3) == wave && nt < 3) { ti[nt] = a; tj[nt] = b; ++nt; }
+    // generation mapping: lane = (pixel pair pp, antenna slot ag); rows of one ds_write are 2 apart
+    // (80-B rows: 8 rows x 32 B land in 16 distinct 16-B granules of the 64 banks)
+    const int pp = lane & 7, ag = lane >> 3;
+    const int grow = 2 * ag + 16 * (W & 1) + (W >> 1);
+    double ax[TA], ay[TA], az[TA];
+#pragma unroll
+    for (int u = 0; u < TA; ++u) {
+        const int an = 32 * u + grow;
+        const bool ok = an < A.Nant;
+        ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
+        ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
+        az[u] = ok ? nu_c * A.antpos[3 * an + 2] : 0.0;
     }
-    f32x16 accR[3], accI[3];
+    const int goff = grow * MF_ROWB + pp * 4;
+
+    f32x16 acc[UPW][2];
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int s = 0; s < UPW; ++s)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { accR[q][e] = 0.f; accI[q][e] = 0.f; }
+        for (int e = 0; e < 16; ++e) { acc[s][0][e] = 0.f; acc[s][1][e] = 0.f; }
 
     const int npanel = A.Pstride / MF_KP;
     const int pbeg = split * A.panels_per_split;
     const int pend = min(npanel, pbeg + A.panels_per_split);
+    if (pbeg >= pend) return;                        // uniform over the block
 
-    // generation mapping: 16 consecutive lanes = the 16 pixels of the panel; a thread handles its
-    // pixel for APT consecutive antennas
-    const int gp = tid & (GPL - 1), ga0 = (tid / GPL) * APT;
-    unsigned char* gbase = img + gp * 4 + ga0 * MF_ROWB;
-    const int koff = 4 * (lane >> 5) * 4;                              // this lane half's 4 pixels
-    int roff[3], coff[3];
+    double2 sx, sy, sz; float2 av;
+    auto fetch = [&](int panel) {
+        const int p = panel * MF_KP + 2 * pp;
+        sx = *reinterpret_cast<const double2*>(sd + p);
+        sy = *reinterpret_cast<const double2*>(sd + A.Pstride + p);
+        sz = *reinterpret_cast<const double2*>(sd + 2 * (size_t)A.Pstride + p);
+        av = *reinterpret_cast<const float2*>(arow + p);
+    };
+    auto generate = [&](unsigned char* buf, int next_panel) {
+        const float w0 = __builtin_amdgcn_sqrtf(fabsf(av.x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av.y) * scl);
+        if (tid < 8)
+            *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * pp) =
+                ((__float_as_uint(av.x) >> 16) & 0x8000u) | (__float_as_uint(av.y) & 0x80000000u);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        roff[q] = (ti[q < nt ? q : 0] * 32 + (lane & 31)) * MF_ROWB + koff;
-        coff[q] = (tj[q < nt ? q : 0] * 32 + (lane & 31)) * MF_ROWB + koff + 2 * MF_IMG;
-    }
+        for (int u = 0; u < TA; ++u) {
+            const double ph0 = ax[u] * sx.x + ay[u] * sy.x + az[u] * sz.x;
+            const double ph1 = ax[u] * sx.y + ay[u] * sy.y + az[u] * sz.y;
+            const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+            const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
+            const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+            uint32_t rh, rl, ih, il;
+            split2(w0 * c0, w1 * c1, rh, rl);
+            split2(w0 * s0, w1 * s1, ih, il);
+            unsigned char* o = buf + goff + u * 32 * MF_ROWB;
+            *reinterpret_cast<uint32_t*>(o) = rh;
+            *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+            *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+            *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+        }
+        fetch(next_panel);                           // latency hidden by the MFMA phase
+    };
 
-    for (int panel = pbeg; panel < pend; ++panel) {
-        __syncthreads();                               // previous panel's fragments consumed
-        {
-            const int p = panel * MF_KP + gp;
-            // pointing vector pre-multiplied by nu/c: the antenna dot product is the phase in turns
-            const double ux = sd[p] * nu_c, uy = sd[A.Pstride + p] * nu_c, uz = sd[2 * (size_t)A.Pstride + p] * nu_c;
-            const float a = arow[p] * scl;
-#pragma unroll 2
-            for (int u = 0; u < APT; ++u) {
-                const int an = ga0 + u;
-                const double ph = ant_lds[3 * an] * ux + ant_lds[3 * an + 1] * uy + ant_lds[3 * an + 2] * uz;
-                const float r = (float)(ph - rint(ph));
-                const float s = __builtin_amdgcn_sinf(r), c = __builtin_amdgcn_cosf(r);
-                uint32_t hi, lo;
-                split2(c, s, hi, lo);
-                *reinterpret_cast<uint32_t*>(gbase + 0 * MF_IMG + u * MF_ROWB) = hi;
-                *reinterpret_cast<uint32_t*>(gbase + 1 * MF_IMG + u * MF_ROWB) = lo;
-                split2(a * c, a * s, hi, lo);
-                *reinterpret_cast<uint32_t*>(gbase + 2 * MF_IMG + u * MF_ROWB) = hi;
-                *reinterpret_cast<uint32_t*>(gbase + 3 * MF_IMG + u * MF_ROWB) = lo;
+    const int foff = (lane & 31) * MF_ROWB + (lane >> 5) * 16;   // fragment: row, k-half
+    auto contract = [&](const unsigned char* buf) {
+        const uint4 sg = *reinterpret_cast<const uint4*>(buf + 2 * MF_IMG + (lane >> 5) * 16);
+        auto frag = [&](int tile, int img, int im) {
+            return *reinterpret_cast<const uint4*>(buf + img * MF_IMG + tile * 32 * MF_ROWB + foff + im * 2 * MF_KP);
+        };
+        auto sfrag = [&](int tile, int img, int im) {
+            uint4 v = frag(tile, img, im);
+#if !defined(RIME_ABL_NOSIGN)
+            v.x ^= sg.x; v.y ^= sg.y; v.z ^= sg.z; v.w ^= sg.w;
+#endif
+            return v;
+        };
+        constexpr int UE = (U0 + UPW < NU) ? U0 + UPW : NU;          // this wave's units: [U0, UE)
+        constexpr int T0 = U0 >> 1, T1 = (UE + 1) >> 1;               // its tiles: [T0, T1)
+        uint4 Lrh, Lih, Lrl, Lil;                                     // sign-applied row-tile fragments
+        static_for<T0, T1>([&](auto tc) {
+            constexpr int tile = decltype(tc)::value;
+            constexpr bool hasR = 2 * tile >= U0, hasI = 2 * tile + 1 < UE;
+            constexpr int sR = hasR ? 2 * tile - U0 : 0, sI = hasI ? 2 * tile + 1 - U0 : 0;   // accumulator slots
+            constexpr int ti = tri_row(TA, tile), tj = tri_col(TA, tile);
+            if constexpr (tile == T0 || tri_row(TA, tile > 0 ? tile - 1 : 0) != ti) {
+                Lrh = sfrag(ti, 0, 0); Lih = sfrag(ti, 0, 1); Lrl = sfrag(ti, 1, 0); Lil = sfrag(ti, 1, 1);
             }
+            const uint4 Brh = frag(tj, 0, 0), Bih = frag(tj, 0, 1), Brl = frag(tj, 1, 0), Bil = frag(tj, 1, 1);
+            // real part Lr.Br + Li.Bi -> acc[sR][0]; imaginary part Lr.Bi -> acc[sI][0], Li.Br -> acc[sI][1]
+            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh, Brh, acc[sR][0]);
+            if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh, Bih, acc[sI][0]);
+            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih, Bih, acc[sR][0]);
+            if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih, Brh, acc[sI][1]);
+            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh, Brl, acc[sR][0]);
+            if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh, Bil, acc[sI][0]);
+            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih, Bil, acc[sR][0]);
+            if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih, Brl, acc[sI][1]);
+            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrl, Brh, acc[sR][0]);
+            if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrl, Bih, acc[sI][0]);
+            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lil, Bih, acc[sR][0]);
+            if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lil, Brh, acc[sI][1]);
+        });
+    };
+
+    // two panels per trip: buffer addresses are compile-time offsets
+    unsigned char* const buf0 = smem;
+    unsigned char* const buf1 = smem + MF_BUF;
+    fetch(pbeg);
+    generate(buf0, min(pbeg + 1, pend - 1));
+    __syncthreads();
+#if defined(RIME_ABL_NOGEN)
+#define RIME_GEN(b, n) if (panel < pbeg + 2) generate(b, n)
+#else
+#define RIME_GEN(b, n) generate(b, n)
+#endif
+#if defined(RIME_ABL_NOMFMA)
+#define RIME_CON(b) { const uint4 q = *reinterpret_cast<const uint4*>(b + foff); acc[0][0][0] += __uint_as_float(q.x ^ q.y ^ q.z ^ q.w); }
+#else
+#define RIME_CON(b) contract(b)
+#endif
+    for (int panel = pbeg; panel < pend; panel += 2) {
+        if (panel + 1 < pend) RIME_GEN(buf1, min(panel + 2, pend - 1));
+        RIME_CON(buf0);
+        __syncthreads();
+        if (panel + 1 < pend) {
+            if (panel + 2 < pend) RIME_GEN(buf0, min(panel + 3, pend - 1));
+            RIME_CON(buf1);
         }
         __syncthreads();
-        {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (q < nt) {
-#pragma unroll
-                    for (int ks = 0; ks < MF_KP / 8; ++ks) {
-                        const uint4 Lh = *reinterpret_cast<const uint4*>(img + roff[q] + ks * 32);
-                        const uint4 Ll = *reinterpret_cast<const uint4*>(img + roff[q] + ks * 32 + MF_IMG);
-                        const uint4 Bh = *reinterpret_cast<const uint4*>(img + coff[q] + ks * 32);
-                        const uint4 Bl = *reinterpret_cast<const uint4*>(img + coff[q] + ks * 32 + MF_IMG);
-                        const f16x8 lh = as_frag(Lh), ll = as_frag(Ll), bh = as_frag(Bh), bl = as_frag(Bl);
-                        const f16x8 lh2 = as_frag(rot90(Lh)), ll2 = as_frag(rot90(Ll));
-                        accR[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh, bh, accR[q], 0, 0, 0);
-                        accI[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh2, bh, accI[q], 0, 0, 0);
-                        accR[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh, bl, accR[q], 0, 0, 0);
-                        accI[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh2, bl, accI[q], 0, 0, 0);
-                        accR[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ll, bh, accR[q], 0, 0, 0);
-                        accI[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ll2, bh, accI[q], 0, 0, 0);
-                    }
-                }
-            }
-        }
     }
 
-    // epilogue: V[i,j] / scale -> the baseline slot(s) of pair (i,j); one store per element
+    // epilogue: V[i,j] / scale -> the baseline slot(s) of pair (i,j)
     const size_t vis_elems = (size_t)A.Nbl * A.Nt * A.Nf * 2;
     float* dst = (A.S == 1) ? A.vis : A.ws + (size_t)split * vis_elems;
     const float inv = 1.0f / scl;
     const int col = lane & 31;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        if (q < nt) {
+    for (int s = 0; s < UPW; ++s) {
+        const int u = U0 + s;
+        if (u < NU) {
+            const int ti = tri_row(TA, u >> 1), tj = tri_col(TA, u >> 1), im = u & 1;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int i = ti[q] * 32 + row, j = tj[q] * 32 + col;
-                const float vr = accR[q][e] * inv, vi = accI[q][e] * inv;
+                const int i = ti * 32 + row, j = tj * 32 + col;
+                const float v = (im ? acc[s][0][e] - acc[s][1][e] : acc[s][0][e]) * inv;
                 const int bd = A.pair_direct[i * MF_NA + j];
-                if (bd >= 0) {
-                    float2* o = reinterpret_cast<float2*>(dst + (((size_t)bd * A.Nt + t) * A.Nf + f) * 2);
-                    *o = make_float2(vr, vi);
-                }
+                if (bd >= 0) dst[(((size_t)bd * A.Nt + t) * A.Nf + f) * 2 + im] = v;
                 const int bc = A.pair_conj[i * MF_NA + j];
-                if (bc >= 0) {
-                    float2* o = reinterpret_cast<float2*>(dst + (((size_t)bc * A.Nt + t) * A.Nf + f) * 2);
-                    *o = make_float2(vr, -vi);
-                }
+                if (bc >= 0) dst[(((size_t)bc * A.Nt + t) * A.Nf + f) * 2 + im] = im ? -v : v;
             }
         }
+    }
+}
+
+template <int TA>
+__global__ void __launch_bounds__(256, 2)
+fringe_ant_fwd_kernel(AntArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    switch (threadIdx.x >> 6) {                      // wave-uniform: every wave runs the same barriers
+        case 0: ant_fwd_body<TA, 0>(A, smem); break;
+        case 1: ant_fwd_body<TA, 1>(A, smem); break;
+        case 2: ant_fwd_body<TA, 2>(A, smem); break;
+        default: ant_fwd_body<TA, 3>(A, smem); break;
     }
 }
 
@@ -230,10 +303,16 @@ fringe_ant_fwd_kernel(AntArgs A)
 // G[i,j] (tile(i) <= tile(j)) collects gvis of pair (i -> j) and the conjugate of pair (j -> i)
 // through the same two tables as the forward.  T is a block-upper-triangular complex GEMM
 // (M = antennas i, N = pixels, K = antennas j) on v_mfma_f32_32x32x16_f16 with the same hi/lo
-// f16 split; G (scaled by a power of two per (t,f)) sits in LDS in A-fragment order for the whole
-// block, E fragments are generated in registers by the lane that consumes them (lane = pixel, so
-// every E value is computed exactly once), and the final contraction with E_i is lane-local:
-// the D rows a lane holds are exactly the antennas it generated.  No atomics.
+// f16 split.  Planar K layout (16 antennas per MFMA):
+//     Tr += Gr.Er + Gi.Ei,     Ti += Gr.Ei + (-Gi).Er
+// G (scaled by a power of two per (t,f)) sits in LDS for the whole block as six planes in
+// A-fragment order (Gr, Gi, -Gi; hi and lo), so no operand is rotated or negated in the loop (VALU
+// and MFMA issue do not overlap on gfx950, see the forward kernel).  E fragments are generated in
+// registers by the lane that consumes them (lane = pixel, so every E value is computed exactly
+// once); the K index of a fragment is mapped to antennas so that the D rows a lane holds are
+// exactly the antennas it generated, which makes the final contraction with E_i lane-local.
+// No atomics.  History at the C4 shape: interleaved (re,im) K layout with rot90 of the G fragments
+// on the fly: 11.1 ms.
 // ---------------------------------------------------------------------------------------
 struct AntBwdArgs {
     const double* antpos; const double* sdir; const double* freqs;
@@ -247,8 +326,9 @@ struct AntBwdArgs {
     double sign;
 };
 
-constexpr int MB_TILES = 10;                       // upper-triangular 32x32 tiles of a 128x128 matrix
-constexpr int MB_GIMG = MB_TILES * 4 * 2 * 32 * 16;  // bytes per G image (hi or lo): 40960
+constexpr int MB_TILES = 10;                        // upper-triangular 32x32 tiles of a 128x128 matrix
+constexpr int MB_PLANE = MB_TILES * 2 * 2 * 32 * 16;  // bytes per G plane: (tile, ks, h, row) x 8 f16 = 20480
+constexpr size_t MB_LDS = 6 * (size_t)MB_PLANE + MF_NA * 3 * sizeof(double);
 
 __device__ __forceinline__ int tri_index(int ti, int tj) { return ti * 4 - ti * (ti - 1) / 2 + (tj - ti); }
 
@@ -256,47 +336,57 @@ __global__ void __launch_bounds__(512, 2)
 fringe_ant_bwd_kernel(AntBwdArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* g_img = smem;                                          // 2 images (hi, lo)
-    double* ant_lds = reinterpret_cast<double*>(smem + 2 * MB_GIMG);      // [128][3]
+    unsigned char* g_img = smem;              // planes: 0 Gr_hi, 1 Gi_hi, 2 -Gi_hi, 3 Gr_lo, 4 Gi_lo, 5 -Gi_lo
+    double* ant_lds = reinterpret_cast<double*>(smem + 6 * MB_PLANE);      // [128][3]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f = blockIdx.y;
     const int t = blockIdx.z / A.S, split = blockIdx.z % A.S;
     const int TA = (A.Nant + 31) / 32;
 
+    const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
     for (int i = tid; i < MF_NA * 3; i += 512)
-        ant_lds[i] = (i < A.Nant * 3) ? A.sign * A.antpos[i] : 0.0;
+        ant_lds[i] = (i < A.Nant * 3) ? nu_c * A.antpos[i] : 0.0;
 
-    // stage G: element (tile, ks, h, row, r) <-> pair (i = 32 ti + row, j = 32 tj + 8 ks + 4 h + r)
+    // stage G: fragment element (tile, ks, h, row, jj) <-> pair (i = 32 ti + row,
+    // j = 32 tj + (jj & 3) + 8 (2 ks + (jj >> 2)) + 4 h); a thread packs the (jj, jj + 1) pair
     const float gs = A.gscale[t * A.Nf + f];
-    for (int e = tid; e < MB_TILES * 4 * 2 * 32 * 4; e += 512) {
-        const int r = e & 3, row = (e >> 2) & 31, h = (e >> 7) & 1, ks = (e >> 8) & 3, tile = e >> 10;
+    for (int e = tid; e < MB_TILES * 2 * 2 * 32 * 4; e += 512) {
+        const int jp = e & 3, row = (e >> 2) & 31, h = (e >> 7) & 1, ks = (e >> 8) & 1, tile = e >> 9;
         int ti = 0, rem = tile;
         while (rem >= 4 - ti) { rem -= 4 - ti; ++ti; }
         const int tj = ti + rem;
-        const int i = 32 * ti + row, j = 32 * tj + 8 * ks + 4 * h + r;
-        float gr = 0.f, gi = 0.f;
+        const int i = 32 * ti + row;
+        const int j0 = 32 * tj + ((2 * jp) & 3) + 8 * (2 * ks + (jp >> 1)) + 4 * h;
+        float gr[2] = {0.f, 0.f}, gi[2] = {0.f, 0.f};
         if (ti < TA && tj < TA) {
-            const int bd = A.pair_direct[i * MF_NA + j];
-            if (bd >= 0) {
-                const float* g = A.gvis + (((size_t)bd * A.Nt + t) * A.Nf + f) * 2;
-                gr += g[0]; gi += g[1];
-            }
-            const int bc = A.pair_conj[i * MF_NA + j];
-            if (bc >= 0) {
-                const float* g = A.gvis + (((size_t)bc * A.Nt + t) * A.Nf + f) * 2;
-                gr += g[0]; gi -= g[1];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int bd = A.pair_direct[i * MF_NA + j0 + q];
+                if (bd >= 0) {
+                    const float* g = A.gvis + (((size_t)bd * A.Nt + t) * A.Nf + f) * 2;
+                    gr[q] += g[0]; gi[q] += g[1];
+                }
+                const int bc = A.pair_conj[i * MF_NA + j0 + q];
+                if (bc >= 0) {
+                    const float* g = A.gvis + (((size_t)bc * A.Nt + t) * A.Nf + f) * 2;
+                    gr[q] += g[0]; gi[q] -= g[1];
+                }
             }
         }
-        uint32_t hi, lo;
-        split2(gr * gs, gi * gs, hi, lo);
-        const int off = ((((tile * 4 + ks) * 2 + h) * 32 + row) * 4 + r) * 4;
-        *reinterpret_cast<uint32_t*>(g_img + off) = hi;
-        *reinterpret_cast<uint32_t*>(g_img + MB_GIMG + off) = lo;
+        uint32_t rh, rl, ih, il;
+        split2(gr[0] * gs, gr[1] * gs, rh, rl);
+        split2(gi[0] * gs, gi[1] * gs, ih, il);
+        const int off = ((((tile * 2 + ks) * 2 + h) * 32 + row) * 4 + jp) * 4;
+        *reinterpret_cast<uint32_t*>(g_img + 0 * MB_PLANE + off) = rh;
+        *reinterpret_cast<uint32_t*>(g_img + 1 * MB_PLANE + off) = ih;
+        *reinterpret_cast<uint32_t*>(g_img + 2 * MB_PLANE + off) = ih ^ 0x80008000u;
+        *reinterpret_cast<uint32_t*>(g_img + 3 * MB_PLANE + off) = rl;
+        *reinterpret_cast<uint32_t*>(g_img + 4 * MB_PLANE + off) = il;
+        *reinterpret_cast<uint32_t*>(g_img + 5 * MB_PLANE + off) = il ^ 0x80008000u;
     }
     __syncthreads();
 
-    const double nu_c = A.freqs[f] * (1.0 / 2.99792458e8);
     const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
     float* orow = A.gpsky + (size_t)t * A.st_t + (size_t)f * A.st_f;
     const float inv = 1.0f / gs;
@@ -307,7 +397,7 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
 
     for (int pt = tbeg + wave; pt < tend; pt += 8) {
         const int p = pt * 32 + (lane & 31);
-        const double sx = sd[p] * nu_c, sy = sd[A.Pstride + p] * nu_c, sz = sd[2 * (size_t)A.Pstride + p] * nu_c;
+        const double sx = sd[p], sy = sd[A.Pstride + p], sz = sd[2 * (size_t)A.Pstride + p];
         f32x16 accR[4], accI[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -318,44 +408,55 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
         for (int tjr = 0; tjr < 4; ++tjr) {
             const int tj = 3 - tjr;                          // descending: row tile tj completes here
             if (tj < TA) {
-                float ec[4][4], es[4][4];
+                float ec[16], es[16];                        // E of antennas 32 tj + (e&3) + 8 (e>>2) + 4 h
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    uint4 Eh, El;
-                    uint32_t* eh = reinterpret_cast<uint32_t*>(&Eh);
-                    uint32_t* el = reinterpret_cast<uint32_t*>(&El);
+                for (int ks = 0; ks < 2; ++ks) {
+                    uint4 Erh, Erl, Eih, Eil;
+                    uint32_t* erh = reinterpret_cast<uint32_t*>(&Erh); uint32_t* erl = reinterpret_cast<uint32_t*>(&Erl);
+                    uint32_t* eih = reinterpret_cast<uint32_t*>(&Eih); uint32_t* eil = reinterpret_cast<uint32_t*>(&Eil);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int an = 32 * tj + 8 * ks + 4 * h + r;
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int an = 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
                         const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
-                        const float rr = (float)(ph - rint(ph));
-                        const float s = __builtin_amdgcn_sinf(rr), c = __builtin_amdgcn_cosf(rr);
-                        ec[ks][r] = c; es[ks][r] = s;
-                        split2(c, s, eh[r], el[r]);
+                        const float rr = (float)__builtin_amdgcn_fract(ph);
+                        ec[8 * ks + jj] = __builtin_amdgcn_cosf(rr);
+                        es[8 * ks + jj] = __builtin_amdgcn_sinf(rr);
                     }
-                    const f16x8 bh = as_frag(Eh), bl = as_frag(El);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        split2(ec[8 * ks + 2 * q], ec[8 * ks + 2 * q + 1], erh[q], erl[q]);
+                        split2(es[8 * ks + 2 * q], es[8 * ks + 2 * q + 1], eih[q], eil[q]);
+                    }
 #pragma unroll
                     for (int ti = 0; ti < 4; ++ti) {
                         if (ti <= tj) {
-                            const int off = (((tri_index(ti, tj) * 4 + ks) * 2 + h) * 32 + (lane & 31)) * 16;
-                            const uint4 Gh = *reinterpret_cast<const uint4*>(g_img + off);
-                            const uint4 Gl = *reinterpret_cast<const uint4*>(g_img + MB_GIMG + off);
-                            const f16x8 gh = as_frag(Gh), gl = as_frag(Gl);
-                            const f16x8 gh2 = as_frag(rot90(Gh)), gl2 = as_frag(rot90(Gl));
-                            accR[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, bh, accR[ti], 0, 0, 0);
-                            accI[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh2, bh, accI[ti], 0, 0, 0);
-                            accR[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, bl, accR[ti], 0, 0, 0);
-                            accI[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh2, bl, accI[ti], 0, 0, 0);
-                            accR[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, bh, accR[ti], 0, 0, 0);
-                            accI[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl2, bh, accI[ti], 0, 0, 0);
+                            const int off = (((tri_index(ti, tj) * 2 + ks) * 2 + h) * 32 + (lane & 31)) * 16;
+                            const uint4 Grh = *reinterpret_cast<const uint4*>(g_img + 0 * MB_PLANE + off);
+                            const uint4 Gih = *reinterpret_cast<const uint4*>(g_img + 1 * MB_PLANE + off);
+                            const uint4 Gnh = *reinterpret_cast<const uint4*>(g_img + 2 * MB_PLANE + off);
+                            const uint4 Grl = *reinterpret_cast<const uint4*>(g_img + 3 * MB_PLANE + off);
+                            const uint4 Gil = *reinterpret_cast<const uint4*>(g_img + 4 * MB_PLANE + off);
+                            const uint4 Gnl = *reinterpret_cast<const uint4*>(g_img + 5 * MB_PLANE + off);
+                            accR[ti] = RIME_MFMA(Grh, Erh, accR[ti]);
+                            accI[ti] = RIME_MFMA(Grh, Eih, accI[ti]);
+                            accR[ti] = RIME_MFMA(Gih, Eih, accR[ti]);
+                            accI[ti] = RIME_MFMA(Gnh, Erh, accI[ti]);
+                            accR[ti] = RIME_MFMA(Grh, Erl, accR[ti]);
+                            accI[ti] = RIME_MFMA(Grh, Eil, accI[ti]);
+                            accR[ti] = RIME_MFMA(Gih, Eil, accR[ti]);
+                            accI[ti] = RIME_MFMA(Gnh, Erl, accI[ti]);
+                            accR[ti] = RIME_MFMA(Grl, Erh, accR[ti]);
+                            accI[ti] = RIME_MFMA(Grl, Eih, accI[ti]);
+                            accR[ti] = RIME_MFMA(Gil, Eih, accR[ti]);
+                            accI[ti] = RIME_MFMA(Gnl, Erh, accI[ti]);
                         }
                     }
                 }
                 // row tile tj is complete: contract with E_i of the same antennas (lane-local)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    part = fmaf(ec[e >> 2][e & 3], accR[tj][e], part);
-                    part = fmaf(es[e >> 2][e & 3], accI[tj][e], part);
+                    part = fmaf(ec[e], accR[tj][e], part);
+                    part = fmaf(es[e], accI[tj][e], part);
                 }
             }
         }
@@ -409,7 +510,7 @@ extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, con
     A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.vis = vis; A.ws = (float*)workspace;
     A.Nant = Nant; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
     A.st_t = st_t; A.st_f = st_f; A.sign = (double)sign;
-    constexpr int KP = 16;
+    constexpr int KP = MF_KP;
     A.S = ant_splits(Nt, Nf, Pstride);
     const int npanel = Pstride / KP;
     A.panels_per_split = (npanel + A.S - 1) / A.S;
@@ -418,9 +519,13 @@ extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, con
     const size_t vis_elems = (size_t)Nbl * Nt * Nf * 2;
     if (A.S > 1 && workspace_bytes < (size_t)A.S * vis_elems * sizeof(float)) return RIME_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t lds = 4 * (size_t)MF_NA * (KP * 4 + 16) + MF_NA * 3 * sizeof(double);
     dim3 grid(1, Nf, Nt * A.S);
-    hipLaunchKernelGGL((fringe_ant_fwd_kernel<KP>), grid, dim3(256), lds, st, A);
+    switch ((Nant + 31) / 32) {
+        case 1: hipLaunchKernelGGL((fringe_ant_fwd_kernel<1>), grid, dim3(256), MF_LDS, st, A); break;
+        case 2: hipLaunchKernelGGL((fringe_ant_fwd_kernel<2>), grid, dim3(256), MF_LDS, st, A); break;
+        case 3: hipLaunchKernelGGL((fringe_ant_fwd_kernel<3>), grid, dim3(256), MF_LDS, st, A); break;
+        default: hipLaunchKernelGGL((fringe_ant_fwd_kernel<4>), grid, dim3(256), MF_LDS, st, A); break;
+    }
     if (A.S > 1) {
         int nb = (int)std::min<size_t>((vis_elems + 255) / 256, 4096);
         hipLaunchKernelGGL((reduce_vis_kernel<float>), dim3(nb), dim3(256), 0, st, A.ws, vis, vis_elems, A.S);
@@ -450,8 +555,7 @@ extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, con
     A.tiles_per_split = per;
     A.S = (ntile + per - 1) / per;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t lds = 2 * (size_t)MB_GIMG + MF_NA * 3 * sizeof(double);
     dim3 grid(1, Nf, Nt * A.S);
-    hipLaunchKernelGGL(fringe_ant_bwd_kernel, grid, dim3(512), lds, st, A);
+    hipLaunchKernelGGL(fringe_ant_bwd_kernel, grid, dim3(512), MB_LDS, st, A);
     return check_launch();
 }

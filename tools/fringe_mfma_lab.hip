@@ -60,7 +60,8 @@ int main(int argc, char** argv)
     size_t nvis = (size_t)Nbl * Nt * Nf * 2;
     CHK(hipMalloc(&dant, ant.size() * 8)); CHK(hipMalloc(&dbl, bl.size() * 8)); CHK(hipMalloc(&dsd, sd.size() * 8));
     CHK(hipMalloc(&dfr, fr.size() * 8)); CHK(hipMalloc(&dps, npsky * 4)); CHK(hipMalloc(&dsc, sc.size() * 4));
-    CHK(hipMalloc(&dv1, nvis * 4)); CHK(hipMalloc(&dv2, nvis * 4)); CHK(hipMalloc(&dws, nvis * 4 * 64));
+    CHK(hipMalloc(&dv1, nvis * 4)); CHK(hipMalloc(&dv2, nvis * 4)); size_t wsb = std::max(std::max(rime_fringe_sum_workspace(RIME_F32, Nbl, Nt, Nf, P, 1, 1, 0, 0), rime_fringe_sum_workspace(RIME_F32, Nbl, Nt, Nf, P, 1, 1, 0, 1)), rime_fringe_ant_workspace(Nbl, Nt, Nf, P)) + 256;
+    CHK(hipMalloc(&dws, wsb));
     CHK(hipMalloc(&dpd, pd.size() * 4)); CHK(hipMalloc(&dpc, pc.size() * 4));
     CHK(hipMemcpy(dant, ant.data(), ant.size() * 8, hipMemcpyHostToDevice));
     CHK(hipMemcpy(dbl, bl.data(), bl.size() * 8, hipMemcpyHostToDevice));
@@ -78,19 +79,22 @@ int main(int argc, char** argv)
     for (int r = 0; r < 2; ++r) {
         CHK(hipEventRecord(e0));
         int rc = rime_fringe_sum_fwd(RIME_F32, dbl, dsd, dfr, dps, off, nullptr, Nbl, Nt, Nf, P, 1, 1, 0, 1,
-                                     1, fr[0], fr[1] - fr[0], 300.0, nullptr, dv1, dws, nvis * 4 * 64, 0);
+                                     1, fr[0], fr[1] - fr[0], 300.0, nullptr, dv1, dws, wsb, 0);
         CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
         if (rc) { printf("valu rc=%d\n", rc); return 1; }
         CHK(hipEventElapsedTime(&ms1, e0, e1));
     }
-    for (int r = 0; r < 2; ++r) {
+    float ms2min = 1e9f;
+    for (int r = 0; r < 6; ++r) {
         CHK(hipEventRecord(e0));
         int rc = rime_fringe_ant_fwd(dant, dsd, dfr, dps, dsc, dpd, dpc, Nant, Nbl, Nt, Nf, P,
-                                     (long long)Nf * P, (long long)P, 1, dv2, dws, nvis * 4 * 64, 0);
+                                     (long long)Nf * P, (long long)P, 1, dv2, dws, wsb, 0);
         CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
         if (rc) { printf("mfma rc=%d (%s)\n", rc, rime_last_error()); return 1; }
         CHK(hipEventElapsedTime(&ms2, e0, e1));
+        if (r > 0) ms2min = fminf(ms2min, ms2);
     }
+    printf("MFMA fwd min of 5: %.3f ms (last %.3f)\n", ms2min, ms2);
     std::vector<float> v1(nvis), v2(nvis);
     CHK(hipMemcpy(v1.data(), dv1, nvis * 4, hipMemcpyDeviceToHost));
     CHK(hipMemcpy(v2.data(), dv2, nvis * 4, hipMemcpyDeviceToHost));
@@ -118,7 +122,7 @@ int main(int argc, char** argv)
         for (int r = 0; r < 2; ++r) {
             CHK(hipEventRecord(e0));
             int rc = rime_fringe_sum_bwd(RIME_F32, dbl, dsd, dfr, dgv, off, nullptr, Nbl, Nt, Nf, P, 1, 1, 0, 1,
-                                         1, fr[0], fr[1] - fr[0], 300.0, nullptr, dg1, dws, nvis * 4 * 64, 0);
+                                         1, fr[0], fr[1] - fr[0], 300.0, nullptr, dg1, dws, wsb, 0);
             CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
             if (rc) { printf("valu bwd rc=%d\n", rc); return 1; }
             CHK(hipEventElapsedTime(&mb1, e0, e1));
