@@ -96,15 +96,24 @@ __device__ __forceinline__ uint4 rot90(const uint4& v)
 //   * a thread generates 2 adjacent pixels x TA antennas whose coordinates (pre-multiplied by
 //     sign nu/c) stay in registers: per pair 3 f64 FMA + fract + cvt + sin + cos + mul and half
 //     a hi/lo split; packed (p, p+1) f16 pairs go out as conflict-free ds_write_b32;
-//   * LDS images are double buffered: one barrier per 16-pixel panel.
+//   * LDS images are double buffered, one barrier per 32-pixel panel (two K steps): 16-pixel
+//     panels are 7 % slower (barrier + first-fragment latency per MFMA burst);
+//   * tried and dropped: v_fma_mixlo/hi_f16 for the split (fewer instructions, but a serial
+//     dependency through the half-register writes: 2 % slower); the f64 "magic number" range
+//     reduction (1 % faster, 4 % more phase noise).
 // Every block covers at most MF_SPLIT_PIX pixels and STORES its result (no read-modify-write):
 // f32 accumulation inside the MFMA chain stays below eps*sqrt(512), and the pixel splits are
-// summed by reduce_vis_kernel in a fixed order (deterministic).
+// summed (and transposed into the result layout) by reduce_vis_kernel in a fixed order.
 // History (C4 shape, 128 antennas, 256 channels x 2 times, 98304 px): interleaved (re,im) K layout
-// with separate L/B images, rot90 on the fly and whole-tile deal: 13.4 ms.
+// with separate L/B images, rot90 on the fly and whole-tile deal: 13.4 ms; this kernel: 11.3 ms
+// (matrix pipe busy 51 -> 57 %, the rest is operand generation on the VALU).
 // ---------------------------------------------------------------------------------------
-constexpr int MF_KP = 16;                       // pixels per panel = K of one MFMA
-constexpr int MF_ROWB = 4 * MF_KP + 16;         // [re 16 x f16][im 16 x f16][pad]: 5 granules (odd)
+#ifndef RIME_MF_KP
+#define RIME_MF_KP 32
+#endif
+constexpr int MF_KP = RIME_MF_KP;               // pixels per panel (one barrier per panel); 16 per MFMA
+constexpr int MF_NH = MF_KP / 16;               // 16-pixel K steps per panel
+constexpr int MF_ROWB = 4 * MF_KP + 16;         // [re KP x f16][im KP x f16][pad]: odd number of 16-B granules
 constexpr int MF_IMG = MF_NA * MF_ROWB;         // one image (hi or lo)
 constexpr int MF_BUF = 2 * MF_IMG + 64;         // hi + lo + sign dwords of the panel
 constexpr size_t MF_LDS = 2 * (size_t)MF_BUF;
@@ -159,109 +168,109 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     const int pend = min(npanel, pbeg + A.panels_per_split);
     if (pbeg >= pend) return;                        // uniform over the block
 
-    double2 sx, sy, sz; float2 av;
-    auto fetch = [&](int panel) {
-        const int p = panel * MF_KP + 2 * pp;
-        sx = *reinterpret_cast<const double2*>(sd + p);
-        sy = *reinterpret_cast<const double2*>(sd + A.Pstride + p);
-        sz = *reinterpret_cast<const double2*>(sd + 2 * (size_t)A.Pstride + p);
-        av = *reinterpret_cast<const float2*>(arow + p);
+    double2 sx[MF_NH], sy[MF_NH], sz[MF_NH]; float2 av[MF_NH];
+    auto fetch = [&](int panel, int hf) {
+        const int p = panel * MF_KP + 16 * hf + 2 * pp;
+        sx[hf] = *reinterpret_cast<const double2*>(sd + p);
+        sy[hf] = *reinterpret_cast<const double2*>(sd + A.Pstride + p);
+        sz[hf] = *reinterpret_cast<const double2*>(sd + 2 * (size_t)A.Pstride + p);
+        av[hf] = *reinterpret_cast<const float2*>(arow + p);
     };
     auto generate = [&](unsigned char* buf, int next_panel) {
-        const float w0 = __builtin_amdgcn_sqrtf(fabsf(av.x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av.y) * scl);
-        if (tid < 8)
-            *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * pp) =
-                ((__float_as_uint(av.x) >> 16) & 0x8000u) | (__float_as_uint(av.y) & 0x80000000u);
 #pragma unroll
-        for (int u = 0; u < TA; ++u) {
-            const double ph0 = ax[u] * sx.x + ay[u] * sy.x + az[u] * sz.x;
-            const double ph1 = ax[u] * sx.y + ay[u] * sy.y + az[u] * sz.y;
-            const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
-            const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
-            const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
-            uint32_t rh, rl, ih, il;
-            split2(w0 * c0, w1 * c1, rh, rl);
-            split2(w0 * s0, w1 * s1, ih, il);
-            unsigned char* o = buf + goff + u * 32 * MF_ROWB;
-            *reinterpret_cast<uint32_t*>(o) = rh;
-            *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
-            *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
-            *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+        for (int hf = 0; hf < MF_NH; ++hf) {
+            const float w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
+            if (tid < 8)
+                *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
+                    ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
+#pragma unroll
+            for (int u = 0; u < TA; ++u) {
+                const double ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
+                const double ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
+                const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
+                const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+                uint32_t rh, rl, ih, il;
+                split2(w0 * c0, w1 * c1, rh, rl);
+                split2(w0 * s0, w1 * s1, ih, il);
+                unsigned char* o = buf + goff + u * 32 * MF_ROWB + 32 * hf;
+                *reinterpret_cast<uint32_t*>(o) = rh;
+                *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+            }
+            fetch(next_panel, hf);                   // latency hidden by the MFMA phase
         }
-        fetch(next_panel);                           // latency hidden by the MFMA phase
     };
 
     const int foff = (lane & 31) * MF_ROWB + (lane >> 5) * 16;   // fragment: row, k-half
+    // (a wave-uniform fast path that skips the masks for sign-free panels was tried: the branch
+    // around the MFMA block makes the register allocator spill the accumulators -- 4x slower)
     auto contract = [&](const unsigned char* buf) {
-        const uint4 sg = *reinterpret_cast<const uint4*>(buf + 2 * MF_IMG + (lane >> 5) * 16);
-        auto frag = [&](int tile, int img, int im) {
-            return *reinterpret_cast<const uint4*>(buf + img * MF_IMG + tile * 32 * MF_ROWB + foff + im * 2 * MF_KP);
+        auto frag = [&](int tile, int img, int im, int ks) {
+            return *reinterpret_cast<const uint4*>(buf + img * MF_IMG + tile * 32 * MF_ROWB + foff + im * 2 * MF_KP + 32 * ks);
         };
-        auto sfrag = [&](int tile, int img, int im) {
-            uint4 v = frag(tile, img, im);
-#if !defined(RIME_ABL_NOSIGN)
+        auto sfrag = [&](int tile, int img, int im, int ks, const uint4& sg) {
+            uint4 v = frag(tile, img, im, ks);
             v.x ^= sg.x; v.y ^= sg.y; v.z ^= sg.z; v.w ^= sg.w;
-#endif
             return v;
         };
         constexpr int UE = (U0 + UPW < NU) ? U0 + UPW : NU;          // this wave's units: [U0, UE)
         constexpr int T0 = U0 >> 1, T1 = (UE + 1) >> 1;               // its tiles: [T0, T1)
-        uint4 Lrh, Lih, Lrl, Lil;                                     // sign-applied row-tile fragments
+        uint4 Lrh[MF_NH], Lih[MF_NH], Lrl[MF_NH], Lil[MF_NH];         // sign-applied row-tile fragments
         static_for<T0, T1>([&](auto tc) {
             constexpr int tile = decltype(tc)::value;
             constexpr bool hasR = 2 * tile >= U0, hasI = 2 * tile + 1 < UE;
             constexpr int sR = hasR ? 2 * tile - U0 : 0, sI = hasI ? 2 * tile + 1 - U0 : 0;   // accumulator slots
             constexpr int ti = tri_row(TA, tile), tj = tri_col(TA, tile);
-            if constexpr (tile == T0 || tri_row(TA, tile > 0 ? tile - 1 : 0) != ti) {
-                Lrh = sfrag(ti, 0, 0); Lih = sfrag(ti, 0, 1); Lrl = sfrag(ti, 1, 0); Lil = sfrag(ti, 1, 1);
+#pragma unroll
+            for (int ks = 0; ks < MF_NH; ++ks) {
+                if constexpr (tile == T0 || tri_row(TA, tile > 0 ? tile - 1 : 0) != ti) {
+                    const uint4 sg = *reinterpret_cast<const uint4*>(buf + 2 * MF_IMG + (2 * ks + (lane >> 5)) * 16);
+                    Lrh[ks] = sfrag(ti, 0, 0, ks, sg); Lih[ks] = sfrag(ti, 0, 1, ks, sg);
+                    Lrl[ks] = sfrag(ti, 1, 0, ks, sg); Lil[ks] = sfrag(ti, 1, 1, ks, sg);
+                }
+                const uint4 Brh = frag(tj, 0, 0, ks), Bih = frag(tj, 0, 1, ks), Brl = frag(tj, 1, 0, ks), Bil = frag(tj, 1, 1, ks);
+                // real part Lr.Br + Li.Bi -> acc[sR][0]; imaginary part Lr.Bi -> acc[sI][0], Li.Br -> acc[sI][1]
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh[ks], Brh, acc[sR][0]);
+                if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh[ks], Bih, acc[sI][0]);
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih[ks], Bih, acc[sR][0]);
+                if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih[ks], Brh, acc[sI][1]);
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh[ks], Brl, acc[sR][0]);
+                if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh[ks], Bil, acc[sI][0]);
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih[ks], Bil, acc[sR][0]);
+                if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih[ks], Brl, acc[sI][1]);
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrl[ks], Brh, acc[sR][0]);
+                if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrl[ks], Bih, acc[sI][0]);
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lil[ks], Bih, acc[sR][0]);
+                if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lil[ks], Brh, acc[sI][1]);
             }
-            const uint4 Brh = frag(tj, 0, 0), Bih = frag(tj, 0, 1), Brl = frag(tj, 1, 0), Bil = frag(tj, 1, 1);
-            // real part Lr.Br + Li.Bi -> acc[sR][0]; imaginary part Lr.Bi -> acc[sI][0], Li.Br -> acc[sI][1]
-            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh, Brh, acc[sR][0]);
-            if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh, Bih, acc[sI][0]);
-            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih, Bih, acc[sR][0]);
-            if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih, Brh, acc[sI][1]);
-            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh, Brl, acc[sR][0]);
-            if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh, Bil, acc[sI][0]);
-            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih, Bil, acc[sR][0]);
-            if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih, Brl, acc[sI][1]);
-            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrl, Brh, acc[sR][0]);
-            if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrl, Bih, acc[sI][0]);
-            if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lil, Bih, acc[sR][0]);
-            if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lil, Brh, acc[sI][1]);
         });
     };
-
     // two panels per trip: buffer addresses are compile-time offsets
     unsigned char* const buf0 = smem;
     unsigned char* const buf1 = smem + MF_BUF;
-    fetch(pbeg);
+#pragma unroll
+    for (int hf = 0; hf < MF_NH; ++hf) fetch(pbeg, hf);
     generate(buf0, min(pbeg + 1, pend - 1));
     __syncthreads();
-#if defined(RIME_ABL_NOGEN)
-#define RIME_GEN(b, n) if (panel < pbeg + 2) generate(b, n)
-#else
-#define RIME_GEN(b, n) generate(b, n)
-#endif
-#if defined(RIME_ABL_NOMFMA)
-#define RIME_CON(b) { const uint4 q = *reinterpret_cast<const uint4*>(b + foff); acc[0][0][0] += __uint_as_float(q.x ^ q.y ^ q.z ^ q.w); }
-#else
-#define RIME_CON(b) contract(b)
-#endif
     for (int panel = pbeg; panel < pend; panel += 2) {
-        if (panel + 1 < pend) RIME_GEN(buf1, min(panel + 2, pend - 1));
-        RIME_CON(buf0);
+        if (panel + 1 < pend) generate(buf1, min(panel + 2, pend - 1));
+        contract(buf0);
         __syncthreads();
         if (panel + 1 < pend) {
-            if (panel + 2 < pend) RIME_GEN(buf0, min(panel + 3, pend - 1));
-            RIME_CON(buf1);
+            if (panel + 2 < pend) generate(buf0, min(panel + 3, pend - 1));
+            contract(buf1);
         }
         __syncthreads();
     }
 
-    // epilogue: V[i,j] / scale -> the baseline slot(s) of pair (i,j)
-    const size_t vis_elems = (size_t)A.Nbl * A.Nt * A.Nf * 2;
-    float* dst = (A.S == 1) ? A.vis : A.ws + (size_t)split * vis_elems;
+    // epilogue: V[i,j] / scale -> the baseline slot(s) of pair (i,j) of this block's slab
+    // ws[split][t][f][re|im][Nbl]: consecutive lanes (columns j) hit consecutive baseline slots, so
+    // the stores coalesce (a scattered store into the [Nbl][Nt][Nf][2] result costs a 32-B sector per
+    // 4-B value: 8 GB instead of 1.6 GB per launch at C4); reduce_vis_kernel sums the splits in a
+    // fixed order and transposes into the result layout.
+    float* dst = A.ws + (((size_t)split * A.Nt + t) * A.Nf + f) * 2 * A.Nbl;
     const float inv = 1.0f / scl;
     const int col = lane & 31;
 #pragma unroll
@@ -275,9 +284,9 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                 const int i = ti * 32 + row, j = tj * 32 + col;
                 const float v = (im ? acc[s][0][e] - acc[s][1][e] : acc[s][0][e]) * inv;
                 const int bd = A.pair_direct[i * MF_NA + j];
-                if (bd >= 0) dst[(((size_t)bd * A.Nt + t) * A.Nf + f) * 2 + im] = v;
+                if (bd >= 0) dst[(size_t)im * A.Nbl + bd] = v;
                 const int bc = A.pair_conj[i * MF_NA + j];
-                if (bc >= 0) dst[(((size_t)bc * A.Nt + t) * A.Nf + f) * 2 + im] = im ? -v : v;
+                if (bc >= 0) dst[(size_t)im * A.Nbl + bc] = im ? -v : v;
             }
         }
     }
@@ -317,6 +326,7 @@ fringe_ant_fwd_kernel(AntArgs A)
 struct AntBwdArgs {
     const double* antpos; const double* sdir; const double* freqs;
     const float* gvis;         // [Nbl, Nt, Nf, 2]
+    const float* gvt;          // workspace: gvis transposed to [Nt, Nf, re|im, Nbl] (coalesced staging)
     const float* gscale;       // [Nt, Nf] power-of-two pre-scale of gvis
     const int* pair_direct; const int* pair_conj;
     float* gpsky;              // strided [t][f][p]
@@ -360,18 +370,14 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
         const int j0 = 32 * tj + ((2 * jp) & 3) + 8 * (2 * ks + (jp >> 1)) + 4 * h;
         float gr[2] = {0.f, 0.f}, gi[2] = {0.f, 0.f};
         if (ti < TA && tj < TA) {
+            const float* gre = A.gvt + ((size_t)t * A.Nf + f) * 2 * A.Nbl;
+            const float* gim = gre + A.Nbl;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int bd = A.pair_direct[i * MF_NA + j0 + q];
-                if (bd >= 0) {
-                    const float* g = A.gvis + (((size_t)bd * A.Nt + t) * A.Nf + f) * 2;
-                    gr[q] += g[0]; gi[q] += g[1];
-                }
+                if (bd >= 0) { gr[q] += gre[bd]; gi[q] += gim[bd]; }
                 const int bc = A.pair_conj[i * MF_NA + j0 + q];
-                if (bc >= 0) {
-                    const float* g = A.gvis + (((size_t)bc * A.Nt + t) * A.Nf + f) * 2;
-                    gr[q] += g[0]; gi[q] -= g[1];
-                }
+                if (bc >= 0) { gr[q] += gre[bc]; gi[q] -= gim[bc]; }
             }
         }
         uint32_t rh, rl, ih, il;
@@ -465,13 +471,61 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
     }
 }
 
-template <typename T>
-__global__ void reduce_vis_kernel(const T* __restrict__ ws, T* __restrict__ out, size_t len, int S)
+// vis[bl][t][f][c] = sum_s ws[s][t][f][c][bl]: block = (32 baselines, 32 channels, one time); reads are
+// coalesced along bl, the 32x32 tile is turned through LDS, writes are 256-B runs along f.
+__global__ void __launch_bounds__(256)
+reduce_vis_kernel(const float* __restrict__ ws, float* __restrict__ vis, int Nbl, int Nt, int Nf, int S)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
-        T v = T(0);
-        for (int s = 0; s < S; ++s) v += ws[(size_t)s * len + i];
-        out[i] = v;
+    __shared__ float tile[32][2][33];
+    const int b0 = blockIdx.x * 32, f0 = blockIdx.y * 32, t = blockIdx.z;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;          // ly: 8 rows
+    const size_t slab = (size_t)Nt * Nf * 2 * Nbl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = f0 + ly + 8 * k, bl = b0 + lx;
+        float vr = 0.f, vi = 0.f;
+        if (f < Nf && bl < Nbl) {
+            const float* src = ws + ((size_t)t * Nf + f) * 2 * Nbl + bl;
+            for (int s = 0; s < S; ++s) { vr += src[(size_t)s * slab]; vi += src[(size_t)s * slab + Nbl]; }
+        }
+        tile[ly + 8 * k][0][lx] = vr;
+        tile[ly + 8 * k][1][lx] = vi;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int bl = b0 + ly + 8 * k, f = f0 + lx;
+        if (bl < Nbl && f < Nf) {
+            float2* o = reinterpret_cast<float2*>(vis + (((size_t)bl * Nt + t) * Nf + f) * 2);
+            *o = make_float2(tile[lx][0][ly + 8 * k], tile[lx][1][ly + 8 * k]);
+        }
+    }
+}
+
+// gvt[t][f][c][bl] = gvis[bl][t][f][c]: the backward stages G per (t, f) block along baselines
+__global__ void __launch_bounds__(256)
+transpose_gvis_kernel(const float* __restrict__ gvis, float* __restrict__ gvt, int Nbl, int Nt, int Nf)
+{
+    __shared__ float tile[32][2][33];
+    const int b0 = blockIdx.x * 32, f0 = blockIdx.y * 32, t = blockIdx.z;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int bl = b0 + ly + 8 * k, f = f0 + lx;
+        float2 v = make_float2(0.f, 0.f);
+        if (bl < Nbl && f < Nf) v = *reinterpret_cast<const float2*>(gvis + (((size_t)bl * Nt + t) * Nf + f) * 2);
+        tile[lx][0][ly + 8 * k] = v.x;
+        tile[lx][1][ly + 8 * k] = v.y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = f0 + ly + 8 * k, bl = b0 + lx;
+        if (f < Nf && bl < Nbl) {
+            float* dst = gvt + ((size_t)t * Nf + f) * 2 * Nbl + bl;
+            dst[0] = tile[ly + 8 * k][0][lx];
+            dst[Nbl] = tile[ly + 8 * k][1][lx];
+        }
     }
 }
 
@@ -492,7 +546,7 @@ using namespace rime;
 extern "C" size_t rime_fringe_ant_workspace(int Nbl, int Nt, int Nf, int Pstride)
 {
     const int S = ant_splits(Nt, Nf, Pstride);
-    return S <= 1 ? 0 : (size_t)S * Nbl * Nt * Nf * 2 * sizeof(float);
+    return (size_t)S * Nbl * Nt * Nf * 2 * sizeof(float);
 }
 
 extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, const double* freqs,
@@ -514,10 +568,10 @@ extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, con
     A.S = ant_splits(Nt, Nf, Pstride);
     const int npanel = Pstride / KP;
     A.panels_per_split = (npanel + A.S - 1) / A.S;
-    A.panels_per_split = ((A.panels_per_split + 3) / 4) * 4;        // splits start on 64-pixel tiles
+    A.panels_per_split = ((A.panels_per_split + 3) / 4) * 4;        // splits start on 64-pixel boundaries
     A.S = (npanel + A.panels_per_split - 1) / A.panels_per_split;
     const size_t vis_elems = (size_t)Nbl * Nt * Nf * 2;
-    if (A.S > 1 && workspace_bytes < (size_t)A.S * vis_elems * sizeof(float)) return RIME_EWORKSPACE;
+    if (!workspace || workspace_bytes < (size_t)A.S * vis_elems * sizeof(float)) return RIME_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(1, Nf, Nt * A.S);
     switch ((Nant + 31) / 32) {
@@ -526,25 +580,30 @@ extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, con
         case 3: hipLaunchKernelGGL((fringe_ant_fwd_kernel<3>), grid, dim3(256), MF_LDS, st, A); break;
         default: hipLaunchKernelGGL((fringe_ant_fwd_kernel<4>), grid, dim3(256), MF_LDS, st, A); break;
     }
-    if (A.S > 1) {
-        int nb = (int)std::min<size_t>((vis_elems + 255) / 256, 4096);
-        hipLaunchKernelGGL((reduce_vis_kernel<float>), dim3(nb), dim3(256), 0, st, A.ws, vis, vis_elems, A.S);
-    }
+    hipLaunchKernelGGL(reduce_vis_kernel, dim3((Nbl + 31) / 32, (Nf + 31) / 32, Nt), dim3(256), 0, st,
+                       A.ws, vis, Nbl, Nt, Nf, A.S);
     return check_launch();
+}
+
+extern "C" size_t rime_fringe_ant_bwd_workspace(int Nbl, int Nt, int Nf)
+{
+    return (size_t)Nbl * Nt * Nf * 2 * sizeof(float);
 }
 
 extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* freqs,
                                    const float* gvis, const float* gscale, const int* pair_direct,
                                    const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
-                                   long long st_t, long long st_f, int sign, float* gpsky, void* stream)
+                                   long long st_t, long long st_f, int sign, float* gpsky,
+                                   void* workspace, size_t workspace_bytes, void* stream)
 {
+    if (!workspace || workspace_bytes < rime_fringe_ant_bwd_workspace(Nbl, Nt, Nf)) return RIME_EWORKSPACE;
     if (!antpos || !sdir || !freqs || !gvis || !gscale || !pair_direct || !pair_conj || !gpsky) return RIME_EINVAL;
     if (Nant <= 0 || Nant > MF_NA || Nbl <= 0 || Nt <= 0 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0)
         return RIME_EINVAL;
     if (sign != 1 && sign != -1) return RIME_EINVAL;
     AntBwdArgs A{};
     A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.gvis = gvis; A.gscale = gscale;
-    A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.gpsky = gpsky;
+    A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.gpsky = gpsky; A.gvt = (const float*)workspace;
     A.Nant = Nant; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
     A.st_t = st_t; A.st_f = st_f; A.sign = (double)sign;
     // pixel ranges are independent outputs: split freely for parallelism (>= 256 pixel tiles/block
@@ -555,6 +614,8 @@ extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, con
     A.tiles_per_split = per;
     A.S = (ntile + per - 1) / per;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(transpose_gvis_kernel, dim3((Nbl + 31) / 32, (Nf + 31) / 32, Nt), dim3(256), 0, st,
+                       gvis, (float*)workspace, Nbl, Nt, Nf);
     dim3 grid(1, Nf, Nt * A.S);
     hipLaunchKernelGGL(fringe_ant_bwd_kernel, grid, dim3(512), MB_LDS, st, A);
     return check_launch();

@@ -165,9 +165,11 @@ def _fringe_ant_call(geom, backward, inp, out, strides):
         # inp: gvis viewed as real (1, Nbl, Nt, Nf, 2); out: gpsky float32 with psky's strides
         g = inp.reshape(geom.Nbl, geom.Nt, geom.Nf, 2)
         scale = _pow2_scale(g.abs().amax(dim=(0, 3))).contiguous()
+        nbytes = lib.rime_fringe_ant_bwd_workspace(geom.Nbl, geom.Nt, geom.Nf)
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=inp.device)
         rc = lib.rime_fringe_ant_bwd(_ptr(a['pos']), _ptr(geom.sdir), _ptr(geom.freqs), _ptr(inp), _ptr(scale),
                                      _ptr(a['direct']), _ptr(a['conj']), a['Nant'], geom.Nbl, geom.Nt, geom.Nf,
-                                     geom.Pstride, st_t, st_f, geom.sign, _ptr(out), _stream())
+                                     geom.Pstride, st_t, st_f, geom.sign, _ptr(out), _ptr(ws), ws.numel(), _stream())
         check(rc, 'rime_fringe_ant_bwd')
 
 

@@ -116,7 +116,8 @@ int rime_fringe_sum_bwd(int dtype,
  *       slot that receives conj(V[i,j]) (pair stored as j -> i, only when tile(j) > tile(i)), or -1
  *   vis / gvis complex64 [Nbl, Nt, Nf]
  * ------------------------------------------------------------------------------------- */
-size_t rime_fringe_ant_workspace(int Nbl, int Nt, int Nf, int Pstride);
+size_t rime_fringe_ant_workspace(int Nbl, int Nt, int Nf, int Pstride);   /* forward: per-split result slabs */
+size_t rime_fringe_ant_bwd_workspace(int Nbl, int Nt, int Nf);              /* backward: transposed gvis */
 int rime_fringe_ant_fwd(const double* antpos, const double* sdir, const double* freqs,
                         const float* psky, const float* scale, const int* pair_direct,
                         const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
@@ -125,7 +126,8 @@ int rime_fringe_ant_fwd(const double* antpos, const double* sdir, const double* 
 int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* freqs,
                         const float* gvis, const float* gscale, const int* pair_direct,
                         const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
-                        long long st_t, long long st_f, int sign, float* gpsky, void* stream);
+                        long long st_t, long long st_f, int sign, float* gpsky,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Materialised fringe, for callers that want the tensor itself (imaging.VisMapper.build_A,

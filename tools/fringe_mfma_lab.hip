@@ -50,6 +50,7 @@ int main(int argc, char** argv)
         // beam-like dynamic range: random sky x an envelope spanning 6 decades
         double env = exp(-13.8 * ud(rng));
         ps[i] = (float)(nd1(rng) * env * 3e-5);
+        if (argc > 4) ps[i] = fabsf(ps[i]);       // 4th argument: non-negative sky (sign-free fast path)
     }
     for (int tf = 0; tf < Nt * Nf; ++tf) {
         float amax = 0;
@@ -60,7 +61,7 @@ int main(int argc, char** argv)
     size_t nvis = (size_t)Nbl * Nt * Nf * 2;
     CHK(hipMalloc(&dant, ant.size() * 8)); CHK(hipMalloc(&dbl, bl.size() * 8)); CHK(hipMalloc(&dsd, sd.size() * 8));
     CHK(hipMalloc(&dfr, fr.size() * 8)); CHK(hipMalloc(&dps, npsky * 4)); CHK(hipMalloc(&dsc, sc.size() * 4));
-    CHK(hipMalloc(&dv1, nvis * 4)); CHK(hipMalloc(&dv2, nvis * 4)); size_t wsb = std::max(std::max(rime_fringe_sum_workspace(RIME_F32, Nbl, Nt, Nf, P, 1, 1, 0, 0), rime_fringe_sum_workspace(RIME_F32, Nbl, Nt, Nf, P, 1, 1, 0, 1)), rime_fringe_ant_workspace(Nbl, Nt, Nf, P)) + 256;
+    CHK(hipMalloc(&dv1, nvis * 4)); CHK(hipMalloc(&dv2, nvis * 4)); size_t wsb = std::max(std::max(rime_fringe_sum_workspace(RIME_F32, Nbl, Nt, Nf, P, 1, 1, 0, 0), rime_fringe_sum_workspace(RIME_F32, Nbl, Nt, Nf, P, 1, 1, 0, 1)), std::max(rime_fringe_ant_workspace(Nbl, Nt, Nf, P), rime_fringe_ant_bwd_workspace(Nbl, Nt, Nf))) + 256;
     CHK(hipMalloc(&dws, wsb));
     CHK(hipMalloc(&dpd, pd.size() * 4)); CHK(hipMalloc(&dpc, pc.size() * 4));
     CHK(hipMemcpy(dant, ant.data(), ant.size() * 8, hipMemcpyHostToDevice));
@@ -130,7 +131,7 @@ int main(int argc, char** argv)
         for (int r = 0; r < 2; ++r) {
             CHK(hipEventRecord(e0));
             int rc = rime_fringe_ant_bwd(dant, dsd, dfr, dgv, dgsc, dpd, dpc, Nant, Nbl, Nt, Nf, P,
-                                         (long long)Nf * P, (long long)P, 1, dg2, 0);
+                                         (long long)Nf * P, (long long)P, 1, dg2, dws, wsb, 0);
             CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
             if (rc) { printf("mfma bwd rc=%d (%s)\n", rc, rime_last_error()); return 1; }
             CHK(hipEventElapsedTime(&mb2, e0, e1));
