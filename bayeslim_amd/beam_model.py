@@ -161,11 +161,18 @@ class PixelBeam(utils.Module):
             beam = beam.to(self.device)
         if not utils.check_devices(sky.device, self.device):
             sky = sky.to(self.device)
-        i1 = torch.as_tensor([mp[0] for mp in modelpairs], device=beam.device)
-        beam1 = beam.index_select(2, i1) if (len(modelpairs) > 1 or beam.shape[2] > 1) else beam
+        select = len(modelpairs) > 1 or beam.shape[2] > 1
+        if select:
+            # index tensors cached per (pairs, device): building them per call is an H2D copy + sync
+            ckey = (tuple(modelpairs), str(beam.device))
+            cache = self.__dict__.setdefault('_mp_index_cache', {})
+            if ckey not in cache:
+                cache[ckey] = (torch.as_tensor([mp[0] for mp in modelpairs], device=beam.device),
+                               torch.as_tensor([mp[1] for mp in modelpairs], device=beam.device))
+            i1, i2 = cache[ckey]
+        beam1 = beam.index_select(2, i1) if select else beam
         if not self.powerbeam:
-            i2 = torch.as_tensor([mp[1] for mp in modelpairs], device=beam.device)
-            beam2 = beam.index_select(2, i2) if (len(modelpairs) > 1 or beam.shape[2] > 1) else beam
+            beam2 = beam.index_select(2, i2) if select else beam
         if sky.ndim == 4:
             sky = sky[:, :, None]
         if self.Npol == 1 and self.Nvec == 1:

@@ -147,7 +147,9 @@ class PixelSky(SkyBase):
     def forward(self, params=None, prior_cache=None, **kwargs):
         sky = self.R(self._forward_params(params))
         out, freqs, angs = self._emit(sky, prior_cache)
-        out.setup_data(freqs=freqs, data=sky * self.px_area.to(sky.device), angs=angs)
+        if self.px_area.device != sky.device:
+            self.px_area = self.px_area.to(sky.device)      # once: a per-call H2D copy is a host sync
+        out.setup_data(freqs=freqs, data=sky * self.px_area, angs=angs)
         return out
 
     def push(self, device, **kwargs):
