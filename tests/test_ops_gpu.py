@@ -209,6 +209,34 @@ def test_fringe_sum_matrix_core_path(ops, Nant, frac, autos, force, conj):
     assert relmax(v64, ref) < 1e-11
 
 
+def test_fringe_sum_matrix_core_splits_and_degenerate_rows(ops):
+    """MFMA path with several pixel splits (partial slabs + transposing reduction), an all-zero
+    psky row (power-of-two scale of an empty row), an all-negative row (sign masks on every
+    pixel) and a time/channel count that does not fill the 32-wide reduction tiles"""
+    ant, pairs, blvecs, freqs, zenaz, psky = make_antenna_case(40, 40, Nt=3, Nf=5, P=20000, frac=1.0, autos=0)
+    psky[0, :, :, 1] = 0.0
+    psky[2, :, :, 3] = -psky[2, :, :, 3].abs()
+    Nt, _, P = zenaz.shape
+    Ps = ops.pad_to_tile(P)
+    sdir = torch.zeros(Nt, 3, Ps, dtype=torch.float64)
+    for t in range(Nt):
+        sdir[t, :, :P] = orc.pointing_vectors(zenaz[t, 0], zenaz[t, 1])
+    geom = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, antpos=ant.cuda(), bl_ants=pairs, mfma=True)
+    assert geom.ant is not None
+    ref_in = psky.clone().requires_grad_(True)
+    ref = oracle_fringe_sum(ref_in, blvecs, zenaz, freqs, [0] * len(pairs))
+    gv = torch.as_tensor(np.random.default_rng(5).normal(size=tuple(ref.shape))
+                         + 1j * np.random.default_rng(6).normal(size=tuple(ref.shape)))
+    (ref * gv.conj()).real.sum().backward()
+    x = pad_psky(psky, Ps).float().cuda().requires_grad_(True)
+    vis = ops.fringe_sum(x, geom)
+    assert torch.isfinite(torch.view_as_real(vis)).all()
+    assert relmax(vis, ref) < 1e-5
+    assert float(vis.detach()[0, :, 0, 1].abs().max()) == 0.0               # the empty row gives exact zeros
+    (vis * gv.to(torch.complex64).cuda().conj()).real.sum().backward()
+    assert relmax(x.grad[..., :P], ref_in.grad) < 1e-4
+
+
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
 def test_fringe_sum_split_paths(ops, dtype):
     """few baselines x many pixels -> pixel-split partial slabs + reduce (fwd);
