@@ -44,7 +44,7 @@ struct AntArgs {
     float* ws;                 // partial slabs when S > 1
     int Nant, Nbl, Nt, Nf, Pstride;
     int S, panels_per_split;
-    long long st_t, st_f;
+    long long st_t, st_f, st_p;   // element strides of psky: time, channel, pixel (2 = one plane of a complex buffer)
     double sign;
 };
 
@@ -174,7 +174,8 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
         sx[hf] = *reinterpret_cast<const double2*>(sd + p);
         sy[hf] = *reinterpret_cast<const double2*>(sd + A.Pstride + p);
         sz[hf] = *reinterpret_cast<const double2*>(sd + 2 * (size_t)A.Pstride + p);
-        av[hf] = *reinterpret_cast<const float2*>(arow + p);
+        if (A.st_p == 1) av[hf] = *reinterpret_cast<const float2*>(arow + p);
+        else av[hf] = make_float2(arow[(size_t)p * A.st_p], arow[(size_t)(p + 1) * A.st_p]);
     };
     auto generate = [&](unsigned char* buf, int next_panel) {
 #pragma unroll
@@ -332,7 +333,7 @@ struct AntBwdArgs {
     float* gpsky;              // strided [t][f][p]
     int Nant, Nbl, Nt, Nf, Pstride;
     int S, tiles_per_split;    // pixel tiles (32 px) per block
-    long long st_t, st_f;
+    long long st_t, st_f, st_p;
     double sign;
 };
 
@@ -467,7 +468,7 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
             }
         }
         part += __shfl_xor(part, 32, 64);
-        if (h == 0) orow[p] = part * inv;
+        if (h == 0) orow[(size_t)p * A.st_p] = part * inv;
     }
 }
 
@@ -552,9 +553,10 @@ extern "C" size_t rime_fringe_ant_workspace(int Nbl, int Nt, int Nf, int Pstride
 extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, const double* freqs,
                                    const float* psky, const float* scale, const int* pair_direct,
                                    const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
-                                   long long st_t, long long st_f, int sign, float* vis,
+                                   long long st_t, long long st_f, long long st_p, int sign, float* vis,
                                    void* workspace, size_t workspace_bytes, void* stream)
 {
+    if (st_p != 1 && st_p != 2) return RIME_EINVAL;
     if (!antpos || !sdir || !freqs || !psky || !scale || !pair_direct || !pair_conj || !vis) return RIME_EINVAL;
     if (Nant <= 0 || Nant > MF_NA || Nbl <= 0 || Nt <= 0 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0)
         return RIME_EINVAL;
@@ -563,7 +565,7 @@ extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, con
     A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.psky = psky; A.scale = scale;
     A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.vis = vis; A.ws = (float*)workspace;
     A.Nant = Nant; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
-    A.st_t = st_t; A.st_f = st_f; A.sign = (double)sign;
+    A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign;
     constexpr int KP = MF_KP;
     A.S = ant_splits(Nt, Nf, Pstride);
     const int npanel = Pstride / KP;
@@ -593,9 +595,10 @@ extern "C" size_t rime_fringe_ant_bwd_workspace(int Nbl, int Nt, int Nf)
 extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* freqs,
                                    const float* gvis, const float* gscale, const int* pair_direct,
                                    const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
-                                   long long st_t, long long st_f, int sign, float* gpsky,
+                                   long long st_t, long long st_f, long long st_p, int sign, float* gpsky,
                                    void* workspace, size_t workspace_bytes, void* stream)
 {
+    if (st_p != 1 && st_p != 2) return RIME_EINVAL;
     if (!workspace || workspace_bytes < rime_fringe_ant_bwd_workspace(Nbl, Nt, Nf)) return RIME_EWORKSPACE;
     if (!antpos || !sdir || !freqs || !gvis || !gscale || !pair_direct || !pair_conj || !gpsky) return RIME_EINVAL;
     if (Nant <= 0 || Nant > MF_NA || Nbl <= 0 || Nt <= 0 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0)
@@ -605,7 +608,7 @@ extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, con
     A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.gvis = gvis; A.gscale = gscale;
     A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.gpsky = gpsky; A.gvt = (const float*)workspace;
     A.Nant = Nant; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
-    A.st_t = st_t; A.st_f = st_f; A.sign = (double)sign;
+    A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign;
     // pixel ranges are independent outputs: split freely for parallelism (>= 256 pixel tiles/block
     // amortise the G staging; fewer when the grid would otherwise be small)
     const int ntile = Pstride / 32;

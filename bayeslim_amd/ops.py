@@ -149,28 +149,48 @@ def _pow2_scale(amax):
     return torch.where(amax > 0, torch.exp2(torch.floor(torch.log2(16384.0 / safe))), torch.ones_like(amax))
 
 
-def _fringe_ant_call(geom, backward, inp, out, strides):
+def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
+    """
+    antenna-factored kernels, one launch per real plane of psky: the Npp polarisation products and,
+    for a complex psky, its real and imaginary planes (V is linear in psky:
+    V[ar + i ai] = V[ar] + i V[ai]; d/d(ai) = Re(conj(F) (-i g))).  Returns the number of launches.
+    """
     a = geom.ant
-    st_t, st_f = int(strides[0]), int(strides[3])
+    m = 2 if cplx else 1                                     # floats per psky element
+    st_t, st_pp, st_f = (int(strides[k]) * m for k in (0, 2, 3))
+    Nbl, Nt, Nf = geom.Nbl, geom.Nt, geom.Nf
+    dev = inp.device
+    common = (_ptr(a['pos']), _ptr(geom.sdir), _ptr(geom.freqs))
+    tables = (_ptr(a['direct']), _ptr(a['conj']), a['Nant'], Nbl, Nt, Nf, geom.Pstride, st_t, st_f, m, geom.sign)
     if not backward:
-        # inp: psky (Nt, 1, 1, Nf, Ps) float32 view; out: vis (1, Nbl, Nt, Nf) complex64
-        scale = _pow2_scale(inp.abs().amax(dim=-1).reshape(geom.Nt, geom.Nf)).contiguous()
-        nbytes = lib.rime_fringe_ant_workspace(geom.Nbl, geom.Nt, geom.Nf, geom.Pstride)
-        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=inp.device)
-        rc = lib.rime_fringe_ant_fwd(_ptr(a['pos']), _ptr(geom.sdir), _ptr(geom.freqs), _ptr(inp), _ptr(scale),
-                                     _ptr(a['direct']), _ptr(a['conj']), a['Nant'], geom.Nbl, geom.Nt, geom.Nf,
-                                     geom.Pstride, st_t, st_f, geom.sign, _ptr(out), _ptr(ws), ws.numel(), _stream())
-        check(rc, 'rime_fringe_ant_fwd')
+        # inp: psky (Nt, 1, Npp, Nf, Ps[, 2]) float32 view; out: vis (Npp, Nbl, Nt, Nf, 2) float32
+        amax = inp.abs().amax(dim=(-1, -2) if cplx else -1)                       # (Nt, 1, Npp, Nf)
+        scale = _pow2_scale(amax.reshape(Nt, Npp, Nf).permute(1, 0, 2)).contiguous()
+        nbytes = lib.rime_fringe_ant_workspace(Nbl, Nt, Nf, geom.Pstride)
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+        tmp = torch.empty((Nbl, Nt, Nf, 2), dtype=torch.float32, device=dev) if cplx else None
+        for pp in range(Npp):
+            for c in range(m):
+                dst = out[pp] if c == 0 else tmp
+                rc = lib.rime_fringe_ant_fwd(*common, ctypes.c_void_p(inp.data_ptr() + 4 * (pp * st_pp + c)),
+                                             _ptr(scale[pp]), *tables, _ptr(dst), _ptr(ws), ws.numel(), _stream())
+                check(rc, 'rime_fringe_ant_fwd')
+            if cplx:                                         # V += i V[ai]
+                out[pp][..., 0] -= tmp[..., 1]
+                out[pp][..., 1] += tmp[..., 0]
     else:
-        # inp: gvis viewed as real (1, Nbl, Nt, Nf, 2); out: gpsky float32 with psky's strides
-        g = inp.reshape(geom.Nbl, geom.Nt, geom.Nf, 2)
-        scale = _pow2_scale(g.abs().amax(dim=(0, 3))).contiguous()
-        nbytes = lib.rime_fringe_ant_bwd_workspace(geom.Nbl, geom.Nt, geom.Nf)
-        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=inp.device)
-        rc = lib.rime_fringe_ant_bwd(_ptr(a['pos']), _ptr(geom.sdir), _ptr(geom.freqs), _ptr(inp), _ptr(scale),
-                                     _ptr(a['direct']), _ptr(a['conj']), a['Nant'], geom.Nbl, geom.Nt, geom.Nf,
-                                     geom.Pstride, st_t, st_f, geom.sign, _ptr(out), _ptr(ws), ws.numel(), _stream())
-        check(rc, 'rime_fringe_ant_bwd')
+        # inp: gvis as real (Npp, Nbl, Nt, Nf, 2); out: gpsky float32 view with psky's strides
+        scale = _pow2_scale(inp.abs().amax(dim=(1, 4))).contiguous()               # (Npp, Nt, Nf)
+        nbytes = lib.rime_fringe_ant_bwd_workspace(Nbl, Nt, Nf)
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+        for pp in range(Npp):
+            for c in range(m):
+                g = inp[pp] if c == 0 else torch.stack([inp[pp][..., 1], -inp[pp][..., 0]], dim=-1).contiguous()
+                rc = lib.rime_fringe_ant_bwd(*common, _ptr(g), _ptr(scale[pp]), *tables,
+                                             ctypes.c_void_p(out.data_ptr() + 4 * (pp * st_pp + c)),
+                                             _ptr(ws), ws.numel(), _stream())
+                check(rc, 'rime_fringe_ant_bwd')
+    return Npp * m
 
 
 def _setup_antenna_path(self, antpos, bl_ants, force=False):
@@ -206,17 +226,16 @@ FringeGeometry._setup_antenna_path = _setup_antenna_path
 
 
 def _fringe_call(geom, backward, inp, out, Npp, cplx, strides=None):
-    if geom.ant is not None and Npp == 1 and not cplx and geom.Nmp == 1 and inp.dtype == torch.float32 \
-            and strides is not None:
+    if geom.ant is not None and geom.Nmp == 1 and inp.dtype == torch.float32 and strides is not None:
         prof = PROFILE
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _fringe_ant_call(geom, backward, inp, out, strides)
+        nlaunch = _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx)
         if prof is not None:
             e1.record()
             prof.append(('fringe_ant_bwd_kernel' if backward else 'fringe_ant_fwd_kernel', e0, e1, geom.elements,
-                         geom.ant['mfma_flops']))
+                         geom.ant['mfma_flops'] * nlaunch))
         return
     code, rdt = _real_dtype(inp)
     fn = lib.rime_fringe_sum_bwd if backward else lib.rime_fringe_sum_fwd

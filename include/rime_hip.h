@@ -108,7 +108,10 @@ int rime_fringe_sum_bwd(int dtype,
  * V = E^H diag(psky) E, computed on v_mfma_f32_32x32x16_f16 with an f16 hi/lo split of the f32
  * operands (three cross products, f32 accumulation).  Replaces the same reference lines as
  * rime_fringe_sum_fwd/bwd.
- *   antpos f64 [Nant, 3] ENU metres; psky / gpsky T [t][f][p] with element strides st_t, st_f
+ *   antpos f64 [Nant, 3] ENU metres; psky / gpsky f32 [t][f][p] with element strides st_t, st_f,
+ *       st_p (1, or 2 for the real / imaginary plane of an interleaved complex buffer).  One call
+ *       handles one real plane: polarisation products and the two planes of a complex psky are
+ *       separate calls (V is linear in psky: V[ar + i ai] = V[ar] + i V[ai])
  *   scale / gscale f32 [Nt, Nf]: power-of-two factors that bring max|psky[t,f,:]| (resp.
  *       max|gvis[:,t,f]|) to ~2^14 -- computed by the caller (a torch amax), exact to undo
  *   pair_direct / pair_conj int32 [128*128]: for antenna indices (i, j) with tile(i) <= tile(j)
@@ -121,12 +124,12 @@ size_t rime_fringe_ant_bwd_workspace(int Nbl, int Nt, int Nf);              /* b
 int rime_fringe_ant_fwd(const double* antpos, const double* sdir, const double* freqs,
                         const float* psky, const float* scale, const int* pair_direct,
                         const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
-                        long long st_t, long long st_f, int sign, float* vis,
+                        long long st_t, long long st_f, long long st_p, int sign, float* vis,
                         void* workspace, size_t workspace_bytes, void* stream);
 int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* freqs,
                         const float* gvis, const float* gscale, const int* pair_direct,
                         const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
-                        long long st_t, long long st_f, int sign, float* gpsky,
+                        long long st_t, long long st_f, long long st_p, int sign, float* gpsky,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------

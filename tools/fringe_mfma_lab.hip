@@ -89,7 +89,7 @@ int main(int argc, char** argv)
     for (int r = 0; r < 6; ++r) {
         CHK(hipEventRecord(e0));
         int rc = rime_fringe_ant_fwd(dant, dsd, dfr, dps, dsc, dpd, dpc, Nant, Nbl, Nt, Nf, P,
-                                     (long long)Nf * P, (long long)P, 1, dv2, dws, wsb, 0);
+                                     (long long)Nf * P, (long long)P, 1LL, 1, dv2, dws, wsb, 0);
         CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
         if (rc) { printf("mfma rc=%d (%s)\n", rc, rime_last_error()); return 1; }
         CHK(hipEventElapsedTime(&ms2, e0, e1));
@@ -131,7 +131,7 @@ int main(int argc, char** argv)
         for (int r = 0; r < 2; ++r) {
             CHK(hipEventRecord(e0));
             int rc = rime_fringe_ant_bwd(dant, dsd, dfr, dgv, dgsc, dpd, dpc, Nant, Nbl, Nt, Nf, P,
-                                         (long long)Nf * P, (long long)P, 1, dg2, dws, wsb, 0);
+                                         (long long)Nf * P, (long long)P, 1LL, 1, dg2, dws, wsb, 0);
             CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
             if (rc) { printf("mfma bwd rc=%d (%s)\n", rc, rime_last_error()); return 1; }
             CHK(hipEventElapsedTime(&mb2, e0, e1));
