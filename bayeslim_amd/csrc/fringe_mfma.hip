@@ -114,12 +114,28 @@ __device__ __forceinline__ uint4 rot90(const uint4& v)
 constexpr int MF_KP = RIME_MF_KP;               // pixels per panel (one barrier per panel); 16 per MFMA
 constexpr int MF_NH = MF_KP / 16;               // 16-pixel K steps per panel
 constexpr int MF_ROWB = 4 * MF_KP + 16;         // [re KP x f16][im KP x f16][pad]: odd number of 16-B granules
-constexpr int MF_IMG = MF_NA * MF_ROWB;         // one image (hi or lo)
-constexpr int MF_BUF = 2 * MF_IMG + 64;         // hi + lo + sign dwords of the panel
-constexpr size_t MF_LDS = 2 * (size_t)MF_BUF;
 
+// Block shapes.  Diagonal block: one group of <= 128 antennas against itself, upper-triangular
+// tiles, 4 waves.  Cross block (arrays with more than 128 antennas): group I (image rows 0..127,
+// the sign-carrying L side) against group J (rows 128..255), all 16 tiles, 8 waves, 1 block per CU.
+template <int TA_, bool CROSS_>
+struct FwdShape {
+    static constexpr int TA = TA_;
+    static constexpr bool CROSS = CROSS_;
+    static constexpr int NW = CROSS ? 8 : 4;                       // waves per block
+    static constexpr int ROWS = CROSS ? 2 * MF_NA : MF_NA;         // antenna rows of the LDS images
+    static constexpr int NT = CROSS ? 16 : TA * (TA + 1) / 2;      // 32x32 output tiles
+    static constexpr int GEN = CROSS ? 4 : TA;                     // antennas per thread and half panel
+    static constexpr int GROWS = NW * 8;                           // antenna rows per generation sweep
+    static constexpr int IMG = ROWS * MF_ROWB;                     // one image (hi or lo)
+    static constexpr int BUF = 2 * IMG + 64;                       // hi + lo + sign dwords of the panel
+    static constexpr size_t LDS = 2 * (size_t)BUF;
+    static constexpr int NU = 2 * NT, UPW = (NU + NW - 1) / NW;
+};
 __host__ __device__ constexpr int tri_row(int TA, int idx) { int ti = 0; while (idx >= TA - ti) { idx -= TA - ti; ++ti; } return ti; }
 __host__ __device__ constexpr int tri_col(int TA, int idx) { int ti = 0; while (idx >= TA - ti) { idx -= TA - ti; ++ti; } return ti + idx; }
+template <class SH> __host__ __device__ constexpr int tile_row(int t) { return SH::CROSS ? t / 4 : tri_row(SH::TA, t); }
+template <class SH> __host__ __device__ constexpr int tile_col(int t) { return SH::CROSS ? t % 4 : tri_col(SH::TA, t); }
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f)
@@ -129,10 +145,12 @@ __device__ __forceinline__ void static_for(F&& f)
 
 #define RIME_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag(a), as_frag(b), c, 0, 0, 0)
 
-template <int TA, int W>
+template <class SH, int W>
 __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* smem)
 {
-    constexpr int NT = TA * (TA + 1) / 2, NU = 2 * NT, UPW = (NU + 3) / 4, U0 = UPW * W;
+    constexpr int NU = SH::NU, UPW = SH::UPW, U0 = UPW * W;
+    constexpr int MF_IMG = SH::IMG, MF_BUF = SH::BUF;
+    constexpr int BROW = SH::CROSS ? 4 : 0;          // image row-tile offset of the column (B) side
     const int tid = threadIdx.x, lane = tid & 63;
     const int f = blockIdx.y;
     const int t = blockIdx.z / A.S, split = blockIdx.z % A.S;
@@ -145,11 +163,11 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // generation mapping: lane = (pixel pair pp, antenna slot ag); rows of one ds_write are 2 apart
     // (80-B rows: 8 rows x 32 B land in 16 distinct 16-B granules of the 64 banks)
     const int pp = lane & 7, ag = lane >> 3;
-    const int grow = 2 * ag + 16 * (W & 1) + (W >> 1);
-    double ax[TA], ay[TA], az[TA];
+    const int grow = SH::CROSS ? 2 * ag + 16 * (W & 3) + (W >> 2) : 2 * ag + 16 * (W & 1) + (W >> 1);
+    double ax[SH::GEN], ay[SH::GEN], az[SH::GEN];
 #pragma unroll
-    for (int u = 0; u < TA; ++u) {
-        const int an = 32 * u + grow;
+    for (int u = 0; u < SH::GEN; ++u) {
+        const int an = SH::GROWS * u + grow;
         const bool ok = an < A.Nant;
         ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
         ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
@@ -185,7 +203,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                 *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
                     ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
 #pragma unroll
-            for (int u = 0; u < TA; ++u) {
+            for (int u = 0; u < SH::GEN; ++u) {
                 const double ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
                 const double ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
                 const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
@@ -194,7 +212,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                 uint32_t rh, rl, ih, il;
                 split2(w0 * c0, w1 * c1, rh, rl);
                 split2(w0 * s0, w1 * s1, ih, il);
-                unsigned char* o = buf + goff + u * 32 * MF_ROWB + 32 * hf;
+                unsigned char* o = buf + goff + u * SH::GROWS * MF_ROWB + 32 * hf;
                 *reinterpret_cast<uint32_t*>(o) = rh;
                 *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
                 *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
@@ -223,10 +241,10 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
             constexpr int tile = decltype(tc)::value;
             constexpr bool hasR = 2 * tile >= U0, hasI = 2 * tile + 1 < UE;
             constexpr int sR = hasR ? 2 * tile - U0 : 0, sI = hasI ? 2 * tile + 1 - U0 : 0;   // accumulator slots
-            constexpr int ti = tri_row(TA, tile), tj = tri_col(TA, tile);
+            constexpr int ti = tile_row<SH>(tile), tj = BROW + tile_col<SH>(tile);
 #pragma unroll
             for (int ks = 0; ks < MF_NH; ++ks) {
-                if constexpr (tile == T0 || tri_row(TA, tile > 0 ? tile - 1 : 0) != ti) {
+                if constexpr (tile == T0 || tile_row<SH>(tile > 0 ? tile - 1 : 0) != ti) {
                     const uint4 sg = *reinterpret_cast<const uint4*>(buf + 2 * MF_IMG + (2 * ks + (lane >> 5)) * 16);
                     Lrh[ks] = sfrag(ti, 0, 0, ks, sg); Lih[ks] = sfrag(ti, 0, 1, ks, sg);
                     Lrl[ks] = sfrag(ti, 1, 0, ks, sg); Lil[ks] = sfrag(ti, 1, 1, ks, sg);
@@ -278,11 +296,11 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     for (int s = 0; s < UPW; ++s) {
         const int u = U0 + s;
         if (u < NU) {
-            const int ti = tri_row(TA, u >> 1), tj = tri_col(TA, u >> 1), im = u & 1;
+            const int ti = tile_row<SH>(u >> 1), tj = tile_col<SH>(u >> 1), im = u & 1;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int i = ti * 32 + row, j = tj * 32 + col;
+                const int i = ti * 32 + row, j = tj * 32 + col;      // indices inside group I / group J
                 const float v = (im ? acc[s][0][e] - acc[s][1][e] : acc[s][0][e]) * inv;
                 const int bd = A.pair_direct[i * MF_NA + j];
                 if (bd >= 0) dst[(size_t)im * A.Nbl + bd] = v;
@@ -298,11 +316,29 @@ __global__ void __launch_bounds__(256, 2)
 fringe_ant_fwd_kernel(AntArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    using SH = FwdShape<TA, false>;
     switch (threadIdx.x >> 6) {                      // wave-uniform: every wave runs the same barriers
-        case 0: ant_fwd_body<TA, 0>(A, smem); break;
-        case 1: ant_fwd_body<TA, 1>(A, smem); break;
-        case 2: ant_fwd_body<TA, 2>(A, smem); break;
-        default: ant_fwd_body<TA, 3>(A, smem); break;
+        case 0: ant_fwd_body<SH, 0>(A, smem); break;
+        case 1: ant_fwd_body<SH, 1>(A, smem); break;
+        case 2: ant_fwd_body<SH, 2>(A, smem); break;
+        default: ant_fwd_body<SH, 3>(A, smem); break;
+    }
+}
+
+__global__ void __launch_bounds__(512, 1)
+fringe_ant_fwd_cross_kernel(AntArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    using SH = FwdShape<4, true>;
+    switch (threadIdx.x >> 6) {
+        case 0: ant_fwd_body<SH, 0>(A, smem); break;
+        case 1: ant_fwd_body<SH, 1>(A, smem); break;
+        case 2: ant_fwd_body<SH, 2>(A, smem); break;
+        case 3: ant_fwd_body<SH, 3>(A, smem); break;
+        case 4: ant_fwd_body<SH, 4>(A, smem); break;
+        case 5: ant_fwd_body<SH, 5>(A, smem); break;
+        case 6: ant_fwd_body<SH, 6>(A, smem); break;
+        default: ant_fwd_body<SH, 7>(A, smem); break;
     }
 }
 
@@ -333,6 +369,7 @@ struct AntBwdArgs {
     float* gpsky;              // strided [t][f][p]
     int Nant, Nbl, Nt, Nf, Pstride;
     int S, tiles_per_split;    // pixel tiles (32 px) per block
+    int accumulate;            // add to gpsky instead of overwriting (blocks after the first)
     long long st_t, st_f, st_p;
     double sign;
 };
@@ -468,7 +505,146 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
             }
         }
         part += __shfl_xor(part, 32, 64);
-        if (h == 0) orow[(size_t)p * A.st_p] = part * inv;
+        if (h == 0) {
+            float* o = orow + (size_t)p * A.st_p;
+            *o = A.accumulate ? *o + part * inv : part * inv;
+        }
+    }
+}
+
+
+// Cross block of the backward (arrays with more than 128 antennas): rows i in group I (antpos rows
+// 0..127), columns j in group J (rows 128..255), all 16 tiles.  T_i = sum_j conj(G[i,j]) E_j as in
+// the diagonal kernel; the E_i of the final contraction belong to the other group and are
+// generated after the MFMA loop.  Four G planes (Gr, Gi; hi, lo; 128 KB) -- the -Gi products use
+// a sign-flipped Er fragment instead (8 v_xor per 16 antennas, shared by the 4 row tiles).
+// Adds to gpsky (A.accumulate): every pixel is owned by one lane, launches are stream-ordered.
+constexpr int MX_PLANE = 16 * 2 * 2 * 32 * 16;        // 32768 B
+constexpr size_t MX_LDS = 4 * (size_t)MX_PLANE + 2 * MF_NA * 3 * sizeof(double);
+
+__global__ void __launch_bounds__(512, 2)
+fringe_ant_bwd_cross_kernel(AntBwdArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* g_img = smem;                       // planes: 0 Gr_hi, 1 Gi_hi, 2 Gr_lo, 3 Gi_lo
+    double* ant_lds = reinterpret_cast<double*>(smem + 4 * MX_PLANE);      // [256][3]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = blockIdx.y;
+    const int t = blockIdx.z / A.S, split = blockIdx.z % A.S;
+
+    const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
+    for (int i = tid; i < 2 * MF_NA * 3; i += 512)
+        ant_lds[i] = (i < A.Nant * 3) ? nu_c * A.antpos[i] : 0.0;
+
+    const float gs = A.gscale[t * A.Nf + f];
+    const float* gre = A.gvt + ((size_t)t * A.Nf + f) * 2 * A.Nbl;
+    const float* gim = gre + A.Nbl;
+    for (int e = tid; e < 16 * 2 * 2 * 32 * 4; e += 512) {
+        const int jp = e & 3, row = (e >> 2) & 31, h = (e >> 7) & 1, ks = (e >> 8) & 1, tile = e >> 9;
+        const int ti = tile >> 2, tj = tile & 3;
+        const int i = 32 * ti + row;
+        const int j0 = 32 * tj + ((2 * jp) & 3) + 8 * (2 * ks + (jp >> 1)) + 4 * h;
+        float gr[2] = {0.f, 0.f}, gi[2] = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int bd = A.pair_direct[i * MF_NA + j0 + q];
+            if (bd >= 0) { gr[q] += gre[bd]; gi[q] += gim[bd]; }
+            const int bc = A.pair_conj[i * MF_NA + j0 + q];
+            if (bc >= 0) { gr[q] += gre[bc]; gi[q] -= gim[bc]; }
+        }
+        uint32_t rh, rl, ih, il;
+        split2(gr[0] * gs, gr[1] * gs, rh, rl);
+        split2(gi[0] * gs, gi[1] * gs, ih, il);
+        const int off = ((((tile * 2 + ks) * 2 + h) * 32 + row) * 4 + jp) * 4;
+        *reinterpret_cast<uint32_t*>(g_img + 0 * MX_PLANE + off) = rh;
+        *reinterpret_cast<uint32_t*>(g_img + 1 * MX_PLANE + off) = ih;
+        *reinterpret_cast<uint32_t*>(g_img + 2 * MX_PLANE + off) = rl;
+        *reinterpret_cast<uint32_t*>(g_img + 3 * MX_PLANE + off) = il;
+    }
+    __syncthreads();
+
+    const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
+    float* orow = A.gpsky + (size_t)t * A.st_t + (size_t)f * A.st_f;
+    const float inv = 1.0f / gs;
+    const int h = lane >> 5;
+    const int ntile = A.Pstride / 32;
+    const int tbeg = split * A.tiles_per_split;
+    const int tend = min(ntile, tbeg + A.tiles_per_split);
+
+    for (int pt = tbeg + wave; pt < tend; pt += 8) {
+        const int p = pt * 32 + (lane & 31);
+        const double sx = sd[p], sy = sd[A.Pstride + p], sz = sd[2 * (size_t)A.Pstride + p];
+        f32x16 accR[4], accI[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { accR[q][e] = 0.f; accI[q][e] = 0.f; }
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 Erh, Erl, Eih, Eil, Nrh, Nrl;
+                uint32_t* erh = reinterpret_cast<uint32_t*>(&Erh); uint32_t* erl = reinterpret_cast<uint32_t*>(&Erl);
+                uint32_t* eih = reinterpret_cast<uint32_t*>(&Eih); uint32_t* eil = reinterpret_cast<uint32_t*>(&Eil);
+                float ec[8], es[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int an = MF_NA + 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
+                    const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
+                    const float rr = (float)__builtin_amdgcn_fract(ph);
+                    ec[jj] = __builtin_amdgcn_cosf(rr);
+                    es[jj] = __builtin_amdgcn_sinf(rr);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    split2(ec[2 * q], ec[2 * q + 1], erh[q], erl[q]);
+                    split2(es[2 * q], es[2 * q + 1], eih[q], eil[q]);
+                }
+                Nrh = make_uint4(Erh.x ^ 0x80008000u, Erh.y ^ 0x80008000u, Erh.z ^ 0x80008000u, Erh.w ^ 0x80008000u);
+                Nrl = make_uint4(Erl.x ^ 0x80008000u, Erl.y ^ 0x80008000u, Erl.z ^ 0x80008000u, Erl.w ^ 0x80008000u);
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) {
+                    const int off = ((((ti * 4 + tj) * 2 + ks) * 2 + h) * 32 + (lane & 31)) * 16;
+                    const uint4 Grh = *reinterpret_cast<const uint4*>(g_img + 0 * MX_PLANE + off);
+                    const uint4 Gih = *reinterpret_cast<const uint4*>(g_img + 1 * MX_PLANE + off);
+                    const uint4 Grl = *reinterpret_cast<const uint4*>(g_img + 2 * MX_PLANE + off);
+                    const uint4 Gil = *reinterpret_cast<const uint4*>(g_img + 3 * MX_PLANE + off);
+                    accR[ti] = RIME_MFMA(Grh, Erh, accR[ti]);
+                    accI[ti] = RIME_MFMA(Grh, Eih, accI[ti]);
+                    accR[ti] = RIME_MFMA(Gih, Eih, accR[ti]);
+                    accI[ti] = RIME_MFMA(Gih, Nrh, accI[ti]);
+                    accR[ti] = RIME_MFMA(Grh, Erl, accR[ti]);
+                    accI[ti] = RIME_MFMA(Grh, Eil, accI[ti]);
+                    accR[ti] = RIME_MFMA(Gih, Eil, accR[ti]);
+                    accI[ti] = RIME_MFMA(Gih, Nrl, accI[ti]);
+                    accR[ti] = RIME_MFMA(Grl, Erh, accR[ti]);
+                    accI[ti] = RIME_MFMA(Grl, Eih, accI[ti]);
+                    accR[ti] = RIME_MFMA(Gil, Eih, accR[ti]);
+                    accI[ti] = RIME_MFMA(Gil, Nrh, accI[ti]);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the live ranges of one K step apart
+            }
+        }
+        // contraction with E_i of group I: the D rows this lane holds
+        float part = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int an = 32 * ti + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
+                const float rr = (float)__builtin_amdgcn_fract(ph);
+                part = fmaf(__builtin_amdgcn_cosf(rr), accR[ti][e], part);
+                part = fmaf(__builtin_amdgcn_sinf(rr), accI[ti][e], part);
+                if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        part += __shfl_xor(part, 32, 64);
+        if (h == 0) {
+            float* o = orow + (size_t)p * A.st_p;
+            *o = A.accumulate ? *o + part * inv : part * inv;
+        }
     }
 }
 
@@ -544,10 +720,70 @@ static int ant_splits(int Nt, int Nf, int Pstride)
 
 using namespace rime;
 
+static void ant_split_plan(int Nt, int Nf, int Pstride, int& S, int& panels_per_split)
+{
+    S = ant_splits(Nt, Nf, Pstride);
+    const int npanel = Pstride / MF_KP;
+    panels_per_split = (npanel + S - 1) / S;
+    panels_per_split = ((panels_per_split + 3) / 4) * 4;            // splits start on 64-pixel boundaries
+    S = (npanel + panels_per_split - 1) / panels_per_split;
+}
+
 extern "C" size_t rime_fringe_ant_workspace(int Nbl, int Nt, int Nf, int Pstride)
 {
-    const int S = ant_splits(Nt, Nf, Pstride);
+    int S, pps;
+    ant_split_plan(Nt, Nf, Pstride, S, pps);
     return (size_t)S * Nbl * Nt * Nf * 2 * sizeof(float);
+}
+
+static bool ant_common_ok(int Nrows, int cross, int Nbl, int Nt, int Nf, int Pstride, long long st_p, int sign)
+{
+    if (st_p != 1 && st_p != 2) return false;
+    if (cross ? (Nrows != 2 * MF_NA) : (Nrows <= 0 || Nrows > MF_NA)) return false;
+    if (Nbl <= 0 || Nt <= 0 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0) return false;
+    return sign == 1 || sign == -1;
+}
+
+extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
+                                         const double* freqs, const float* psky, const float* scale,
+                                         const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf,
+                                         int Pstride, long long st_t, long long st_f, long long st_p, int sign,
+                                         void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!antpos || !sdir || !freqs || !psky || !scale || !pair_direct || !pair_conj) return RIME_EINVAL;
+    if (!ant_common_ok(Nrows, cross, Nbl, Nt, Nf, Pstride, st_p, sign)) return RIME_EINVAL;
+    AntArgs A{};
+    A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.psky = psky; A.scale = scale;
+    A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.vis = nullptr; A.ws = (float*)workspace;
+    A.Nant = Nrows; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
+    A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign;
+    ant_split_plan(Nt, Nf, Pstride, A.S, A.panels_per_split);
+    if (!workspace || workspace_bytes < rime_fringe_ant_workspace(Nbl, Nt, Nf, Pstride)) return RIME_EWORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(1, Nf, Nt * A.S);
+    if (cross) {
+        hipLaunchKernelGGL(fringe_ant_fwd_cross_kernel, grid, dim3(512), (FwdShape<4, true>::LDS), st, A);
+        return check_launch();
+    }
+    switch ((Nrows + 31) / 32) {
+        case 1: hipLaunchKernelGGL((fringe_ant_fwd_kernel<1>), grid, dim3(256), (FwdShape<1, false>::LDS), st, A); break;
+        case 2: hipLaunchKernelGGL((fringe_ant_fwd_kernel<2>), grid, dim3(256), (FwdShape<2, false>::LDS), st, A); break;
+        case 3: hipLaunchKernelGGL((fringe_ant_fwd_kernel<3>), grid, dim3(256), (FwdShape<3, false>::LDS), st, A); break;
+        default: hipLaunchKernelGGL((fringe_ant_fwd_kernel<4>), grid, dim3(256), (FwdShape<4, false>::LDS), st, A); break;
+    }
+    return check_launch();
+}
+
+extern "C" int rime_fringe_ant_fwd_finish(const void* workspace, size_t workspace_bytes, float* vis,
+                                          int Nbl, int Nt, int Nf, int Pstride, void* stream)
+{
+    if (!vis || Nbl <= 0 || Nt <= 0 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0) return RIME_EINVAL;
+    if (!workspace || workspace_bytes < rime_fringe_ant_workspace(Nbl, Nt, Nf, Pstride)) return RIME_EWORKSPACE;
+    int S, pps;
+    ant_split_plan(Nt, Nf, Pstride, S, pps);
+    hipLaunchKernelGGL(reduce_vis_kernel, dim3((Nbl + 31) / 32, (Nf + 31) / 32, Nt), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), (const float*)workspace, vis, Nbl, Nt, Nf, S);
+    return check_launch();
 }
 
 extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, const double* freqs,
@@ -556,35 +792,12 @@ extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, con
                                    long long st_t, long long st_f, long long st_p, int sign, float* vis,
                                    void* workspace, size_t workspace_bytes, void* stream)
 {
-    if (st_p != 1 && st_p != 2) return RIME_EINVAL;
-    if (!antpos || !sdir || !freqs || !psky || !scale || !pair_direct || !pair_conj || !vis) return RIME_EINVAL;
-    if (Nant <= 0 || Nant > MF_NA || Nbl <= 0 || Nt <= 0 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0)
-        return RIME_EINVAL;
-    if (sign != 1 && sign != -1) return RIME_EINVAL;
-    AntArgs A{};
-    A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.psky = psky; A.scale = scale;
-    A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.vis = vis; A.ws = (float*)workspace;
-    A.Nant = Nant; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
-    A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign;
-    constexpr int KP = MF_KP;
-    A.S = ant_splits(Nt, Nf, Pstride);
-    const int npanel = Pstride / KP;
-    A.panels_per_split = (npanel + A.S - 1) / A.S;
-    A.panels_per_split = ((A.panels_per_split + 3) / 4) * 4;        // splits start on 64-pixel boundaries
-    A.S = (npanel + A.panels_per_split - 1) / A.panels_per_split;
-    const size_t vis_elems = (size_t)Nbl * Nt * Nf * 2;
-    if (!workspace || workspace_bytes < (size_t)A.S * vis_elems * sizeof(float)) return RIME_EWORKSPACE;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid(1, Nf, Nt * A.S);
-    switch ((Nant + 31) / 32) {
-        case 1: hipLaunchKernelGGL((fringe_ant_fwd_kernel<1>), grid, dim3(256), MF_LDS, st, A); break;
-        case 2: hipLaunchKernelGGL((fringe_ant_fwd_kernel<2>), grid, dim3(256), MF_LDS, st, A); break;
-        case 3: hipLaunchKernelGGL((fringe_ant_fwd_kernel<3>), grid, dim3(256), MF_LDS, st, A); break;
-        default: hipLaunchKernelGGL((fringe_ant_fwd_kernel<4>), grid, dim3(256), MF_LDS, st, A); break;
-    }
-    hipLaunchKernelGGL(reduce_vis_kernel, dim3((Nbl + 31) / 32, (Nf + 31) / 32, Nt), dim3(256), 0, st,
-                       A.ws, vis, Nbl, Nt, Nf, A.S);
-    return check_launch();
+    if (!vis) return RIME_EINVAL;
+    const int rc = rime_fringe_ant_fwd_block(antpos, Nant, 0, sdir, freqs, psky, scale, pair_direct, pair_conj,
+                                             Nbl, Nt, Nf, Pstride, st_t, st_f, st_p, sign, workspace,
+                                             workspace_bytes, stream);
+    if (rc != RIME_OK) return rc;
+    return rime_fringe_ant_fwd_finish(workspace, workspace_bytes, vis, Nbl, Nt, Nf, Pstride, stream);
 }
 
 extern "C" size_t rime_fringe_ant_bwd_workspace(int Nbl, int Nt, int Nf)
@@ -592,23 +805,31 @@ extern "C" size_t rime_fringe_ant_bwd_workspace(int Nbl, int Nt, int Nf)
     return (size_t)Nbl * Nt * Nf * 2 * sizeof(float);
 }
 
-extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* freqs,
-                                   const float* gvis, const float* gscale, const int* pair_direct,
-                                   const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
-                                   long long st_t, long long st_f, long long st_p, int sign, float* gpsky,
-                                   void* workspace, size_t workspace_bytes, void* stream)
+extern "C" int rime_fringe_ant_bwd_prepare(const float* gvis, int Nbl, int Nt, int Nf,
+                                           void* workspace, size_t workspace_bytes, void* stream)
 {
-    if (st_p != 1 && st_p != 2) return RIME_EINVAL;
+    if (!gvis || Nbl <= 0 || Nt <= 0 || Nf <= 0) return RIME_EINVAL;
     if (!workspace || workspace_bytes < rime_fringe_ant_bwd_workspace(Nbl, Nt, Nf)) return RIME_EWORKSPACE;
-    if (!antpos || !sdir || !freqs || !gvis || !gscale || !pair_direct || !pair_conj || !gpsky) return RIME_EINVAL;
-    if (Nant <= 0 || Nant > MF_NA || Nbl <= 0 || Nt <= 0 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0)
-        return RIME_EINVAL;
-    if (sign != 1 && sign != -1) return RIME_EINVAL;
+    hipLaunchKernelGGL(transpose_gvis_kernel, dim3((Nbl + 31) / 32, (Nf + 31) / 32, Nt), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), gvis, (float*)workspace, Nbl, Nt, Nf);
+    return check_launch();
+}
+
+extern "C" int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
+                                         const double* freqs, const float* gscale, const int* pair_direct,
+                                         const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
+                                         long long st_t, long long st_f, long long st_p, int sign,
+                                         int accumulate, float* gpsky, const void* workspace,
+                                         size_t workspace_bytes, void* stream)
+{
+    if (!antpos || !sdir || !freqs || !gscale || !pair_direct || !pair_conj || !gpsky) return RIME_EINVAL;
+    if (!ant_common_ok(Nrows, cross, Nbl, Nt, Nf, Pstride, st_p, sign)) return RIME_EINVAL;
+    if (!workspace || workspace_bytes < rime_fringe_ant_bwd_workspace(Nbl, Nt, Nf)) return RIME_EWORKSPACE;
     AntBwdArgs A{};
-    A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.gvis = gvis; A.gscale = gscale;
+    A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.gvis = nullptr; A.gscale = gscale;
     A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.gpsky = gpsky; A.gvt = (const float*)workspace;
-    A.Nant = Nant; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
-    A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign;
+    A.Nant = Nrows; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
+    A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign; A.accumulate = accumulate ? 1 : 0;
     // pixel ranges are independent outputs: split freely for parallelism (>= 256 pixel tiles/block
     // amortise the G staging; fewer when the grid would otherwise be small)
     const int ntile = Pstride / 32;
@@ -617,9 +838,20 @@ extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, con
     A.tiles_per_split = per;
     A.S = (ntile + per - 1) / per;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(transpose_gvis_kernel, dim3((Nbl + 31) / 32, (Nf + 31) / 32, Nt), dim3(256), 0, st,
-                       gvis, (float*)workspace, Nbl, Nt, Nf);
     dim3 grid(1, Nf, Nt * A.S);
-    hipLaunchKernelGGL(fringe_ant_bwd_kernel, grid, dim3(512), MB_LDS, st, A);
+    if (cross) hipLaunchKernelGGL(fringe_ant_bwd_cross_kernel, grid, dim3(512), MX_LDS, st, A);
+    else hipLaunchKernelGGL(fringe_ant_bwd_kernel, grid, dim3(512), MB_LDS, st, A);
     return check_launch();
+}
+
+extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* freqs,
+                                   const float* gvis, const float* gscale, const int* pair_direct,
+                                   const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
+                                   long long st_t, long long st_f, long long st_p, int sign, float* gpsky,
+                                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    const int rc = rime_fringe_ant_bwd_prepare(gvis, Nbl, Nt, Nf, workspace, workspace_bytes, stream);
+    if (rc != RIME_OK) return rc;
+    return rime_fringe_ant_bwd_block(antpos, Nant, 0, sdir, freqs, gscale, pair_direct, pair_conj, Nbl, Nt, Nf,
+                                     Pstride, st_t, st_f, st_p, sign, 0, gpsky, workspace, workspace_bytes, stream);
 }

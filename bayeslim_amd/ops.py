@@ -110,20 +110,41 @@ class FringeGeometry:
             self.bl_order = torch.as_tensor(order, dtype=torch.int32, device=dev)
 
 
-def _antenna_tables(bl_ants, Nant):
-    """pair_direct / pair_conj tables of the matrix-core path (see include/rime_hip.h)"""
-    direct = np.full((MFMA_MAX_ANTS, MFMA_MAX_ANTS), -1, dtype=np.int32)
-    conj = np.full((MFMA_MAX_ANTS, MFMA_MAX_ANTS), -1, dtype=np.int32)
+MFMA_GROUP = 128          # antennas per group of the matrix-core path (4 x 4 tiles of 32)
+
+
+def _antenna_blocks(bl_ants, Nant):
+    """
+    Pair tables of the matrix-core path (see include/rime_hip.h).  Antennas are cut into groups of
+    MFMA_GROUP; returns {(I, J): (direct, conj)} with I <= J, int32 [128, 128] tables of baseline
+    slots indexed by the LOCAL antenna indices (row in group I, column in group J), or None when a
+    pair occurs twice (not representable).
+    """
+    tabs = {}
+
+    def get(key):
+        if key not in tabs:
+            tabs[key] = (np.full((MFMA_GROUP, MFMA_GROUP), -1, dtype=np.int32),
+                         np.full((MFMA_GROUP, MFMA_GROUP), -1, dtype=np.int32))
+        return tabs[key]
+
     for b, (a1, a2) in enumerate(bl_ants):
-        if a1 // 32 <= a2 // 32:
-            if direct[a1, a2] >= 0:
-                return None                       # duplicate pair: not representable
-            direct[a1, a2] = b
+        g1, l1 = divmod(a1, MFMA_GROUP)
+        g2, l2 = divmod(a2, MFMA_GROUP)
+        if g1 == g2:
+            direct, conj = get((g1, g1))
+            if l1 // 32 <= l2 // 32:
+                tab, i, j = direct, l1, l2
+            else:
+                tab, i, j = conj, l2, l1
+        elif g1 < g2:
+            tab, i, j = get((g1, g2))[0], l1, l2           # baseline I_i -> J_j: V[i, j]
         else:
-            if conj[a2, a1] >= 0:
-                return None
-            conj[a2, a1] = b
-    return direct, conj
+            tab, i, j = get((g2, g1))[1], l2, l1           # baseline J_j -> I_i: conj(V[i, j])
+        if tab[i, j] >= 0:
+            return None
+        tab[i, j] = b
+    return tabs
 
 
 def _dense_strides(t):
@@ -140,7 +161,7 @@ def _dense_strides(t):
     return (ctypes.c_longlong * 4)(*[int(max(s, 1)) for s in st[:4]])
 
 
-MFMA_MAX_ANTS = 128
+MFMA_MAX_ANTS = 2048      # table memory only: 136 blocks x 128 KB at 2048 antennas
 
 
 def _pow2_scale(amax):
@@ -151,17 +172,18 @@ def _pow2_scale(amax):
 
 def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
     """
-    antenna-factored kernels, one launch per real plane of psky: the Npp polarisation products and,
+    antenna-factored kernels, one pass per real plane of psky: the Npp polarisation products and,
     for a complex psky, its real and imaginary planes (V is linear in psky:
-    V[ar + i ai] = V[ar] + i V[ai]; d/d(ai) = Re(conj(F) (-i g))).  Returns the number of launches.
+    V[ar + i ai] = V[ar] + i V[ai]; d/d(ai) = Re(conj(F) (-i g))).  A pass launches one kernel per
+    antenna-group block.  Returns the number of passes.
     """
     a = geom.ant
     m = 2 if cplx else 1                                     # floats per psky element
     st_t, st_pp, st_f = (int(strides[k]) * m for k in (0, 2, 3))
     Nbl, Nt, Nf = geom.Nbl, geom.Nt, geom.Nf
     dev = inp.device
-    common = (_ptr(a['pos']), _ptr(geom.sdir), _ptr(geom.freqs))
-    tables = (_ptr(a['direct']), _ptr(a['conj']), a['Nant'], Nbl, Nt, Nf, geom.Pstride, st_t, st_f, m, geom.sign)
+    geo = (_ptr(geom.sdir), _ptr(geom.freqs))
+    shape = (Nbl, Nt, Nf, geom.Pstride, st_t, st_f, m, geom.sign)
     if not backward:
         # inp: psky (Nt, 1, Npp, Nf, Ps[, 2]) float32 view; out: vis (Npp, Nbl, Nt, Nf, 2) float32
         amax = inp.abs().amax(dim=(-1, -2) if cplx else -1)                       # (Nt, 1, Npp, Nf)
@@ -172,9 +194,15 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
         for pp in range(Npp):
             for c in range(m):
                 dst = out[pp] if c == 0 else tmp
-                rc = lib.rime_fringe_ant_fwd(*common, ctypes.c_void_p(inp.data_ptr() + 4 * (pp * st_pp + c)),
-                                             _ptr(scale[pp]), *tables, _ptr(dst), _ptr(ws), ws.numel(), _stream())
-                check(rc, 'rime_fringe_ant_fwd')
+                src = ctypes.c_void_p(inp.data_ptr() + 4 * (pp * st_pp + c))
+                for blk in a['blocks']:
+                    rc = lib.rime_fringe_ant_fwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], *geo, src,
+                                                       _ptr(scale[pp]), _ptr(blk['direct']), _ptr(blk['conj']),
+                                                       *shape, _ptr(ws), ws.numel(), _stream())
+                    check(rc, 'rime_fringe_ant_fwd_block')
+                rc = lib.rime_fringe_ant_fwd_finish(_ptr(ws), ws.numel(), _ptr(dst), Nbl, Nt, Nf, geom.Pstride,
+                                                    _stream())
+                check(rc, 'rime_fringe_ant_fwd_finish')
             if cplx:                                         # V += i V[ai]
                 out[pp][..., 0] -= tmp[..., 1]
                 out[pp][..., 1] += tmp[..., 0]
@@ -186,10 +214,14 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
         for pp in range(Npp):
             for c in range(m):
                 g = inp[pp] if c == 0 else torch.stack([inp[pp][..., 1], -inp[pp][..., 0]], dim=-1).contiguous()
-                rc = lib.rime_fringe_ant_bwd(*common, _ptr(g), _ptr(scale[pp]), *tables,
-                                             ctypes.c_void_p(out.data_ptr() + 4 * (pp * st_pp + c)),
-                                             _ptr(ws), ws.numel(), _stream())
-                check(rc, 'rime_fringe_ant_bwd')
+                rc = lib.rime_fringe_ant_bwd_prepare(_ptr(g), Nbl, Nt, Nf, _ptr(ws), ws.numel(), _stream())
+                check(rc, 'rime_fringe_ant_bwd_prepare')
+                dst = ctypes.c_void_p(out.data_ptr() + 4 * (pp * st_pp + c))
+                for k, blk in enumerate(a['blocks']):
+                    rc = lib.rime_fringe_ant_bwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], *geo,
+                                                       _ptr(scale[pp]), _ptr(blk['direct']), _ptr(blk['conj']),
+                                                       *shape, int(k > 0), dst, _ptr(ws), ws.numel(), _stream())
+                    check(rc, 'rime_fringe_ant_bwd_block')
     return Npp * m
 
 
@@ -200,11 +232,11 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False):
     if Nant > MFMA_MAX_ANTS or len(bl_ants) != self.Nbl:
         return
     # worth it when the array is big enough to fill 32x32 tiles and most pairs are requested
-    # (measured: 128 antennas / 8128 baselines 3.7x (fwd) and 5.3x (bwd) faster than the
+    # (measured: 128 antennas / 8128 baselines 4.8x (fwd) and 5.8x (bwd) faster than the
     # baseline-formulation kernels; 19 antennas 3x slower)
     if not force and (Nant < 48 or self.Nbl < Nant * Nant // 8):
         return
-    tabs = _antenna_tables(bl_ants, Nant)
+    tabs = _antenna_blocks(bl_ants, Nant)
     if tabs is None:
         return
     # the factorisation must reproduce the baseline vectors it replaces
@@ -214,12 +246,26 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False):
     if not torch.allclose(pos[i2] - pos[i1], self.blvecs, rtol=0, atol=1e-9):
         return
     dev = self.blvecs.device
-    # executed matrix-core work per launch (forward == backward): per 8 pixels, 6 MFMAs of
-    # 2*32*32*16 flop on each upper-triangular 32x32 antenna tile
-    TA = (Nant + 31) // 32
-    mfma_flops = self.Nt * self.Nf * (self.Pstride // 8) * (TA * (TA + 1) // 2) * 6 * 32768
-    self.ant = dict(pos=pos, Nant=Nant, direct=torch.as_tensor(tabs[0].reshape(-1), device=dev),
-                    conj=torch.as_tensor(tabs[1].reshape(-1), device=dev), mfma_flops=mfma_flops)
+    blocks, tiles = [], 0
+    for (gi, gj) in sorted(tabs):
+        direct, conj = tabs[(gi, gj)]
+        pi = pos[gi * MFMA_GROUP:min((gi + 1) * MFMA_GROUP, Nant)]
+        if gi == gj:
+            rows, TA = pi.contiguous(), (pi.shape[0] + 31) // 32
+            tiles += TA * (TA + 1) // 2
+        else:
+            pj = pos[gj * MFMA_GROUP:min((gj + 1) * MFMA_GROUP, Nant)]
+            rows = torch.zeros(2 * MFMA_GROUP, 3, dtype=torch.float64, device=pos.device)
+            rows[:pi.shape[0]] = pi
+            rows[MFMA_GROUP:MFMA_GROUP + pj.shape[0]] = pj
+            tiles += 16
+        blocks.append(dict(pos=rows, nrows=int(rows.shape[0]), cross=int(gi != gj),
+                           direct=torch.as_tensor(direct.reshape(-1), device=dev),
+                           conj=torch.as_tensor(conj.reshape(-1), device=dev)))
+    # executed matrix-core work per pass (forward == backward): per 16 pixels, 12 MFMAs of
+    # 2*32*32*16 flop on each 32x32 antenna tile of every block
+    mfma_flops = self.Nt * self.Nf * (self.Pstride // 16) * tiles * 12 * 32768
+    self.ant = dict(blocks=blocks, Nant=Nant, mfma_flops=mfma_flops)
 
 
 FringeGeometry._setup_antenna_path = _setup_antenna_path

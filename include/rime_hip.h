@@ -101,8 +101,7 @@ int rime_fringe_sum_bwd(int dtype,
                         void* gpsky, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * Antenna-factored fringe sum on the matrix cores (float32, 1-pol real psky, one beam-model
- * pair, Nant <= 128).  Same result as rime_fringe_sum_fwd/bwd for baselines that are antenna
+ * Antenna-factored fringe sum on the matrix cores (float32, one beam-model pair).  Same result as rime_fringe_sum_fwd/bwd for baselines that are antenna
  * pairs: with E_a = exp(sign 2 pi i nu r_a.s / c) the fringe of baseline (a1 -> a2) is
  * E_a2 conj(E_a1), so per (time, channel) all visibilities are one Hermitian rank-P update
  * V = E^H diag(psky) E, computed on v_mfma_f32_32x32x16_f16 with an f16 hi/lo split of the f32
@@ -131,6 +130,33 @@ int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* 
                         const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
                         long long st_t, long long st_f, long long st_p, int sign, float* gpsky,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Arrays with more than 128 antennas: the antennas are cut into groups of <= 128 and the pair
+ * matrix into blocks (I, J), I <= J.  rime_fringe_ant_fwd == one diagonal block + finish;
+ * rime_fringe_ant_bwd == prepare + one diagonal block.
+ *   diagonal block (cross = 0): antpos [Nrows <= 128, 3] of group I, tables as above (local indices)
+ *   cross block    (cross = 1): antpos [256, 3] = group I then group J, each zero-padded to 128 rows;
+ *       pair_direct[i*128 + j] = slot of baseline (I_i -> J_j), pair_conj[i*128 + j] = slot of
+ *       baseline (J_j -> I_i), or -1
+ * Forward blocks fill disjoint baseline slots of the slab workspace (every baseline must belong
+ * to exactly one block); _finish sums the pixel splits and writes vis [Nbl, Nt, Nf].  Backward:
+ * _prepare transposes gvis into the workspace once, every block reads it; blocks after the first
+ * pass accumulate = 1 (stream order makes the sum deterministic). */
+int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
+                              const double* freqs, const float* psky, const float* scale,
+                              const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf,
+                              int Pstride, long long st_t, long long st_f, long long st_p, int sign,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int rime_fringe_ant_fwd_finish(const void* workspace, size_t workspace_bytes, float* vis,
+                               int Nbl, int Nt, int Nf, int Pstride, void* stream);
+int rime_fringe_ant_bwd_prepare(const float* gvis, int Nbl, int Nt, int Nf,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
+                              const double* freqs, const float* gscale, const int* pair_direct,
+                              const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
+                              long long st_t, long long st_f, long long st_p, int sign,
+                              int accumulate, float* gpsky, const void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Materialised fringe, for callers that want the tensor itself (imaging.VisMapper.build_A,

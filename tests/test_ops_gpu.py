@@ -250,6 +250,34 @@ def test_fringe_sum_matrix_core_polarised(ops, Npp, cplx, conj):
     assert relmax(gx[..., :P], ref_in.grad) < 1e-4
 
 
+@pytest.mark.parametrize('Nant,frac,Npp', [(200, 0.3, 1), (260, 0.2, 1), (150, 0.5, 2)])
+def test_fringe_sum_matrix_core_antenna_groups(ops, Nant, frac, Npp):
+    """more than 128 antennas: groups of 128, diagonal + cross blocks (both pair orientations in
+    the cross blocks, a last group that does not fill its tiles), forward and backward"""
+    ant, pairs, blvecs, freqs, zenaz, _ = make_antenna_case(Nant, Nant, Nt=2, Nf=3, P=400, frac=frac, autos=3)
+    rng = np.random.default_rng(3)
+    Nt, _, P = zenaz.shape
+    psky = torch.as_tensor(rng.normal(size=(Nt, 1, Npp, 3, P)) * np.exp(-9.0 * rng.uniform(size=(Nt, 1, Npp, 3, P))))
+    Ps = ops.pad_to_tile(P)
+    sdir = torch.zeros(Nt, 3, Ps, dtype=torch.float64)
+    for t in range(Nt):
+        sdir[t, :, :P] = orc.pointing_vectors(zenaz[t, 0], zenaz[t, 1])
+    geom = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, antpos=ant.cuda(), bl_ants=pairs, mfma=True)
+    assert geom.ant is not None
+    ngroups = (Nant + 127) // 128
+    assert ngroups <= len(geom.ant['blocks']) <= ngroups * (ngroups + 1) // 2   # empty blocks are skipped
+    ref_in = psky.clone().requires_grad_(True)
+    ref = oracle_fringe_sum(ref_in, blvecs, zenaz, freqs, [0] * len(pairs))
+    gv = torch.as_tensor(np.random.default_rng(5).normal(size=tuple(ref.shape))
+                         + 1j * np.random.default_rng(6).normal(size=tuple(ref.shape)))
+    (ref * gv.conj()).real.sum().backward()
+    x = pad_psky(psky, Ps).float().cuda().requires_grad_(True)
+    vis = ops.fringe_sum(x, geom)
+    assert relmax(vis, ref) < 1e-5
+    (vis * gv.to(torch.complex64).cuda().conj()).real.sum().backward()
+    assert relmax(x.grad[..., :P], ref_in.grad) < 1e-4
+
+
 def test_fringe_sum_matrix_core_splits_and_degenerate_rows(ops):
     """MFMA path with several pixel splits (partial slabs + transposing reduction), an all-zero
     psky row (power-of-two scale of an empty row), an all-negative row (sign masks on every
