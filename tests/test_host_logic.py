@@ -258,3 +258,35 @@ def test_eq2top_basic_geometry():
     assert abs(zen[2] - 90.0) < 1e-6 and abs(az[2] - 90.0) < 1e-6       # RA = LST + 6h: rising due east
     angs = tel.eq2top(jd, torch.tensor([0.0]), torch.tensor([0.0]), store=True)
     assert tel.hash(jd, torch.tensor([0.0])) in tel.conv_cache and angs.shape == (2, 1)   # tests/test_telescope.py:27-38
+
+
+def test_antenna_block_tables():
+    """pair tables of the matrix-core path: every baseline lands in exactly one slot of exactly one
+    (group I <= group J) block, with the orientation rules include/rime_hip.h documents"""
+    from bayeslim_amd import ops
+    rng = np.random.default_rng(0)
+    Nant = 300                                   # groups of 128, 128, 44
+    pairs = [(i, j) for i in range(Nant) for j in range(i, Nant) if rng.random() < 0.05]
+    pairs = [p if rng.random() < 0.5 else p[::-1] for p in pairs]
+    tabs = ops._antenna_blocks(pairs, Nant)
+    assert set(tabs) <= {(i, j) for i in range(3) for j in range(i, 3)}
+    seen = np.zeros(len(pairs), dtype=int)
+    for (gi, gj), (direct, conj) in tabs.items():
+        for tab, is_conj in ((direct, False), (conj, True)):
+            ii, jj = np.nonzero(tab >= 0)
+            for i, j in zip(ii, jj):
+                b = tab[i, j]
+                seen[b] += 1
+                a1, a2 = pairs[b]
+                row, col = gi * 128 + i, gj * 128 + j            # V[row, col] = sum conj(E_row) E_col
+                assert (a1, a2) == ((col, row) if is_conj else (row, col))
+                if gi == gj:
+                    assert i // 32 <= j // 32                     # upper-triangular tiles only
+                    if is_conj:
+                        assert i // 32 < j // 32
+    assert (seen == 1).all()
+    # a pair and its reverse are distinct slots; the same pair twice cannot be represented
+    assert ops._antenna_blocks([(1, 2), (2, 1)], 4) is not None
+    assert ops._antenna_blocks([(130, 2), (2, 130)], 140) is not None
+    assert ops._antenna_blocks([(1, 2), (1, 2)], 4) is None
+    assert ops._antenna_blocks([(2, 130), (2, 130)], 140) is None
