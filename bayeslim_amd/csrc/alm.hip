@@ -271,6 +271,253 @@ alm2pix_bwd_mfma_kernel(const float* __restrict__ gout, const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// float32 fast path: f16 hi/lo split operands on v_mfma_f32_32x32x16_f16 (three cross products,
+// f32 accumulation -- the scheme of fringe_mfma.hip; 22 significant bits, 16x the f32-MFMA rate), so
+// that both directions run at the speed Ylm streams from HBM instead of the f32 matrix-core rate.
+// The small operand (alm rows / gout rows) is scaled per row by a power of two, split once by
+// split_rows_kernel into A-fragment order in a workspace and copied to LDS by the GEMM blocks; the
+// streamed operand (Ylm, scaled by the caller's power of two y_scale) is split in registers by the
+// lane that loaded it.
+// ---------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split2h(float a, float b, uint32_t& hi, uint32_t& lo)
+{
+    auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    hi = __builtin_bit_cast(uint32_t, h);
+    auto l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+#define ALM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
+
+// Row operand X [R][L] (f32) -> per-row power-of-two scale, f16 hi / lo images in A-fragment order:
+// granule ((s * 2 + h) * Rpad + r) holds k = 16 s + 8 h + 0..7 of row r (zero beyond L / R).
+// `neg_odd`: negate odd k (the imaginary parts of alm: out = are Yre - aim Yim).  One block per row.
+__global__ void __launch_bounds__(256)
+split_rows_kernel(const float* __restrict__ X, int R, int L, int Rpad, int neg_odd,
+                  uint4* __restrict__ img_hi, uint4* __restrict__ img_lo, float* __restrict__ inv_scale)
+{
+    __shared__ float red[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int nsteps = (L + 15) / 16;
+    float scale = 1.0f;
+    if (r < R) {
+        float m = 0.f;
+        for (int i = tid; i < L; i += 256) m = fmaxf(m, fabsf(X[(size_t)r * L + i]));
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) scale = exp2f(floorf(log2f(8192.0f / m)));            // max|x| * scale in [2^12, 2^13]
+        if (tid == 0) inv_scale[r] = 1.0f / scale;
+    } else if (tid == 0) inv_scale[r] = 0.f;
+    for (int g = tid; g < nsteps * 2; g += 256) {
+        float v[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int k = g * 8 + jj;
+            float x = (r < R && k < L) ? X[(size_t)r * L + k] * scale : 0.f;
+            v[jj] = (neg_odd && (jj & 1)) ? -x : x;
+        }
+        uint4 hi, lo;
+        split2h(v[0], v[1], hi.x, lo.x); split2h(v[2], v[3], hi.y, lo.y);
+        split2h(v[4], v[5], hi.z, lo.z); split2h(v[6], v[7], hi.w, lo.w);
+        img_hi[(size_t)g * Rpad + r] = hi;
+        img_lo[(size_t)g * Rpad + r] = lo;
+    }
+}
+
+// forward: out[r, j] = sum_k A[r, k] Y[k, j], k = (c, re|im).  Block = 4 waves x 32 pixels, MT row
+// tiles per wave; per chunk of 32 coefficients (4 K steps) the block copies the pre-split A
+// granules to LDS (fetched one chunk ahead into registers) and every lane splits the 16 Ylm values
+// it loaded (also one chunk ahead): 12 MT MFMAs against ~130 VALU instructions per chunk and wave.
+template <int MT>
+__global__ void __launch_bounds__(256)
+alm2pix_fwd_f16_kernel(const uint4* __restrict__ a_hi, const uint4* __restrict__ a_lo,
+                       const float* __restrict__ inv_scale, const float* __restrict__ Ylm, float y_scale,
+                       int R, int Rpad, int Ncoeff, int Npix, float* __restrict__ out)
+{
+    constexpr int ROWS = MT * 32;
+    constexpr int NG = 8 * ROWS;                       // granules per image and chunk: (ks, h, row)
+    constexpr int PT = NG / 256;                       // per thread
+    __shared__ uint4 lds_hi[NG], lds_lo[NG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.y * ROWS;
+    const int j0 = (blockIdx.x * 4 + wave) * 32;
+    const int jl = min(j0 + (lane & 31), Npix - 1);
+    const int h = lane >> 5;
+    const int nsteps = (2 * Ncoeff + 15) / 16;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    float2 bcur[16], bnxt[16];                         // [ks * 4 + i]: coefficient c0 + 8 ks + 4 h + i
+    uint4 ahq[PT], alq[PT];
+    auto load_b = [&](int c0, float2 (&b)[16]) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = c0 + 8 * (u >> 2) + 4 * h + (u & 3);
+            b[u] = (c < Ncoeff) ? *reinterpret_cast<const float2*>(Ylm + ((size_t)c * Npix + jl) * 2)
+                                : make_float2(0.f, 0.f);
+        }
+    };
+    auto fetch_a = [&](int s0) {                       // K steps s0 .. s0 + 3
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int i = tid + u * 256;
+            const int row = i % ROWS, g = i / ROWS;    // g = ks * 2 + h
+            const int sg = s0 * 2 + g;
+            const bool ok = sg < nsteps * 2;
+            ahq[u] = ok ? a_hi[(size_t)sg * Rpad + r0 + row] : make_uint4(0, 0, 0, 0);
+            alq[u] = ok ? a_lo[(size_t)sg * Rpad + r0 + row] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    load_b(0, bcur);
+    fetch_a(0);
+    for (int c0 = 0; c0 < Ncoeff; c0 += 32) {
+        __syncthreads();                               // previous chunk consumed
+#pragma unroll
+        for (int u = 0; u < PT; ++u) { lds_hi[tid + u * 256] = ahq[u]; lds_lo[tid + u * 256] = alq[u]; }
+        __syncthreads();
+        if (c0 + 32 < Ncoeff) { load_b(c0 + 32, bnxt); fetch_a(c0 / 8 + 4); }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 bh, bl;
+            split2h(bcur[ks * 4 + 0].x * y_scale, bcur[ks * 4 + 0].y * y_scale, bh.x, bl.x);
+            split2h(bcur[ks * 4 + 1].x * y_scale, bcur[ks * 4 + 1].y * y_scale, bh.y, bl.y);
+            split2h(bcur[ks * 4 + 2].x * y_scale, bcur[ks * 4 + 2].y * y_scale, bh.z, bl.z);
+            split2h(bcur[ks * 4 + 3].x * y_scale, bcur[ks * 4 + 3].y * y_scale, bh.w, bl.w);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int gi = (ks * 2 + h) * ROWS + m * 32 + (lane & 31);
+                const uint4 ah = lds_hi[gi], al = lds_lo[gi];
+                acc[m] = ALM_MFMA(ah, bh, acc[m]);
+                acc[m] = ALM_MFMA(ah, bl, acc[m]);
+                acc[m] = ALM_MFMA(al, bh, acc[m]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) bcur[u] = bnxt[u];
+    }
+    const int col = j0 + (lane & 31);
+    if (col < Npix) {
+        const float iy = 1.0f / y_scale;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = r0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < R) out[(size_t)row * Npix + col] = acc[m][e] * inv_scale[row] * iy;
+            }
+    }
+}
+
+// backward: galm[r, c, q] = sum_j gout[r, j] Y[c, j, q] (q ? -1 : +1).  K = pixels (16 per MFMA).
+// Wave = 32 coefficients x MT row tiles with separate accumulators for the re and im columns: a
+// lane loads 8 consecutive pixels (re, im interleaved, 64 B) of ITS coefficient and uses both
+// components.  Block = 4 waves = 128 coefficients sharing the pre-split gout granules through
+// LDS; grid.y splits the pixel axis (partials reduced by alm_reduce_kernel).
+template <int MT>
+__global__ void __launch_bounds__(256)
+alm2pix_bwd_f16_kernel(const uint4* __restrict__ g_hi, const uint4* __restrict__ g_lo,
+                       const float* __restrict__ inv_scale, const float* __restrict__ Ylm, float y_scale,
+                       int R, int Rpad, int Ncoeff, int Npix, int steps_per_split, float* __restrict__ part)
+{
+    constexpr int ROWS = MT * 32;
+    constexpr int NG = 4 * ROWS;                       // granules per image and chunk of 2 K steps
+    constexpr int PT = (NG + 255) / 256;
+    __shared__ uint4 lds_hi[NG], lds_lo[NG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.z * ROWS;
+    const int c = (blockIdx.x * 4 + wave) * 32 + (lane & 31);
+    const int cl = min(c, Ncoeff - 1);
+    const int h = lane >> 5;
+    const int nsteps = (Npix + 15) / 16;
+    const int sbeg = blockIdx.y * steps_per_split;
+    const int send = min(nsteps, sbeg + steps_per_split);
+    f32x16 accr[MT], acci[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { accr[m][e] = 0.f; acci[m][e] = 0.f; }
+
+    float4 ycur[8], ynxt[8];                           // [ks * 4 + i]: pixels 16 (s + ks) + 8 h + 2 i, +1
+    uint4 ahq[PT], alq[PT];
+    const float* yrow = Ylm + (size_t)cl * Npix * 2;
+    auto load_y = [&](int s0, float4 (&y)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = 16 * (s0 + (u >> 2)) + 8 * h + 2 * (u & 3);
+            if (j + 1 < Npix) y[u] = *reinterpret_cast<const float4*>(yrow + (size_t)j * 2);
+            else if (j < Npix) y[u] = make_float4(yrow[(size_t)j * 2], yrow[(size_t)j * 2 + 1], 0.f, 0.f);
+            else y[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto fetch_a = [&](int s0) {
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int i = tid + u * 256;
+            const int row = i % ROWS, g = i / ROWS;    // g = ks * 2 + h
+            const int sg = s0 * 2 + g;
+            const bool ok = i < NG && sg < send * 2;
+            ahq[u] = ok ? g_hi[(size_t)sg * Rpad + r0 + row] : make_uint4(0, 0, 0, 0);
+            alq[u] = ok ? g_lo[(size_t)sg * Rpad + r0 + row] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    if (sbeg < send) { load_y(sbeg, ycur); fetch_a(sbeg); }
+    for (int s0 = sbeg; s0 < send; s0 += 2) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PT; ++u)
+            if (tid + u * 256 < NG) { lds_hi[tid + u * 256] = ahq[u]; lds_lo[tid + u * 256] = alq[u]; }
+        __syncthreads();
+        if (s0 + 2 < send) { load_y(s0 + 2, ynxt); fetch_a(s0 + 2); }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 rh, rl, ih, il;
+            split2h(ycur[ks * 4 + 0].x * y_scale, ycur[ks * 4 + 0].z * y_scale, rh.x, rl.x);
+            split2h(ycur[ks * 4 + 1].x * y_scale, ycur[ks * 4 + 1].z * y_scale, rh.y, rl.y);
+            split2h(ycur[ks * 4 + 2].x * y_scale, ycur[ks * 4 + 2].z * y_scale, rh.z, rl.z);
+            split2h(ycur[ks * 4 + 3].x * y_scale, ycur[ks * 4 + 3].z * y_scale, rh.w, rl.w);
+            split2h(ycur[ks * 4 + 0].y * y_scale, ycur[ks * 4 + 0].w * y_scale, ih.x, il.x);
+            split2h(ycur[ks * 4 + 1].y * y_scale, ycur[ks * 4 + 1].w * y_scale, ih.y, il.y);
+            split2h(ycur[ks * 4 + 2].y * y_scale, ycur[ks * 4 + 2].w * y_scale, ih.z, il.z);
+            split2h(ycur[ks * 4 + 3].y * y_scale, ycur[ks * 4 + 3].w * y_scale, ih.w, il.w);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int gi = (ks * 2 + h) * ROWS + m * 32 + (lane & 31);
+                const uint4 ah = lds_hi[gi], al = lds_lo[gi];
+                accr[m] = ALM_MFMA(ah, rh, accr[m]);
+                acci[m] = ALM_MFMA(ah, ih, acci[m]);
+                accr[m] = ALM_MFMA(ah, rl, accr[m]);
+                acci[m] = ALM_MFMA(ah, il, acci[m]);
+                accr[m] = ALM_MFMA(al, rh, accr[m]);
+                acci[m] = ALM_MFMA(al, ih, acci[m]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ycur[u] = ynxt[u];
+    }
+    if (c < Ncoeff) {
+        float* dst = part + (size_t)blockIdx.y * R * Ncoeff * 2;
+        const float iy = 1.0f / y_scale;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = r0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < R) {
+                    const float sc = inv_scale[row] * iy;
+                    *reinterpret_cast<float2*>(dst + ((size_t)row * Ncoeff + c) * 2) =
+                        make_float2(accr[m][e] * sc, -acci[m][e] * sc);
+                }
+            }
+    }
+}
+
 __global__ void alm_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t len, int S)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
@@ -291,16 +538,66 @@ static int bwd_splits(int R, int Ncoeff, int Npix)
     return (int)std::max<long>(1, S);
 }
 
+// ---- f16-split fast path: shapes and workspace layout ---------------------------------------
+struct SplitPlan {
+    int MT, Rpad, nsteps;            // row tiles per block, padded rows, K steps of 16
+    size_t img_bytes;                // one f16 image (hi or lo) of the row operand
+    int S, steps_per_split;          // backward only: pixel splits
+};
+
+static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward)
+{
+    SplitPlan p{};
+    p.MT = R > 64 ? 4 : (R > 32 ? 2 : 1);
+    p.Rpad = ((R + p.MT * 32 - 1) / (p.MT * 32)) * p.MT * 32;
+    p.nsteps = (K + 15) / 16;
+    p.img_bytes = (size_t)p.nsteps * 2 * p.Rpad * 16;
+    p.S = 1; p.steps_per_split = p.nsteps;
+    if (backward) {
+        // >= ~1024 blocks of 128 coefficients x MT row tiles; every split a multiple of 2 K steps
+        const long blocks = (long)((Ncoeff + 127) / 128) * (p.Rpad / (p.MT * 32));
+        long S = (1024 + blocks - 1) / blocks;
+        const long maxS = std::max(1, p.nsteps / 32);
+        S = std::max<long>(1, std::min(S, maxS));
+        int sps = (int)((p.nsteps + S - 1) / S);
+        sps = ((sps + 1) / 2) * 2;
+        p.steps_per_split = sps;
+        p.S = (p.nsteps + sps - 1) / sps;
+    }
+    return p;
+}
+
 } // namespace rime
 
 using namespace rime;
 
-extern "C" int rime_alm2pix_fwd(int dtype, const void* alm, const void* Ylm, int R, int Ncoeff,
-                                int Npix, void* out, void* stream)
+extern "C" size_t rime_alm2pix_fwd_workspace(int dtype, int R, int Ncoeff, int Npix)
 {
-    if (!alm || !Ylm || !out || R <= 0 || Ncoeff <= 0 || Npix <= 0) return RIME_EINVAL;
+    if (dtype != RIME_F32 || R <= 0 || Ncoeff <= 0) return 0;
+    const SplitPlan p = split_plan(R, 2 * Ncoeff, Ncoeff, false);
+    return 2 * p.img_bytes + (size_t)p.Rpad * sizeof(float);
+}
+
+extern "C" int rime_alm2pix_fwd(int dtype, const void* alm, const void* Ylm, double y_scale, int R, int Ncoeff,
+                                int Npix, void* out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!alm || !Ylm || !out || R <= 0 || Ncoeff <= 0 || Npix <= 0 || y_scale < 0) return RIME_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == RIME_F32) {
+    if (dtype == RIME_F32 && y_scale > 0) {
+        const SplitPlan p = split_plan(R, 2 * Ncoeff, Ncoeff, false);
+        if (!workspace || workspace_bytes < 2 * p.img_bytes + (size_t)p.Rpad * sizeof(float)) return RIME_EWORKSPACE;
+        uint4* hi = (uint4*)workspace;
+        uint4* lo = (uint4*)((char*)workspace + p.img_bytes);
+        float* inv = (float*)((char*)workspace + 2 * p.img_bytes);
+        hipLaunchKernelGGL(split_rows_kernel, dim3(p.Rpad), dim3(256), 0, st, (const float*)alm, R, 2 * Ncoeff,
+                           p.Rpad, 1, hi, lo, inv);
+        dim3 grid((Npix + 127) / 128, p.Rpad / (p.MT * 32));
+        const float ys = (float)y_scale;
+        const float* Y = (const float*)Ylm; float* o = (float*)out;
+        if (p.MT == 4) hipLaunchKernelGGL((alm2pix_fwd_f16_kernel<4>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, o);
+        else if (p.MT == 2) hipLaunchKernelGGL((alm2pix_fwd_f16_kernel<2>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, o);
+        else hipLaunchKernelGGL((alm2pix_fwd_f16_kernel<1>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, o);
+    } else if (dtype == RIME_F32) {
         const float* a = (const float*)alm; const float* Y = (const float*)Ylm; float* o = (float*)out;
         const int MT = R > 64 ? 4 : (R > 32 ? 2 : 1);
         dim3 grid((Npix + 127) / 128, (R + MT * 32 - 1) / (MT * 32));
@@ -318,17 +615,44 @@ extern "C" int rime_alm2pix_fwd(int dtype, const void* alm, const void* Ylm, int
 
 extern "C" size_t rime_alm2pix_bwd_workspace(int dtype, int R, int Ncoeff, int Npix)
 {
-    if (dtype != RIME_F32) return 0;
-    const int S = bwd_splits(R, Ncoeff, Npix);
-    return S <= 1 ? 0 : (size_t)S * R * Ncoeff * 2 * sizeof(float);
+    if (dtype != RIME_F32 || R <= 0 || Ncoeff <= 0 || Npix <= 0) return 0;
+    // exact-f32 path: split partials; f16-split path: images + row scales + split partials
+    const int S0 = bwd_splits(R, Ncoeff, Npix);
+    const size_t exact = S0 <= 1 ? 0 : (size_t)S0 * R * Ncoeff * 2 * sizeof(float);
+    const SplitPlan p = split_plan(R, Npix, Ncoeff, true);
+    const size_t fast = 2 * p.img_bytes + (size_t)p.Rpad * sizeof(float) + (size_t)p.S * R * Ncoeff * 2 * sizeof(float);
+    return std::max(exact, fast);
 }
 
-extern "C" int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, int R, int Ncoeff,
+extern "C" int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, double y_scale, int R, int Ncoeff,
                                 int Npix, void* galm, void* workspace, size_t workspace_bytes,
                                 void* stream)
 {
-    if (!gout || !Ylm || !galm || R <= 0 || Ncoeff <= 0 || Npix <= 0) return RIME_EINVAL;
+    if (!gout || !Ylm || !galm || R <= 0 || Ncoeff <= 0 || Npix <= 0 || y_scale < 0) return RIME_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == RIME_F32 && y_scale > 0) {
+        const SplitPlan p = split_plan(R, Npix, Ncoeff, true);
+        const size_t len = (size_t)R * Ncoeff * 2;
+        const size_t need = 2 * p.img_bytes + (size_t)p.Rpad * sizeof(float) + (size_t)p.S * len * sizeof(float);
+        if (!workspace || workspace_bytes < need) return RIME_EWORKSPACE;
+        uint4* hi = (uint4*)workspace;
+        uint4* lo = (uint4*)((char*)workspace + p.img_bytes);
+        float* inv = (float*)((char*)workspace + 2 * p.img_bytes);
+        float* part = p.S > 1 ? inv + p.Rpad : (float*)galm;
+        hipLaunchKernelGGL(split_rows_kernel, dim3(p.Rpad), dim3(256), 0, st, (const float*)gout, R, Npix,
+                           p.Rpad, 0, hi, lo, inv);
+        dim3 grid((Ncoeff + 127) / 128, p.S, p.Rpad / (p.MT * 32));
+        const float ys = (float)y_scale;
+        const float* Y = (const float*)Ylm;
+        if (p.MT == 4) hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<4>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.steps_per_split, part);
+        else if (p.MT == 2) hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<2>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.steps_per_split, part);
+        else hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<1>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.steps_per_split, part);
+        if (p.S > 1) {
+            int nb = (int)std::min<size_t>((len + 255) / 256, 2048);
+            hipLaunchKernelGGL(alm_reduce_kernel, dim3(nb), dim3(256), 0, st, part, (float*)galm, len, p.S);
+        }
+        return check_launch();
+    }
     if (dtype == RIME_F32) {
         const int S = bwd_splits(R, Ncoeff, Npix);
         const size_t len = (size_t)R * Ncoeff * 2;
@@ -348,14 +672,10 @@ extern "C" int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, in
         }
         return check_launch();
     }
+    if (dtype != RIME_F64) return RIME_EINVAL;
     constexpr int CT = 4, RTB = 8;
     dim3 grid((Ncoeff + CT - 1) / CT, (R + RTB - 1) / RTB);
-    if (dtype == RIME_F32)
-        hipLaunchKernelGGL((alm2pix_bwd_kernel<float, CT, RTB>), grid, dim3(256), 0, st,
-                           (const float*)gout, (const float*)Ylm, R, Ncoeff, Npix, (float*)galm);
-    else if (dtype == RIME_F64)
-        hipLaunchKernelGGL((alm2pix_bwd_kernel<double, CT, RTB>), grid, dim3(256), 0, st,
-                           (const double*)gout, (const double*)Ylm, R, Ncoeff, Npix, (double*)galm);
-    else return RIME_EINVAL;
+    hipLaunchKernelGGL((alm2pix_bwd_kernel<double, CT, RTB>), grid, dim3(256), 0, st,
+                       (const double*)gout, (const double*)Ylm, R, Ncoeff, Npix, (double*)galm);
     return check_launch();
 }

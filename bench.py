@@ -69,6 +69,8 @@ WORKLOADS = {
                desc='HERA-128 (8128 bl), nside=128 diffuse + 1e4 point sources, 256 freqs'),
     'c2': dict(array='hera19', nside=32, Nf=64, Npt=0, nt=30,
                desc='HERA-19 hex (171 bl), nside=32 diffuse sky, 64 freqs, 30 times'),
+    'c3': dict(array='hera37', nside=64, Nf=128, Npt=0, nt=60, lmax=128,
+               desc='HERA-37 (666 bl), a_lm sky lmax=128 on nside=64 via sph_harm + PixelBeam interp, 128 freqs, 60 times'),
 }
 
 
@@ -129,10 +131,23 @@ def build_model(inp, dev, bls, seed=0, fblock=None):
     tel = telescope_model.TelescopeModel((LON, LAT))
     gen = torch.Generator(device='cpu').manual_seed(seed)
     Npix = len(inp['ra'])
-    skyp = torch.nn.Parameter(torch.randn(1, 1, cfg['Nf'], Npix, generator=gen, dtype=f32).to(dev))
     angs = torch.as_tensor(np.stack([inp['ra'], inp['dec']]), device=dev)
-    diffuse = sky_model.PixelSky(skyp.detach()[:, :, f0:f1], angs, inp['px_area'],
-                                 R=sky_model.PixelSkyResponse(freqs, device=dev),
+    if cfg.get('lmax'):
+        # a_lm sky: params (1, 1, Nf, Ncoeff) complex -> map through AlmModel (HIP alm2pix kernels)
+        from bayeslim_amd import sph_harm
+        l, m = sph_harm.gen_lm(cfg['lmax'], real_field=True)
+        A = sph_harm.AlmModel(l, m, real_output=True)
+        A.device = dev
+        A.setup_Ylm(90.0 - inp['dec'], inp['ra'], generate=True)
+        amp = (1.0 / (1.0 + torch.as_tensor(np.asarray(l), dtype=f32)))[None, None, None, :]
+        re = torch.randn(1, 1, cfg['Nf'], len(l), generator=gen, dtype=f32) * amp
+        im = torch.randn(1, 1, cfg['Nf'], len(l), generator=gen, dtype=f32) * amp
+        skyp = torch.nn.Parameter(torch.complex(re, im).to(dev))
+        Rsky = sky_model.PixelSkyResponse(freqs, spatial_mode='alm', spat_LM=A, comp_params=False, device=dev)
+    else:
+        skyp = torch.nn.Parameter(torch.randn(1, 1, cfg['Nf'], Npix, generator=gen, dtype=f32).to(dev))
+        Rsky = sky_model.PixelSkyResponse(freqs, device=dev)
+    diffuse = sky_model.PixelSky(skyp.detach()[:, :, f0:f1], angs, inp['px_area'], R=Rsky,
                                  parameter=False, name='diffuse')
     leaves = [skyp]
     per_channel = [(skyp, 2)]                      # (parameter, channel axis)

@@ -197,13 +197,19 @@ int rime_interp_scatter_bwd(int dtype, int is_complex, const void* goutT,
  * Backward: galm[r, c] = sum_j gout[r, j] * conj(Ylm[c, j])   (complex, interleaved); the pixel
  *   axis may be split over blocks, partial sums go to a caller-owned workspace
  *   (rime_alm2pix_bwd_workspace bytes) and are reduced deterministically.
- * float32 runs on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32); float64 on the VALU.
+ * float32, y_scale > 0: operands split into f16 hi + lo halves on v_mfma_f32_32x32x16_f16 (three
+ *   cross products, f32 accumulation, 22 significant bits) so both directions run at the rate Ylm
+ *   streams from HBM.  y_scale is a power of two that brings max|Ylm| into [2^10, 2^14] (1.0 for
+ *   orthonormal Ylm); the row operand is scaled per row inside the library.
+ * float32, y_scale == 0: exact-f32 matrix cores (v_mfma_f32_32x32x2_f32).  float64: VALU.
+ * Both directions take a caller-owned workspace (rime_alm2pix_*_workspace bytes).
  * ------------------------------------------------------------------------------------- */
-int rime_alm2pix_fwd(int dtype, const void* alm, const void* Ylm, int R, int Ncoeff, int Npix,
-                     void* out, void* stream);
+size_t rime_alm2pix_fwd_workspace(int dtype, int R, int Ncoeff, int Npix);
+int rime_alm2pix_fwd(int dtype, const void* alm, const void* Ylm, double y_scale, int R, int Ncoeff,
+                     int Npix, void* out, void* workspace, size_t workspace_bytes, void* stream);
 size_t rime_alm2pix_bwd_workspace(int dtype, int R, int Ncoeff, int Npix);
-int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, int R, int Ncoeff, int Npix,
-                     void* galm, void* workspace, size_t workspace_bytes, void* stream);
+int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, double y_scale, int R, int Ncoeff,
+                     int Npix, void* galm, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }
