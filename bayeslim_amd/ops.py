@@ -10,6 +10,7 @@ tensors and raises otherwise -- there is no CPU path in the product.
   alm2pix      : out = Re(alm @ Ylm)                             sph_harm.py:1342-1372
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -110,6 +111,7 @@ class FringeGeometry:
             self.bl_order = torch.as_tensor(order, dtype=torch.int32, device=dev)
 
 
+MFMA_MIN_ANTS = int(os.environ.get('RIME_MFMA_MIN_ANTS', '33'))   # 'auto' threshold (see _setup_antenna_path)
 MFMA_GROUP = 128          # antennas per group of the matrix-core path (4 x 4 tiles of 32)
 
 
@@ -231,10 +233,11 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False):
     bl_ants = [(int(a), int(b)) for a, b in bl_ants]
     if Nant > MFMA_MAX_ANTS or len(bl_ants) != self.Nbl:
         return
-    # worth it when the array is big enough to fill 32x32 tiles and most pairs are requested
-    # (measured: 128 antennas / 8128 baselines 4.8x (fwd) and 5.8x (bwd) faster than the
-    # baseline-formulation kernels; 19 antennas 3x slower)
-    if not force and (Nant < 48 or self.Nbl < Nant * Nant // 8):
+    # worth it when the array needs at least two 32-antenna tiles and most pairs are requested
+    # (measured against the baseline-formulation kernels: 128 antennas / 8128 baselines 4.8x (fwd)
+    # and 5.8x (bwd) faster; 37 antennas / 666 baselines 1.1x and 1.6x faster; 19 antennas 1.7x and
+    # 1.1x slower)
+    if not force and (Nant < MFMA_MIN_ANTS or self.Nbl < Nant * Nant // 8):
         return
     tabs = _antenna_blocks(bl_ants, Nant)
     if tabs is None:
