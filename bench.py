@@ -258,7 +258,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shard', default='auto', choices=['auto', 'freq', 'bl'],
                     help='multi-GPU partition: channel blocks or baseline blocks (auto: channels when the '
-                         'antenna-factored matrix-core kernels apply, i.e. workload c4; else baselines)')
+                         'antenna-factored matrix-core kernels apply, i.e. workloads c3 / c4; else baselines)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -284,7 +284,7 @@ def main():
     bls = all_baselines(inp)
     shard = args.shard
     if shard == 'auto':
-        shard = 'freq' if args.workload == 'c4' else 'bl'
+        shard = 'freq' if args.workload in ('c3', 'c4') else 'bl'     # >= 33 antennas: antenna-factored kernels
     if shard == 'freq':
         bounds = rdist.shard_bounds(cfg['Nf'], world)
         my_bls, fblock, gdim = bls, bounds[rank], 4
