@@ -293,26 +293,38 @@ __device__ __forceinline__ void split2h(float a, float b, uint32_t& hi, uint32_t
 
 // Row operand X [R][L] (f32) -> per-row power-of-two scale, f16 hi / lo images in A-fragment order:
 // granule ((s * 2 + h) * Rpad + r) holds k = 16 s + 8 h + 0..7 of row r (zero beyond L / R).
-// `neg_odd`: negate odd k (the imaginary parts of alm: out = are Yre - aim Yim).  One block per row.
+// `neg_odd`: negate odd k (the imaginary parts of alm: out = are Yre - aim Yim).
+// Two kernels so that long rows (gout: Npix values) spread over the chip: row_absmax_kernel
+// (grid = rows x segments, integer atomicMax on the bit patterns of |x|: order-independent) and
+// split_rows_kernel (same grid).
+constexpr int SPLIT_SEG = 4096;                        // values per block
+
+__global__ void __launch_bounds__(256)
+row_absmax_kernel(const float* __restrict__ X, int R, int L, unsigned int* __restrict__ rowmax)
+{
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int k0 = blockIdx.y * SPLIT_SEG, k1 = min(L, k0 + SPLIT_SEG);
+    float m = 0.f;
+    for (int i = k0 + tid; i < k1; i += 256) m = fmaxf(m, fabsf(X[(size_t)r * L + i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0 && m > 0.f) atomicMax(rowmax + r, __float_as_uint(m));
+}
+
 __global__ void __launch_bounds__(256)
 split_rows_kernel(const float* __restrict__ X, int R, int L, int Rpad, int neg_odd,
-                  uint4* __restrict__ img_hi, uint4* __restrict__ img_lo, float* __restrict__ inv_scale)
+                  const unsigned int* __restrict__ rowmax, uint4* __restrict__ img_hi,
+                  uint4* __restrict__ img_lo, float* __restrict__ inv_scale)
 {
-    __shared__ float red[4];
     const int r = blockIdx.x, tid = threadIdx.x;
     const int nsteps = (L + 15) / 16;
     float scale = 1.0f;
     if (r < R) {
-        float m = 0.f;
-        for (int i = tid; i < L; i += 256) m = fmaxf(m, fabsf(X[(size_t)r * L + i]));
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        if ((tid & 63) == 0) red[tid >> 6] = m;
-        __syncthreads();
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float m = __uint_as_float(rowmax[r]);
         if (m > 0.f) scale = exp2f(floorf(log2f(8192.0f / m)));            // max|x| * scale in [2^12, 2^13]
-        if (tid == 0) inv_scale[r] = 1.0f / scale;
-    } else if (tid == 0) inv_scale[r] = 0.f;
-    for (int g = tid; g < nsteps * 2; g += 256) {
+    }
+    if (blockIdx.y == 0 && tid == 0) inv_scale[r] = (r < R) ? 1.0f / scale : 0.f;
+    const int g0 = blockIdx.y * (SPLIT_SEG / 8), g1 = min(nsteps * 2, g0 + SPLIT_SEG / 8);
+    for (int g = g0 + tid; g < g1; g += 256) {
         float v[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
@@ -416,44 +428,62 @@ alm2pix_fwd_f16_kernel(const uint4* __restrict__ a_hi, const uint4* __restrict__
 }
 
 // backward: galm[r, c, q] = sum_j gout[r, j] Y[c, j, q] (q ? -1 : +1).  K = pixels (16 per MFMA).
-// Wave = 32 coefficients x MT row tiles with separate accumulators for the re and im columns: a
-// lane loads 8 consecutive pixels (re, im interleaved, 64 B) of ITS coefficient and uses both
-// components.  Block = 4 waves = 128 coefficients sharing the pre-split gout granules through
-// LDS; grid.y splits the pixel axis (partials reduced by alm_reduce_kernel).
+// Wave = 32 coefficients x MT row tiles with separate accumulators for the re and im columns (a
+// B fragment needs 8 consecutive pixels of ONE coefficient row, and both components are used).
+// Block = 4 waves = 128 coefficients.  Per chunk of 32 pixels the block stages the Ylm tile
+// [128 coefficients][32 px][re,im] through LDS -- global loads are 256-B row segments, 16 B per lane,
+// fetched one chunk ahead -- together with the pre-split gout granules; the 32-pixel chunks are
+// dealt cyclically to S blocks (partials reduced by alm_reduce_kernel).  Measured 2.0 TB/s of Ylm
+// at R = 128 and 3.5 TB/s at R = 4: latency-bound (one chunk = 32 KB per block in flight, ~7 us
+// loaded latency); per-lane row streaming without LDS staging and contiguous split ranges are
+// within 5 % of this.
 template <int MT>
 __global__ void __launch_bounds__(256)
 alm2pix_bwd_f16_kernel(const uint4* __restrict__ g_hi, const uint4* __restrict__ g_lo,
                        const float* __restrict__ inv_scale, const float* __restrict__ Ylm, float y_scale,
-                       int R, int Rpad, int Ncoeff, int Npix, int steps_per_split, float* __restrict__ part)
+                       int R, int Rpad, int Ncoeff, int Npix, int S, float* __restrict__ part)
 {
     constexpr int ROWS = MT * 32;
-    constexpr int NG = 4 * ROWS;                       // granules per image and chunk of 2 K steps
+    constexpr int NG = 4 * ROWS;                       // gout granules per image and chunk of 2 K steps
     constexpr int PT = (NG + 255) / 256;
+    constexpr int YROW = 272;                          // 32 px x 8 B + 16 B pad: conflict-free 16-B reads
     __shared__ uint4 lds_hi[NG], lds_lo[NG];
+    __shared__ __align__(16) unsigned char y_lds[128 * YROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 32-pixel chunks are dealt cyclically to the S blocks of a coefficient tile, and the split index is
+    // the fastest grid dimension: blocks that run together read ADJACENT 256-B segments of the same
+    // Ylm rows (contiguous split ranges stream 128 x S scattered segments: 2.2 instead of 3+ TB/s)
+    const int split = blockIdx.x;
     const int r0 = blockIdx.z * ROWS;
-    const int c = (blockIdx.x * 4 + wave) * 32 + (lane & 31);
-    const int cl = min(c, Ncoeff - 1);
+    const int cblk = blockIdx.y * 128;
+    const int c = cblk + wave * 32 + (lane & 31);
     const int h = lane >> 5;
     const int nsteps = (Npix + 15) / 16;
-    const int sbeg = blockIdx.y * steps_per_split;
-    const int send = min(nsteps, sbeg + steps_per_split);
+    const int send = nsteps;
     f32x16 accr[MT], acci[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { accr[m][e] = 0.f; acci[m][e] = 0.f; }
 
-    float4 ycur[8], ynxt[8];                           // [ks * 4 + i]: pixels 16 (s + ks) + 8 h + 2 i, +1
+    float4 yq[8];                                      // this thread's 8 x 16 B of the next Ylm tile
     uint4 ahq[PT], alq[PT];
-    const float* yrow = Ylm + (size_t)cl * Npix * 2;
-    auto load_y = [&](int s0, float4 (&y)[8]) {
+    const bool aligned = (Npix & 1) == 0;              // rows start 16-B aligned
+    auto fetch_y = [&](int s0) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int j = 16 * (s0 + (u >> 2)) + 8 * h + 2 * (u & 3);
-            if (j + 1 < Npix) y[u] = *reinterpret_cast<const float4*>(yrow + (size_t)j * 2);
-            else if (j < Npix) y[u] = make_float4(yrow[(size_t)j * 2], yrow[(size_t)j * 2 + 1], 0.f, 0.f);
-            else y[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int i = tid + u * 256;               // (row, 16-B segment): 2 pixels
+            const int row = i >> 4, seg = i & 15;
+            const int cc = cblk + row, j = 16 * s0 + 2 * seg;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cc < Ncoeff && j < Npix) {
+                const float* src = Ylm + ((size_t)cc * Npix + j) * 2;
+                if (j + 1 < Npix) {
+                    if (aligned) v = *reinterpret_cast<const float4*>(src);
+                    else v = make_float4(src[0], src[1], src[2], src[3]);
+                } else { v.x = src[0]; v.y = src[1]; }
+            }
+            yq[u] = v;
         }
     };
     auto fetch_a = [&](int s0) {
@@ -467,25 +497,34 @@ alm2pix_bwd_f16_kernel(const uint4* __restrict__ g_hi, const uint4* __restrict__
             alq[u] = ok ? g_lo[(size_t)sg * Rpad + r0 + row] : make_uint4(0, 0, 0, 0);
         }
     };
-    if (sbeg < send) { load_y(sbeg, ycur); fetch_a(sbeg); }
-    for (int s0 = sbeg; s0 < send; s0 += 2) {
+    if (2 * split < send) { fetch_y(2 * split); fetch_a(2 * split); }
+    const unsigned char* ymine = y_lds + (wave * 32 + (lane & 31)) * YROW + 64 * h;
+    for (int s0 = 2 * split; s0 < send; s0 += 2 * S) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PT; ++u)
             if (tid + u * 256 < NG) { lds_hi[tid + u * 256] = ahq[u]; lds_lo[tid + u * 256] = alq[u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + u * 256;
+            *reinterpret_cast<float4*>(y_lds + (i >> 4) * YROW + (i & 15) * 16) = yq[u];
+        }
         __syncthreads();
-        if (s0 + 2 < send) { load_y(s0 + 2, ynxt); fetch_a(s0 + 2); }
+        if (s0 + 2 * S < send) { fetch_y(s0 + 2 * S); fetch_a(s0 + 2 * S); }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            float4 y[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[q] = *reinterpret_cast<const float4*>(ymine + 128 * ks + 16 * q);
             uint4 rh, rl, ih, il;
-            split2h(ycur[ks * 4 + 0].x * y_scale, ycur[ks * 4 + 0].z * y_scale, rh.x, rl.x);
-            split2h(ycur[ks * 4 + 1].x * y_scale, ycur[ks * 4 + 1].z * y_scale, rh.y, rl.y);
-            split2h(ycur[ks * 4 + 2].x * y_scale, ycur[ks * 4 + 2].z * y_scale, rh.z, rl.z);
-            split2h(ycur[ks * 4 + 3].x * y_scale, ycur[ks * 4 + 3].z * y_scale, rh.w, rl.w);
-            split2h(ycur[ks * 4 + 0].y * y_scale, ycur[ks * 4 + 0].w * y_scale, ih.x, il.x);
-            split2h(ycur[ks * 4 + 1].y * y_scale, ycur[ks * 4 + 1].w * y_scale, ih.y, il.y);
-            split2h(ycur[ks * 4 + 2].y * y_scale, ycur[ks * 4 + 2].w * y_scale, ih.z, il.z);
-            split2h(ycur[ks * 4 + 3].y * y_scale, ycur[ks * 4 + 3].w * y_scale, ih.w, il.w);
+            split2h(y[0].x * y_scale, y[0].z * y_scale, rh.x, rl.x);
+            split2h(y[1].x * y_scale, y[1].z * y_scale, rh.y, rl.y);
+            split2h(y[2].x * y_scale, y[2].z * y_scale, rh.z, rl.z);
+            split2h(y[3].x * y_scale, y[3].z * y_scale, rh.w, rl.w);
+            split2h(y[0].y * y_scale, y[0].w * y_scale, ih.x, il.x);
+            split2h(y[1].y * y_scale, y[1].w * y_scale, ih.y, il.y);
+            split2h(y[2].y * y_scale, y[2].w * y_scale, ih.z, il.z);
+            split2h(y[3].y * y_scale, y[3].w * y_scale, ih.w, il.w);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int gi = (ks * 2 + h) * ROWS + m * 32 + (lane & 31);
@@ -498,11 +537,9 @@ alm2pix_bwd_f16_kernel(const uint4* __restrict__ g_hi, const uint4* __restrict__
                 acci[m] = ALM_MFMA(al, ih, acci[m]);
             }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ycur[u] = ynxt[u];
     }
     if (c < Ncoeff) {
-        float* dst = part + (size_t)blockIdx.y * R * Ncoeff * 2;
+        float* dst = part + (size_t)split * R * Ncoeff * 2;
         const float iy = 1.0f / y_scale;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -554,17 +591,33 @@ static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward)
     p.img_bytes = (size_t)p.nsteps * 2 * p.Rpad * 16;
     p.S = 1; p.steps_per_split = p.nsteps;
     if (backward) {
-        // >= ~1024 blocks of 128 coefficients x MT row tiles; every split a multiple of 2 K steps
+        // ~2048 blocks of 128 coefficients x MT row tiles
         const long blocks = (long)((Ncoeff + 127) / 128) * (p.Rpad / (p.MT * 32));
-        long S = (1024 + blocks - 1) / blocks;
-        const long maxS = std::max(1, p.nsteps / 32);
-        S = std::max<long>(1, std::min(S, maxS));
-        int sps = (int)((p.nsteps + S - 1) / S);
-        sps = ((sps + 1) / 2) * 2;
-        p.steps_per_split = sps;
-        p.S = (p.nsteps + sps - 1) / sps;
+        long S = (2048 + blocks - 1) / blocks;                   // measured flat between 1024 and 4096 blocks
+        const long maxS = std::max(1, p.nsteps / 32);          // >= 16 chunks of 2 K steps per block
+        p.S = (int)std::max<long>(1, std::min(S, maxS));
+        p.steps_per_split = 0;                                   // chunks are dealt cyclically
     }
     return p;
+}
+
+static void launch_split_rows(const float* X, int R, int L, const SplitPlan& p, int neg_odd, void* workspace,
+                              hipStream_t st, uint4*& hi, uint4*& lo, float*& inv)
+{
+    hi = (uint4*)workspace;
+    lo = (uint4*)((char*)workspace + p.img_bytes);
+    inv = (float*)((char*)workspace + 2 * p.img_bytes);
+    unsigned int* rowmax = (unsigned int*)(inv + p.Rpad);
+    const int nseg = (2 * p.nsteps * 8 + SPLIT_SEG - 1) / SPLIT_SEG;
+    (void)hipMemsetAsync(rowmax, 0, (size_t)p.Rpad * sizeof(unsigned int), st);
+    hipLaunchKernelGGL(row_absmax_kernel, dim3(R, (L + SPLIT_SEG - 1) / SPLIT_SEG), dim3(256), 0, st, X, R, L, rowmax);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(p.Rpad, std::max(1, nseg)), dim3(256), 0, st, X, R, L, p.Rpad,
+                       neg_odd, rowmax, hi, lo, inv);
+}
+
+static size_t split_ws_bytes(const SplitPlan& p)
+{
+    return 2 * p.img_bytes + (size_t)p.Rpad * (sizeof(float) + sizeof(unsigned int));
 }
 
 } // namespace rime
@@ -575,7 +628,7 @@ extern "C" size_t rime_alm2pix_fwd_workspace(int dtype, int R, int Ncoeff, int N
 {
     if (dtype != RIME_F32 || R <= 0 || Ncoeff <= 0) return 0;
     const SplitPlan p = split_plan(R, 2 * Ncoeff, Ncoeff, false);
-    return 2 * p.img_bytes + (size_t)p.Rpad * sizeof(float);
+    return split_ws_bytes(p);
 }
 
 extern "C" int rime_alm2pix_fwd(int dtype, const void* alm, const void* Ylm, double y_scale, int R, int Ncoeff,
@@ -585,12 +638,9 @@ extern "C" int rime_alm2pix_fwd(int dtype, const void* alm, const void* Ylm, dou
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == RIME_F32 && y_scale > 0) {
         const SplitPlan p = split_plan(R, 2 * Ncoeff, Ncoeff, false);
-        if (!workspace || workspace_bytes < 2 * p.img_bytes + (size_t)p.Rpad * sizeof(float)) return RIME_EWORKSPACE;
-        uint4* hi = (uint4*)workspace;
-        uint4* lo = (uint4*)((char*)workspace + p.img_bytes);
-        float* inv = (float*)((char*)workspace + 2 * p.img_bytes);
-        hipLaunchKernelGGL(split_rows_kernel, dim3(p.Rpad), dim3(256), 0, st, (const float*)alm, R, 2 * Ncoeff,
-                           p.Rpad, 1, hi, lo, inv);
+        if (!workspace || workspace_bytes < split_ws_bytes(p)) return RIME_EWORKSPACE;
+        uint4 *hi, *lo; float* inv;
+        launch_split_rows((const float*)alm, R, 2 * Ncoeff, p, 1, workspace, st, hi, lo, inv);
         dim3 grid((Npix + 127) / 128, p.Rpad / (p.MT * 32));
         const float ys = (float)y_scale;
         const float* Y = (const float*)Ylm; float* o = (float*)out;
@@ -620,7 +670,7 @@ extern "C" size_t rime_alm2pix_bwd_workspace(int dtype, int R, int Ncoeff, int N
     const int S0 = bwd_splits(R, Ncoeff, Npix);
     const size_t exact = S0 <= 1 ? 0 : (size_t)S0 * R * Ncoeff * 2 * sizeof(float);
     const SplitPlan p = split_plan(R, Npix, Ncoeff, true);
-    const size_t fast = 2 * p.img_bytes + (size_t)p.Rpad * sizeof(float) + (size_t)p.S * R * Ncoeff * 2 * sizeof(float);
+    const size_t fast = split_ws_bytes(p) + (size_t)p.S * R * Ncoeff * 2 * sizeof(float);
     return std::max(exact, fast);
 }
 
@@ -633,20 +683,17 @@ extern "C" int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, do
     if (dtype == RIME_F32 && y_scale > 0) {
         const SplitPlan p = split_plan(R, Npix, Ncoeff, true);
         const size_t len = (size_t)R * Ncoeff * 2;
-        const size_t need = 2 * p.img_bytes + (size_t)p.Rpad * sizeof(float) + (size_t)p.S * len * sizeof(float);
+        const size_t need = split_ws_bytes(p) + (size_t)p.S * len * sizeof(float);
         if (!workspace || workspace_bytes < need) return RIME_EWORKSPACE;
-        uint4* hi = (uint4*)workspace;
-        uint4* lo = (uint4*)((char*)workspace + p.img_bytes);
-        float* inv = (float*)((char*)workspace + 2 * p.img_bytes);
-        float* part = p.S > 1 ? inv + p.Rpad : (float*)galm;
-        hipLaunchKernelGGL(split_rows_kernel, dim3(p.Rpad), dim3(256), 0, st, (const float*)gout, R, Npix,
-                           p.Rpad, 0, hi, lo, inv);
-        dim3 grid((Ncoeff + 127) / 128, p.S, p.Rpad / (p.MT * 32));
+        uint4 *hi, *lo; float* inv;
+        launch_split_rows((const float*)gout, R, Npix, p, 0, workspace, st, hi, lo, inv);
+        float* part = p.S > 1 ? (float*)((char*)workspace + split_ws_bytes(p)) : (float*)galm;
+        dim3 grid(p.S, (Ncoeff + 127) / 128, p.Rpad / (p.MT * 32));
         const float ys = (float)y_scale;
         const float* Y = (const float*)Ylm;
-        if (p.MT == 4) hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<4>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.steps_per_split, part);
-        else if (p.MT == 2) hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<2>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.steps_per_split, part);
-        else hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<1>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.steps_per_split, part);
+        if (p.MT == 4) hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<4>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.S, part);
+        else if (p.MT == 2) hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<2>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.S, part);
+        else hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<1>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.S, part);
         if (p.S > 1) {
             int nb = (int)std::min<size_t>((len + 255) / 256, 2048);
             hipLaunchKernelGGL(alm_reduce_kernel, dim3(nb), dim3(256), 0, st, part, (float*)galm, len, p.S);

@@ -188,7 +188,11 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
     shape = (Nbl, Nt, Nf, geom.Pstride, st_t, st_f, m, geom.sign)
     if not backward:
         # inp: psky (Nt, 1, Npp, Nf, Ps[, 2]) float32 view; out: vis (Npp, Nbl, Nt, Nf, 2) float32
-        amax = inp.abs().amax(dim=(-1, -2) if cplx else -1)                       # (Nt, 1, Npp, Nf)
+        if cplx:
+            amax = inp.abs().amax(dim=(-1, -2))                                    # (Nt, 1, Npp, Nf)
+        else:
+            lo, hi = torch.aminmax(inp, dim=-1)                                    # one pass, no |psky| temporary
+            amax = torch.maximum(hi, -lo)
         scale = _pow2_scale(amax.reshape(Nt, Npp, Nf).permute(1, 0, 2)).contiguous()
         nbytes = lib.rime_fringe_ant_workspace(Nbl, Nt, Nf, geom.Pstride)
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
