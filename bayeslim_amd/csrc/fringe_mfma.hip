@@ -30,7 +30,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int MF_NA = 128;                   // antennas per block (4 x 4 tiles)
-constexpr int MF_SPLIT_PIX = 8192;           // pixels per block (bounds the f32 MFMA accumulation chain)
+#ifndef RIME_MF_SPLIT_PIX
+#define RIME_MF_SPLIT_PIX 8192
+#endif
+constexpr int MF_SPLIT_PIX = RIME_MF_SPLIT_PIX;           // pixels per block (bounds the f32 MFMA accumulation chain)
 
 struct AntArgs {
     const double* antpos;      // [Nant, 3]

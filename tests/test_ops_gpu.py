@@ -278,6 +278,45 @@ def test_fringe_sum_matrix_core_antenna_groups(ops, Nant, frac, Npp):
     assert relmax(x.grad[..., :P], ref_in.grad) < 1e-4
 
 
+def test_fringe_sum_full_size_properties(ops):
+    """BASELINE config 4 at full size (128 antennas / 8128 baselines, 256 channels, 98 304 visible
+    pixels): size-independent properties instead of an oracle -- linearity, the adjoint identity
+    Re<V(x), G> == <x, V^T(G)> between the forward and backward kernels, and agreement of the
+    antenna-factored (matrix-core) and baseline-formulation (vector-ALU) kernels"""
+    rng = np.random.default_rng(0)
+    Nant, Nf, P = 128, 256, 98304
+    ant = rng.normal(0, 80.0, (Nant, 3)); ant[:, 2] *= 0.02
+    pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
+    blvecs = T64(np.stack([ant[b] - ant[a] for a, b in pairs])).cuda()
+    cz, az = rng.uniform(0, 1, P), rng.uniform(0, 2 * np.pi, P)
+    sz = np.sqrt(1 - cz ** 2)
+    sdir = T64(np.stack([sz * np.sin(az), sz * np.cos(az), cz])[None]).cuda()
+    freqs = torch.linspace(120e6, 180e6, Nf, dtype=torch.float64)
+    gm = ops.FringeGeometry(blvecs, sdir, freqs, antpos=T64(ant).cuda(), bl_ants=pairs)
+    gv = ops.FringeGeometry(blvecs, sdir, freqs, mfma=False)
+    assert gm.ant is not None and gv.ant is None
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    env = torch.exp(-9.0 * torch.rand(1, 1, 1, Nf, P, device='cuda', generator=gen))
+    x1 = torch.randn(1, 1, 1, Nf, P, device='cuda', generator=gen) * env
+    x2 = torch.randn(1, 1, 1, Nf, P, device='cuda', generator=gen) * env
+    v1, v2 = ops.fringe_sum(x1, gm), ops.fringe_sum(x2, gm)
+    scale = float(v1.abs().max())
+    # linearity
+    v12 = ops.fringe_sum(0.75 * x1 - 1.5 * x2, gm)
+    assert float((v12 - (0.75 * v1 - 1.5 * v2)).abs().max()) < 2e-5 * scale
+    # matrix-core vs vector-ALU kernels
+    assert float((v1 - ops.fringe_sum(x1, gv)).abs().max()) < 1e-5 * scale
+    # adjoint identity, both kernel families
+    G = torch.randn(v1.shape, device='cuda', generator=gen) + 1j * torch.randn(v1.shape, device='cuda', generator=gen)
+    for geom in (gm, gv):
+        x = x1.clone().requires_grad_(True)
+        v = ops.fringe_sum(x, geom)
+        lhs = (v.detach() * G.conj()).real.double().sum()
+        (v * G.conj()).real.sum().backward()
+        rhs = (x.grad.double() * x1.double()).sum()
+        assert abs(float(lhs - rhs)) < 1e-4 * abs(float(lhs)) + 1e-6
+
+
 def test_fringe_sum_matrix_core_splits_and_degenerate_rows(ops):
     """MFMA path with several pixel splits (partial slabs + transposing reduction), an all-zero
     psky row (power-of-two scale of an empty row), an all-negative row (sign masks on every
