@@ -434,22 +434,25 @@ def interp_gather(m, stencil, out_stride=None):
 
 
 # ---------------------------------------------------------------------------------------
-_YSCALE_CACHE = {}
 ALM_SPLIT_F16 = True        # float32: f16 hi/lo split operands on the f16 matrix cores (22 bits) instead
                             # of the exact-f32 MFMA kernels (set False to force those)
 
 
 def _ylm_scale(Y):
-    """power of two bringing max|Ylm| to [2^10, 2^11] (cached per tensor: Ylm matrices are reused
-    every forward and a max over C3's 3 GB matrix costs as much as the transform itself)"""
-    key = (Y.data_ptr(), tuple(Y.shape), Y._version)
-    s = _YSCALE_CACHE.get(key)
-    if s is None:
-        amax = float(Y.abs().amax().item())
-        s = float(2.0 ** np.floor(np.log2(2048.0 / amax))) if amax > 0 and np.isfinite(amax) else 1.0
-        if len(_YSCALE_CACHE) > 64:
-            _YSCALE_CACHE.clear()
-        _YSCALE_CACHE[key] = s
+    """
+    power of two bringing max|Ylm| to [2^10, 2^11].  Ylm matrices are reused every forward and a max
+    over C3's 3 GB matrix costs as much as the transform itself, so the value is remembered ON the
+    tensor object (with its version counter): a different tensor, or an in-place update, recomputes.
+    """
+    tag = getattr(Y, '_rime_yscale', None)
+    if tag is not None and tag[0] == Y._version:
+        return tag[1]
+    amax = float(Y.detach().abs().amax().item())
+    s = float(2.0 ** np.floor(np.log2(2048.0 / amax))) if amax > 0 and np.isfinite(amax) else 1.0
+    try:
+        Y._rime_yscale = (Y._version, s)
+    except Exception:
+        pass
     return s
 
 
@@ -467,7 +470,7 @@ class _Alm2Pix(torch.autograd.Function):
         assert Y.dtype == a.dtype, 'alm %s vs Ylm %s' % (a.dtype, Y.dtype)
         R = int(np.prod(lead)) if len(lead) else 1
         out = torch.empty(lead + (Npix,), dtype=rdt, device=a.device)
-        ys = _ylm_scale(Y) if (rdt == torch.float32 and ALM_SPLIT_F16) else 0.0
+        ys = _ylm_scale(Ylm) if (rdt == torch.float32 and ALM_SPLIT_F16) else 0.0
         nbytes = lib.rime_alm2pix_fwd_workspace(code, R, Nc, Npix) if ys > 0 else 0
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=a.device)
         rc = lib.rime_alm2pix_fwd(code, _ptr(torch.view_as_real(a)), _ptr(torch.view_as_real(Y)), ys,

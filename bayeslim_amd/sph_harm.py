@@ -149,10 +149,24 @@ class AlmModel:
         if torch.is_complex(Ylm) and torch.is_complex(params) and self.real_output:
             if not params.is_cuda:
                 raise RuntimeError('AlmModel.forward_alm needs GPU tensors (no CPU path)')
-            return ops.alm2pix(params, Ylm.to(params.dtype))
+            return ops.alm2pix(params, self._cast_Ylm(Ylm, params.dtype))
         # real Ylm (built with real=True) or complex output requested: plain GEMM (hipBLASLt)
         out = torch.einsum('...i,ij->...j', params, Ylm.to(params.dtype))
         return out.real if (self.real_output and torch.is_complex(out)) else out
+
+    def _cast_Ylm(self, Ylm, dtype):
+        """Ylm in the parameters' dtype, converted once per Ylm object (a complex128 matrix used with
+        complex64 parameters would otherwise be re-cast -- 3.3 GB at C3 -- on every forward)"""
+        if Ylm.dtype == dtype:
+            return Ylm
+        cache = self.__dict__.setdefault('_Ylm_cast_cache', {})
+        ent = cache.get(id(Ylm))
+        if ent is None or ent[0] is not Ylm or ent[1] != Ylm._version or ent[2].dtype != dtype:
+            if len(cache) > 8:
+                cache.clear()
+            ent = (Ylm, Ylm._version, Ylm.to(dtype))
+            cache[id(Ylm)] = ent
+        return ent[2]
 
     @staticmethod
     def setup_angs(theta, phi, separable):
@@ -211,5 +225,6 @@ class AlmModel:
         if getattr(self, 'alm_mult', None) is not None:
             self.alm_mult = utils.push(self.alm_mult, device)
         self._inflated_key = None
+        self.__dict__.pop('_Ylm_cast_cache', None)
         if self.LM is not None:
             self.LM.push(device)
