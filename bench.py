@@ -198,15 +198,35 @@ def all_baselines(inp):
 # ---------------------------------------------------------------------------------------------
 # CPU baseline: the oracle restatement of the reference path on a bounded sample
 # ---------------------------------------------------------------------------------------------
-def cpu_baseline(inp, nbl_sample=16, bl_batch=8):
+def usable_cpus():
+    """host cores this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (a GPU box exposes 256 logical CPUs in the mask but grants a 16-CPU quota)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+
+def cpu_baseline(inp, nbl_sample=48, bl_batch=8):
     """
     forward + backward of the oracle (op for op the reference's per-time loop: FoV cut ->
     interpolated beam -> beam x sky -> (Nbl,Nf,P) fringe -> product -> pixel sum) in float32 on
-    all host cores, for the first `nbl_sample` baselines x 1 time step of the SAME workload
+    the usable host cores, for the first `nbl_sample` baselines x 1 time step of the SAME workload
     (diffuse component), minibatched over baselines as the reference must be to fit host RAM.
     """
     from oracle import rime_oracle as orc
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    ncores = usable_cpus()
     torch.set_num_threads(ncores)
     f32 = torch.float32
     freqs = torch.as_tensor(inp['freqs'], dtype=f32)
