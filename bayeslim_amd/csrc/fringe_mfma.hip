@@ -67,6 +67,19 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
     lo = pack_rtz(ra, rb);
 }
 
+// the same split for values that are not products: the residual a - hi is one mixed-precision FMA
+// (a * 1.0 - hi, the f16 half read in place) instead of v_cvt_f32_f16 + v_sub_f32 -- the compiler
+// only forms v_fma_mix when there is a multiply to fuse
+__device__ __forceinline__ void split2_plain(float a, float b, uint32_t& hi, uint32_t& lo)
+{
+    auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    hi = __builtin_bit_cast(uint32_t, h);
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(hi));
+    lo = pack_rtz(ra, rb);
+}
+
 __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_cast(f16x8, v); }
 
 // (Lr, Li) -> (-Li, Lr) for each of the four packed pairs: left operand of the imaginary part
@@ -471,8 +484,8 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        split2(ec[8 * ks + 2 * q], ec[8 * ks + 2 * q + 1], erh[q], erl[q]);
-                        split2(es[8 * ks + 2 * q], es[8 * ks + 2 * q + 1], eih[q], eil[q]);
+                        split2_plain(ec[8 * ks + 2 * q], ec[8 * ks + 2 * q + 1], erh[q], erl[q]);
+                        split2_plain(es[8 * ks + 2 * q], es[8 * ks + 2 * q + 1], eih[q], eil[q]);
                     }
 #pragma unroll
                     for (int ti = 0; ti < 4; ++ti) {
@@ -601,8 +614,8 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    split2(ec[2 * q], ec[2 * q + 1], erh[q], erl[q]);
-                    split2(es[2 * q], es[2 * q + 1], eih[q], eil[q]);
+                    split2_plain(ec[2 * q], ec[2 * q + 1], erh[q], erl[q]);
+                    split2_plain(es[2 * q], es[2 * q + 1], eih[q], eil[q]);
                 }
                 Nrh = make_uint4(Erh.x ^ 0x80008000u, Erh.y ^ 0x80008000u, Erh.z ^ 0x80008000u, Erh.w ^ 0x80008000u);
                 Nrl = make_uint4(Erl.x ^ 0x80008000u, Erl.y ^ 0x80008000u, Erl.z ^ 0x80008000u, Erl.w ^ 0x80008000u);
