@@ -115,8 +115,11 @@ __device__ __forceinline__ uint4 rot90(const uint4& v)
 //   * LDS images are double buffered, one barrier per 32-pixel panel (two K steps): 16-pixel
 //     panels are 7 % slower (barrier + first-fragment latency per MFMA burst);
 //   * tried and dropped: v_fma_mixlo/hi_f16 for the split (fewer instructions, but a serial
-//     dependency through the half-register writes: 2 % slower); the f64 "magic number" range
-//     reduction (1 % faster, 4 % more phase noise).
+//     dependency through the half-register writes: 2 % slower); v_pk_mul_f32 for the weight
+//     products (packed f32 costs two issue slots: 2 % slower); the f64 "magic number" range
+//     reduction (1 % faster, 4 % more phase noise); a per-K-step unit deal for <= 64 antennas (no
+//     gain: those shapes are bound by operand generation); > 8192 pixels per split (slower tail,
+//     3x the f32 accumulation error); a uniform branch that skips the sign masks (spills).
 // Every block covers at most MF_SPLIT_PIX pixels and STORES its result (no read-modify-write):
 // f32 accumulation inside the MFMA chain stays below eps*sqrt(512), and the pixel splits are
 // summed (and transposed into the result layout) by reduce_vis_kernel in a fixed order.
