@@ -53,6 +53,7 @@ struct FringeArgs {
     int bl_off, bl_cnt, mp;
     int Nbl, Nt, Nf, Pstride, Nmp;
     int S, tiles_per_split;
+    int nbx;                   // blocks per (time, split): blockIdx.x = (t * S + split) * nbx + bx (grid.z is capped at 65535)
     long long st_t, st_mp, st_pp, st_f;   // psky / gpsky strides [elements] of (time, model pair, pol product, channel)
     double sign;
     double freq0_c, dfreq_c;      // freq0 / c, dfreq / c   [turns per metre]
@@ -192,12 +193,13 @@ fringe_fwd_kernel(FringeArgs A)
     T* a_lds = reinterpret_cast<T*>(f_lds + CH);                                // [TP][ASTRIDE]
 
     const int tid = threadIdx.x;
-    const int slot = blockIdx.x * blockDim.x + tid;
+    const int bxi = blockIdx.x % A.nbx, tsi = blockIdx.x / A.nbx;
+    const int slot = bxi * blockDim.x + tid;
     const bool active = slot < A.bl_cnt;
     const int b = active ? (A.bl_order ? A.bl_order[A.bl_off + slot] : A.bl_off + slot) : 0;
     const int k0 = blockIdx.y * CH;
-    const int t = blockIdx.z / A.S;
-    const int split = blockIdx.z % A.S;
+    const int t = tsi / A.S;
+    const int split = tsi % A.S;
     const int nk = min(CH, A.Nf - k0);
 
     const double bx = A.sign * A.blvecs[3 * b + 0];
@@ -319,9 +321,10 @@ fringe_bwd_kernel(FringeArgs A)
     T* g_lds = reinterpret_cast<T*>(f_lds + CH);                                // [TB][GSTRIDE]
 
     const int tid = threadIdx.x;
+    const int bxi = blockIdx.x % A.nbx, tsi = blockIdx.x / A.nbx;
     const int k0 = blockIdx.y * CH;
-    const int t = blockIdx.z / A.S;
-    const int split = blockIdx.z % A.S;
+    const int t = tsi / A.S;
+    const int split = tsi % A.S;
     const int nk = min(CH, A.Nf - k0);
     const double nu_c = A.freq0_c + (double)(k0 + CH / 2) * A.dfreq_c;
     const double dnu = A.dfreq_c;
@@ -341,7 +344,7 @@ fringe_bwd_kernel(FringeArgs A)
     const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
 #pragma unroll
     for (int j = 0; j < PIX; ++j) {
-        p[j] = (blockIdx.x * PIX + j) * blockDim.x + tid;
+        p[j] = (bxi * PIX + j) * blockDim.x + tid;
         const int pc = min(p[j], A.Pstride - 1);
         sx[j] = sd[pc]; sy[j] = sd[A.Pstride + pc]; sz[j] = sd[2 * (size_t)A.Pstride + pc];
     }
@@ -456,8 +459,9 @@ gen_fringe_kernel(const double* __restrict__ blvecs, const double* __restrict__ 
                   const double* __restrict__ freqs, int Nbl, int Nf, int P, int sstride, double sign,
                   T* __restrict__ out)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
+    const int npb = (P + blockDim.x - 1) / blockDim.x;           // grid.x = Nbl * npb (grid.y is capped at 65535)
+    const int p = (blockIdx.x % npb) * blockDim.x + threadIdx.x;
+    const int b = blockIdx.x / npb;
     if (p >= P) return;
     const double tau = sign * (blvecs[3 * b] * sdir[p] + blvecs[3 * b + 1] * sdir[sstride + p]
                                + blvecs[3 * b + 2] * sdir[2 * (size_t)sstride + p]);
@@ -571,7 +575,8 @@ static int launch_fwd_t(const FringeArgs& base, const int* mp_off, int mode, hip
         if (A.bl_cnt <= 0) continue;
         A.S = pl.S; A.tiles_per_split = pl.tiles_per_split;
         const int block = A.bl_cnt >= 256 ? 256 : ((A.bl_cnt + 63) / 64) * 64;
-        dim3 grid((A.bl_cnt + block - 1) / block, (A.Nf + CH - 1) / CH, A.Nt * A.S);
+        A.nbx = (A.bl_cnt + block - 1) / block;
+        dim3 grid((unsigned)A.nbx * A.Nt * A.S, (A.Nf + CH - 1) / CH, 1);
         size_t lds = (3 * TP + CH) * sizeof(double) + (size_t)TP * G::ASTRIDE * sizeof(T);
 #define RIME_FWD(M) hipLaunchKernelGGL((fringe_fwd_kernel<T, NPP, CPLX, CH, M>), grid, dim3(block), lds, st, A)
         if constexpr (sizeof(T) == 4) {
@@ -615,7 +620,8 @@ static int launch_bwd_t(const FringeArgs& base, const int* mp_off, int mode, hip
         A.S = pl.S < 1 ? 1 : pl.S; A.tiles_per_split = pl.tiles_per_split;
         const size_t plane = (size_t)NPP * A.Nf * A.Pstride * G::NC;
         if (A.S > 1 && ws_bytes < (size_t)A.S * A.Nt * plane * sizeof(T)) return RIME_EWORKSPACE;
-        dim3 grid((A.Pstride + pl.block * PIX - 1) / (pl.block * PIX), (A.Nf + CH - 1) / CH, A.Nt * A.S);
+        A.nbx = (A.Pstride + pl.block * PIX - 1) / (pl.block * PIX);
+        dim3 grid((unsigned)A.nbx * A.Nt * A.S, (A.Nf + CH - 1) / CH, 1);
         size_t lds = (3 * TB + CH) * sizeof(double) + (size_t)TB * G::GSTRIDE * sizeof(T);
         // 4 waves/SIMD (<=128 VGPRs, a few spilled dwords) beat 3 at 136 VGPRs: 66.4 vs 71.9 ms (lab)
         constexpr int WPS = (sizeof(T) == 4 && NPP * (CPLX ? 2 : 1) * CH <= 32) ? 4 : 1;
@@ -769,7 +775,7 @@ extern "C" int rime_gen_fringe(int dtype, const double* blvecs, const double* sd
     if (!blvecs || !sdir || !freqs || !out) return RIME_EINVAL;
     if (Nbl <= 0 || Nf <= 0 || P <= 0 || sdir_stride < P || (sign != 1 && sign != -1)) return RIME_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid((P + 255) / 256, Nbl), block(256);
+    dim3 grid((unsigned)((P + 255) / 256) * Nbl), block(256);
     if (dtype == RIME_F32)
         hipLaunchKernelGGL((gen_fringe_kernel<float>), grid, block, 0, st, blvecs, sdir, freqs, Nbl, Nf, P,
                            sdir_stride, (double)sign, reinterpret_cast<float*>(out));

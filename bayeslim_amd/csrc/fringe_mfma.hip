@@ -171,8 +171,10 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     constexpr int MF_IMG = SH::IMG, MF_BUF = SH::BUF;
     constexpr int BROW = SH::CROSS ? 4 : 0;          // image row-tile offset of the column (B) side
     const int tid = threadIdx.x, lane = tid & 63;
-    const int f = blockIdx.y;
-    const int t = blockIdx.z / A.S, split = blockIdx.z % A.S;
+    // 1-D grid, channel fastest: blocks that run together share (t, split), i.e. the same pointing
+    // vectors (L2 hits), and no grid dimension hits the 65535 cap
+    const int f = blockIdx.x % A.Nf, ts = blockIdx.x / A.Nf;
+    const int t = ts / A.S, split = ts % A.S;
 
     const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
     const float scl = A.scale[t * A.Nf + f];
@@ -407,8 +409,10 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
     double* ant_lds = reinterpret_cast<double*>(smem + 6 * MB_PLANE);      // [128][3]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int f = blockIdx.y;
-    const int t = blockIdx.z / A.S, split = blockIdx.z % A.S;
+    // 1-D grid, channel fastest: blocks that run together share (t, split), i.e. the same pointing
+    // vectors (L2 hits), and no grid dimension hits the 65535 cap
+    const int f = blockIdx.x % A.Nf, ts = blockIdx.x / A.Nf;
+    const int t = ts / A.S, split = ts % A.S;
     const int TA = (A.Nant + 31) / 32;
 
     const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
@@ -549,8 +553,10 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
     double* ant_lds = reinterpret_cast<double*>(smem + 4 * MX_PLANE);      // [256][3]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int f = blockIdx.y;
-    const int t = blockIdx.z / A.S, split = blockIdx.z % A.S;
+    // 1-D grid, channel fastest: blocks that run together share (t, split), i.e. the same pointing
+    // vectors (L2 hits), and no grid dimension hits the 65535 cap
+    const int f = blockIdx.x % A.Nf, ts = blockIdx.x / A.Nf;
+    const int t = ts / A.S, split = ts % A.S;
 
     const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
     for (int i = tid; i < 2 * MF_NA * 3; i += 512)
@@ -759,7 +765,7 @@ static bool ant_common_ok(int Nrows, int cross, int Nbl, int Nt, int Nf, int Pst
 {
     if (st_p != 1 && st_p != 2) return false;
     if (cross ? (Nrows != 2 * MF_NA) : (Nrows <= 0 || Nrows > MF_NA)) return false;
-    if (Nbl <= 0 || Nt <= 0 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0) return false;
+    if (Nbl <= 0 || Nt <= 0 || Nt > 65535 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0) return false;
     return sign == 1 || sign == -1;
 }
 
@@ -779,7 +785,7 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
     ant_split_plan(Nt, Nf, Pstride, A.S, A.panels_per_split);
     if (!workspace || workspace_bytes < rime_fringe_ant_workspace(Nbl, Nt, Nf, Pstride)) return RIME_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid(1, Nf, Nt * A.S);
+    dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
     if (cross) {
         hipLaunchKernelGGL(fringe_ant_fwd_cross_kernel, grid, dim3(512), (FwdShape<4, true>::LDS), st, A);
         return check_launch();
@@ -857,7 +863,7 @@ extern "C" int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cr
     A.tiles_per_split = per;
     A.S = (ntile + per - 1) / per;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid(1, Nf, Nt * A.S);
+    dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
     if (cross) hipLaunchKernelGGL(fringe_ant_bwd_cross_kernel, grid, dim3(512), MX_LDS, st, A);
     else hipLaunchKernelGGL(fringe_ant_bwd_kernel, grid, dim3(512), MB_LDS, st, A);
     return check_launch();

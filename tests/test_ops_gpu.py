@@ -365,6 +365,22 @@ def test_fringe_sum_split_paths(ops, dtype):
         assert relmax(x.grad[..., :P], ref_in.grad) < (1e-11 if dtype == 'f64' else 1e-4)
 
 
+def test_fringe_sum_many_time_steps(ops):
+    """more (time, split) blocks than a grid y/z dimension holds (65535): the launch geometry keeps
+    them on grid.x; every time step repeats the same inputs, so all must equal the oracle's single one"""
+    blvecs, freqs, zenaz, psky, bl_mp = make_case(3, Nbl=3, Nt=1, Nf=2, P=40, Nmp=1, Npp=1, cplx=False)
+    ref = oracle_fringe_sum(psky, blvecs, zenaz, freqs, bl_mp)                   # (1, Nbl, 1, Nf)
+    Nt = 66000
+    geom, Ps = to_gpu_geometry(ops, blvecs, freqs, zenaz.expand(Nt, -1, -1).contiguous(), bl_mp, 1)
+    x = pad_psky(psky, Ps).expand(Nt, -1, -1, -1, -1).contiguous().cuda()
+    vis = ops.fringe_sum(x, geom)
+    assert vis.shape == (1, 3, Nt, 2)
+    assert relmax(vis[:, :, :1], ref) < 1e-11
+    assert float((vis - vis[:, :, :1]).abs().max()) == 0.0
+    g = ops.gen_fringe(blvecs.cuda(), geom.sdir[0], freqs, dtype=torch.float64)
+    assert relmax(g[..., :40], orc.gen_fringe(blvecs, zenaz[0, 0], zenaz[0, 1], freqs)) < 1e-11
+
+
 def test_fringe_sum_golden_prod_and_sum(ops):
     g = load_golden('prod_and_sum')
     zenaz = T64(np.stack([g['zen'], g['az']]))[None]
