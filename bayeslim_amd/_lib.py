@@ -30,10 +30,10 @@ SIGNATURES = {
     'rime_fringe_sum_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _ip, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                  _i, _d, _d, _d, _llp, _vp, _vp, _sz, _vp]),
     'rime_fringe_ant_workspace': (_sz, [_i, _i, _i, _i]),
-    'rime_fringe_ant_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp, _vp, _sz, _vp]),
+    'rime_fringe_ant_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp, _vp, _sz, _vp]),
     'rime_fringe_ant_bwd_workspace': (_sz, [_i, _i, _i]),
     'rime_fringe_ant_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp, _vp, _sz, _vp]),
-    'rime_fringe_ant_fwd_block': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
+    'rime_fringe_ant_fwd_block': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
                                        _vp, _sz, _vp]),
     'rime_fringe_ant_fwd_finish': (_i, [_vp, _sz, _vp, _i, _i, _i, _i, _vp]),
     'rime_fringe_ant_bwd_prepare': (_i, [_vp, _i, _i, _i, _vp, _sz, _vp]),

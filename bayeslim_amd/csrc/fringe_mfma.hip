@@ -41,6 +41,7 @@ struct AntArgs {
     const double* freqs;       // [Nf]
     const float* psky;         // strided [t][f][p]
     const float* scale;        // [Nt, Nf] power-of-two pre-scale of psky rows
+    const float* rowmin;       // [Nt, Nf] min of each psky row, or NULL: rows with min >= 0 skip the sign masks
     const int* pair_direct;    // [128*128] baseline slot receiving V[i,j], or -1
     const int* pair_conj;      // [128*128] baseline slot receiving conj(V[i,j]), or -1
     float* vis;                // [Nbl, Nt, Nf, 2]
@@ -164,7 +165,7 @@ __device__ __forceinline__ void static_for(F&& f)
 
 #define RIME_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag(a), as_frag(b), c, 0, 0, 0)
 
-template <class SH, int W>
+template <class SH, int W, bool SIGNED>
 __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* smem)
 {
     constexpr int NU = SH::NU, UPW = SH::UPW, U0 = UPW * W;
@@ -220,7 +221,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
 #pragma unroll
         for (int hf = 0; hf < MF_NH; ++hf) {
             const float w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
-            if (tid < 8)
+            if (SIGNED && tid < 8)
                 *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
                     ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
 #pragma unroll
@@ -252,40 +253,42 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
         };
         auto sfrag = [&](int tile, int img, int im, int ks, const uint4& sg) {
             uint4 v = frag(tile, img, im, ks);
-            v.x ^= sg.x; v.y ^= sg.y; v.z ^= sg.z; v.w ^= sg.w;
+            if constexpr (SIGNED) { v.x ^= sg.x; v.y ^= sg.y; v.z ^= sg.z; v.w ^= sg.w; }
             return v;
         };
         constexpr int UE = (U0 + UPW < NU) ? U0 + UPW : NU;          // this wave's units: [U0, UE)
         constexpr int T0 = U0 >> 1, T1 = (UE + 1) >> 1;               // its tiles: [T0, T1)
-        uint4 Lrh[MF_NH], Lih[MF_NH], Lrl[MF_NH], Lil[MF_NH];         // sign-applied row-tile fragments
-        static_for<T0, T1>([&](auto tc) {
-            constexpr int tile = decltype(tc)::value;
-            constexpr bool hasR = 2 * tile >= U0, hasI = 2 * tile + 1 < UE;
-            constexpr int sR = hasR ? 2 * tile - U0 : 0, sI = hasI ? 2 * tile + 1 - U0 : 0;   // accumulator slots
-            constexpr int ti = tile_row<SH>(tile), tj = BROW + tile_col<SH>(tile);
+        // K step outermost: only one K step's row fragments are live at a time (16 registers fewer)
 #pragma unroll
-            for (int ks = 0; ks < MF_NH; ++ks) {
+        for (int ks = 0; ks < MF_NH; ++ks) {
+            uint4 Lrh, Lih, Lrl, Lil;                                 // sign-applied row-tile fragments
+            static_for<T0, T1>([&](auto tc) {
+                constexpr int tile = decltype(tc)::value;
+                constexpr bool hasR = 2 * tile >= U0, hasI = 2 * tile + 1 < UE;
+                constexpr int sR = hasR ? 2 * tile - U0 : 0, sI = hasI ? 2 * tile + 1 - U0 : 0;   // accumulator slots
+                constexpr int ti = tile_row<SH>(tile), tj = BROW + tile_col<SH>(tile);
                 if constexpr (tile == T0 || tile_row<SH>(tile > 0 ? tile - 1 : 0) != ti) {
-                    const uint4 sg = *reinterpret_cast<const uint4*>(buf + 2 * MF_IMG + (2 * ks + (lane >> 5)) * 16);
-                    Lrh[ks] = sfrag(ti, 0, 0, ks, sg); Lih[ks] = sfrag(ti, 0, 1, ks, sg);
-                    Lrl[ks] = sfrag(ti, 1, 0, ks, sg); Lil[ks] = sfrag(ti, 1, 1, ks, sg);
+                    uint4 sg = make_uint4(0, 0, 0, 0);
+                    if constexpr (SIGNED) sg = *reinterpret_cast<const uint4*>(buf + 2 * MF_IMG + (2 * ks + (lane >> 5)) * 16);
+                    Lrh = sfrag(ti, 0, 0, ks, sg); Lih = sfrag(ti, 0, 1, ks, sg);
+                    Lrl = sfrag(ti, 1, 0, ks, sg); Lil = sfrag(ti, 1, 1, ks, sg);
                 }
                 const uint4 Brh = frag(tj, 0, 0, ks), Bih = frag(tj, 0, 1, ks), Brl = frag(tj, 1, 0, ks), Bil = frag(tj, 1, 1, ks);
                 // real part Lr.Br + Li.Bi -> acc[sR][0]; imaginary part Lr.Bi -> acc[sI][0], Li.Br -> acc[sI][1]
-                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh[ks], Brh, acc[sR][0]);
-                if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh[ks], Bih, acc[sI][0]);
-                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih[ks], Bih, acc[sR][0]);
-                if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih[ks], Brh, acc[sI][1]);
-                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh[ks], Brl, acc[sR][0]);
-                if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh[ks], Bil, acc[sI][0]);
-                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih[ks], Bil, acc[sR][0]);
-                if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih[ks], Brl, acc[sI][1]);
-                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrl[ks], Brh, acc[sR][0]);
-                if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrl[ks], Bih, acc[sI][0]);
-                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lil[ks], Bih, acc[sR][0]);
-                if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lil[ks], Brh, acc[sI][1]);
-            }
-        });
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh, Brh, acc[sR][0]);
+                if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh, Bih, acc[sI][0]);
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih, Bih, acc[sR][0]);
+                if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih, Brh, acc[sI][1]);
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh, Brl, acc[sR][0]);
+                if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh, Bil, acc[sI][0]);
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih, Bil, acc[sR][0]);
+                if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih, Brl, acc[sI][1]);
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrl, Brh, acc[sR][0]);
+                if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrl, Bih, acc[sI][0]);
+                if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lil, Bih, acc[sR][0]);
+                if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lil, Brh, acc[sI][1]);
+            });
+        }
     };
     // two panels per trip: buffer addresses are compile-time offsets
     unsigned char* const buf0 = smem;
@@ -332,35 +335,47 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     }
 }
 
-template <int TA>
+// A block works on one psky row (t, f): rows without a negative value (beam-weighted emission is
+// non-negative) take the kernel instantiation without sign masks.  Both instantiations are launched
+// over the full grid and a block returns at once when its row belongs to the other one: a branch
+// inside one kernel costs registers (the allocator serves the union of both paths and spills).
+__device__ __forceinline__ bool row_is_signed(const AntArgs& A)
+{
+    if (!A.rowmin) return true;
+    const int f = blockIdx.x % A.Nf, t = (blockIdx.x / A.Nf) / A.S;
+    return A.rowmin[t * A.Nf + f] < 0.f;
+}
+
+template <class SH, bool SIGNED>
+__device__ __forceinline__ void ant_fwd_dispatch(const AntArgs& A, unsigned char* smem)
+{
+    if (row_is_signed(A) != SIGNED) return;          // uniform over the block
+    switch (threadIdx.x >> 6) {                      // wave-uniform: every wave runs the same barriers
+        case 0: ant_fwd_body<SH, 0, SIGNED>(A, smem); break;
+        case 1: ant_fwd_body<SH, 1, SIGNED>(A, smem); break;
+        case 2: ant_fwd_body<SH, 2, SIGNED>(A, smem); break;
+        case 3: ant_fwd_body<SH, 3, SIGNED>(A, smem); break;
+        case 4: if constexpr (SH::NW > 4) ant_fwd_body<SH, 4, SIGNED>(A, smem); break;
+        case 5: if constexpr (SH::NW > 4) ant_fwd_body<SH, 5, SIGNED>(A, smem); break;
+        case 6: if constexpr (SH::NW > 4) ant_fwd_body<SH, 6, SIGNED>(A, smem); break;
+        default: if constexpr (SH::NW > 4) ant_fwd_body<SH, 7, SIGNED>(A, smem); break;
+    }
+}
+
+template <int TA, bool SIGNED>
 __global__ void __launch_bounds__(256, 2)
 fringe_ant_fwd_kernel(AntArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    using SH = FwdShape<TA, false>;
-    switch (threadIdx.x >> 6) {                      // wave-uniform: every wave runs the same barriers
-        case 0: ant_fwd_body<SH, 0>(A, smem); break;
-        case 1: ant_fwd_body<SH, 1>(A, smem); break;
-        case 2: ant_fwd_body<SH, 2>(A, smem); break;
-        default: ant_fwd_body<SH, 3>(A, smem); break;
-    }
+    ant_fwd_dispatch<FwdShape<TA, false>, SIGNED>(A, smem);
 }
 
+template <bool SIGNED>
 __global__ void __launch_bounds__(512, 1)
 fringe_ant_fwd_cross_kernel(AntArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    using SH = FwdShape<4, true>;
-    switch (threadIdx.x >> 6) {
-        case 0: ant_fwd_body<SH, 0>(A, smem); break;
-        case 1: ant_fwd_body<SH, 1>(A, smem); break;
-        case 2: ant_fwd_body<SH, 2>(A, smem); break;
-        case 3: ant_fwd_body<SH, 3>(A, smem); break;
-        case 4: ant_fwd_body<SH, 4>(A, smem); break;
-        case 5: ant_fwd_body<SH, 5>(A, smem); break;
-        case 6: ant_fwd_body<SH, 6>(A, smem); break;
-        default: ant_fwd_body<SH, 7>(A, smem); break;
-    }
+    ant_fwd_dispatch<FwdShape<4, true>, SIGNED>(A, smem);
 }
 
 
@@ -771,14 +786,14 @@ static bool ant_common_ok(int Nrows, int cross, int Nbl, int Nt, int Nf, int Pst
 
 extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
                                          const double* freqs, const float* psky, const float* scale,
-                                         const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf,
+                                         const float* rowmin, const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf,
                                          int Pstride, long long st_t, long long st_f, long long st_p, int sign,
                                          void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!antpos || !sdir || !freqs || !psky || !scale || !pair_direct || !pair_conj) return RIME_EINVAL;
     if (!ant_common_ok(Nrows, cross, Nbl, Nt, Nf, Pstride, st_p, sign)) return RIME_EINVAL;
     AntArgs A{};
-    A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.psky = psky; A.scale = scale;
+    A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.psky = psky; A.scale = scale; A.rowmin = rowmin;
     A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.vis = nullptr; A.ws = (float*)workspace;
     A.Nant = Nrows; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
     A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign;
@@ -786,16 +801,22 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
     if (!workspace || workspace_bytes < rime_fringe_ant_workspace(Nbl, Nt, Nf, Pstride)) return RIME_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
+#define RIME_FWD_PAIR(KERNEL_T, KERNEL_F, THREADS, LDSB)                                   \
+    do {                                                                                   \
+        hipLaunchKernelGGL(KERNEL_T, grid, dim3(THREADS), LDSB, st, A);                    \
+        if (rowmin) hipLaunchKernelGGL(KERNEL_F, grid, dim3(THREADS), LDSB, st, A);        \
+    } while (0)
     if (cross) {
-        hipLaunchKernelGGL(fringe_ant_fwd_cross_kernel, grid, dim3(512), (FwdShape<4, true>::LDS), st, A);
+        RIME_FWD_PAIR((fringe_ant_fwd_cross_kernel<true>), (fringe_ant_fwd_cross_kernel<false>), 512, (FwdShape<4, true>::LDS));
         return check_launch();
     }
     switch ((Nrows + 31) / 32) {
-        case 1: hipLaunchKernelGGL((fringe_ant_fwd_kernel<1>), grid, dim3(256), (FwdShape<1, false>::LDS), st, A); break;
-        case 2: hipLaunchKernelGGL((fringe_ant_fwd_kernel<2>), grid, dim3(256), (FwdShape<2, false>::LDS), st, A); break;
-        case 3: hipLaunchKernelGGL((fringe_ant_fwd_kernel<3>), grid, dim3(256), (FwdShape<3, false>::LDS), st, A); break;
-        default: hipLaunchKernelGGL((fringe_ant_fwd_kernel<4>), grid, dim3(256), (FwdShape<4, false>::LDS), st, A); break;
+        case 1: RIME_FWD_PAIR((fringe_ant_fwd_kernel<1, true>), (fringe_ant_fwd_kernel<1, false>), 256, (FwdShape<1, false>::LDS)); break;
+        case 2: RIME_FWD_PAIR((fringe_ant_fwd_kernel<2, true>), (fringe_ant_fwd_kernel<2, false>), 256, (FwdShape<2, false>::LDS)); break;
+        case 3: RIME_FWD_PAIR((fringe_ant_fwd_kernel<3, true>), (fringe_ant_fwd_kernel<3, false>), 256, (FwdShape<3, false>::LDS)); break;
+        default: RIME_FWD_PAIR((fringe_ant_fwd_kernel<4, true>), (fringe_ant_fwd_kernel<4, false>), 256, (FwdShape<4, false>::LDS)); break;
     }
+#undef RIME_FWD_PAIR
     return check_launch();
 }
 
@@ -812,13 +833,14 @@ extern "C" int rime_fringe_ant_fwd_finish(const void* workspace, size_t workspac
 }
 
 extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, const double* freqs,
-                                   const float* psky, const float* scale, const int* pair_direct,
+                                   const float* psky, const float* scale, const float* rowmin,
+                                   const int* pair_direct,
                                    const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
                                    long long st_t, long long st_f, long long st_p, int sign, float* vis,
                                    void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!vis) return RIME_EINVAL;
-    const int rc = rime_fringe_ant_fwd_block(antpos, Nant, 0, sdir, freqs, psky, scale, pair_direct, pair_conj,
+    const int rc = rime_fringe_ant_fwd_block(antpos, Nant, 0, sdir, freqs, psky, scale, rowmin, pair_direct, pair_conj,
                                              Nbl, Nt, Nf, Pstride, st_t, st_f, st_p, sign, workspace,
                                              workspace_bytes, stream);
     if (rc != RIME_OK) return rc;

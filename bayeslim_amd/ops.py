@@ -190,9 +190,12 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
         # inp: psky (Nt, 1, Npp, Nf, Ps[, 2]) float32 view; out: vis (Npp, Nbl, Nt, Nf, 2) float32
         if cplx:
             amax = inp.abs().amax(dim=(-1, -2))                                    # (Nt, 1, Npp, Nf)
+            lo = inp.amin(dim=-2)                                                  # (Nt, 1, Npp, Nf, 2): per plane
+            rowmin = [lo[..., c].reshape(Nt, Npp, Nf).permute(1, 0, 2).contiguous() for c in range(2)]
         else:
             lo, hi = torch.aminmax(inp, dim=-1)                                    # one pass, no |psky| temporary
             amax = torch.maximum(hi, -lo)
+            rowmin = [lo.reshape(Nt, Npp, Nf).permute(1, 0, 2).contiguous()]
         scale = _pow2_scale(amax.reshape(Nt, Npp, Nf).permute(1, 0, 2)).contiguous()
         nbytes = lib.rime_fringe_ant_workspace(Nbl, Nt, Nf, geom.Pstride)
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
@@ -203,7 +206,8 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
                 src = ctypes.c_void_p(inp.data_ptr() + 4 * (pp * st_pp + c))
                 for blk in a['blocks']:
                     rc = lib.rime_fringe_ant_fwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], *geo, src,
-                                                       _ptr(scale[pp]), _ptr(blk['direct']), _ptr(blk['conj']),
+                                                       _ptr(scale[pp]), _ptr(rowmin[c][pp]),
+                                                       _ptr(blk['direct']), _ptr(blk['conj']),
                                                        *shape, _ptr(ws), ws.numel(), _stream())
                     check(rc, 'rime_fringe_ant_fwd_block')
                 rc = lib.rime_fringe_ant_fwd_finish(_ptr(ws), ws.numel(), _ptr(dst), Nbl, Nt, Nf, geom.Pstride,

@@ -113,6 +113,8 @@ int rime_fringe_sum_bwd(int dtype,
  *       separate calls (V is linear in psky: V[ar + i ai] = V[ar] + i V[ai])
  *   scale / gscale f32 [Nt, Nf]: power-of-two factors that bring max|psky[t,f,:]| (resp.
  *       max|gvis[:,t,f]|) to ~2^14 -- computed by the caller (a torch amax), exact to undo
+ *   rowmin f32 [Nt, Nf] or NULL (forward): min of each psky row; rows with min >= 0 run without the
+ *       per-pixel sign masks (NULL: every row is treated as signed)
  *   pair_direct / pair_conj int32 [128*128]: for antenna indices (i, j) with tile(i) <= tile(j)
  *       (tile = index / 32) the baseline slot that receives V[i,j] (pair stored as i -> j) and the
  *       slot that receives conj(V[i,j]) (pair stored as j -> i, only when tile(j) > tile(i)), or -1
@@ -121,7 +123,8 @@ int rime_fringe_sum_bwd(int dtype,
 size_t rime_fringe_ant_workspace(int Nbl, int Nt, int Nf, int Pstride);   /* forward: per-split result slabs */
 size_t rime_fringe_ant_bwd_workspace(int Nbl, int Nt, int Nf);              /* backward: transposed gvis */
 int rime_fringe_ant_fwd(const double* antpos, const double* sdir, const double* freqs,
-                        const float* psky, const float* scale, const int* pair_direct,
+                        const float* psky, const float* scale, const float* rowmin,
+                        const int* pair_direct,
                         const int* pair_conj, int Nant, int Nbl, int Nt, int Nf, int Pstride,
                         long long st_t, long long st_f, long long st_p, int sign, float* vis,
                         void* workspace, size_t workspace_bytes, void* stream);
@@ -144,7 +147,7 @@ int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* 
  * pass accumulate = 1 (stream order makes the sum deterministic). */
 int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
                               const double* freqs, const float* psky, const float* scale,
-                              const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf,
+                              const float* rowmin, const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf,
                               int Pstride, long long st_t, long long st_f, long long st_p, int sign,
                               void* workspace, size_t workspace_bytes, void* stream);
 int rime_fringe_ant_fwd_finish(const void* workspace, size_t workspace_bytes, float* vis,

@@ -73,6 +73,12 @@ int main(int argc, char** argv)
     CHK(hipMemcpy(dpd, pd.data(), pd.size() * 4, hipMemcpyHostToDevice));
     CHK(hipMemcpy(dpc, pc.data(), pc.size() * 4, hipMemcpyHostToDevice));
     CHK(hipMemset(dv2, 0, nvis * 4));
+    float* drm = nullptr;                     // per-row minimum of psky (rows without negatives skip the sign masks)
+    {
+        std::vector<float> rm((size_t)Nt * Nf);
+        for (int tf = 0; tf < Nt * Nf; ++tf) { float m = 0; for (int p = 0; p < P; ++p) m = fminf(m, ps[(size_t)tf * P + p]); rm[tf] = m; }
+        CHK(hipMalloc(&drm, rm.size() * 4)); CHK(hipMemcpy(drm, rm.data(), rm.size() * 4, hipMemcpyHostToDevice));
+    }
 
     int off[2] = {0, Nbl};
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
@@ -88,7 +94,7 @@ int main(int argc, char** argv)
     float ms2min = 1e9f;
     for (int r = 0; r < 6; ++r) {
         CHK(hipEventRecord(e0));
-        int rc = rime_fringe_ant_fwd(dant, dsd, dfr, dps, dsc, dpd, dpc, Nant, Nbl, Nt, Nf, P,
+        int rc = rime_fringe_ant_fwd(dant, dsd, dfr, dps, dsc, drm, dpd, dpc, Nant, Nbl, Nt, Nf, P,
                                      (long long)Nf * P, (long long)P, 1LL, 1, dv2, dws, wsb, 0);
         CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
         if (rc) { printf("mfma rc=%d (%s)\n", rc, rime_last_error()); return 1; }
