@@ -297,16 +297,28 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     for (int hf = 0; hf < MF_NH; ++hf) fetch(pbeg, hf);
     generate(buf0, min(pbeg + 1, pend - 1));
     __syncthreads();
+#if defined(RIME_ABL_NOGEN)        /* lab ablations (tools/fringe_mfma_lab.hip): never defined in the library build */
+#define RIME_GEN(b, n) do { if (panel < pbeg + 2) generate(b, n); } while (0)
+#else
+#define RIME_GEN(b, n) generate(b, n)
+#endif
+#if defined(RIME_ABL_NOMFMA)
+#define RIME_CON(b) do { const uint4 q = *reinterpret_cast<const uint4*>(b + foff); acc[0][0][0] += __uint_as_float(q.x ^ q.y ^ q.z ^ q.w); } while (0)
+#else
+#define RIME_CON(b) contract(b)
+#endif
     for (int panel = pbeg; panel < pend; panel += 2) {
-        if (panel + 1 < pend) generate(buf1, min(panel + 2, pend - 1));
-        contract(buf0);
+        if (panel + 1 < pend) RIME_GEN(buf1, min(panel + 2, pend - 1));
+        RIME_CON(buf0);
         __syncthreads();
         if (panel + 1 < pend) {
-            if (panel + 2 < pend) generate(buf0, min(panel + 3, pend - 1));
-            contract(buf1);
+            if (panel + 2 < pend) RIME_GEN(buf0, min(panel + 3, pend - 1));
+            RIME_CON(buf1);
         }
         __syncthreads();
     }
+#undef RIME_GEN
+#undef RIME_CON
 
     // epilogue: V[i,j] / scale -> the baseline slot(s) of pair (i,j) of this block's slab
     // ws[split][t][f][re|im][Nbl]: consecutive lanes (columns j) hit consecutive baseline slots, so
