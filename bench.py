@@ -58,6 +58,12 @@ def hera_array(kind):
         ants, vecs = utils._make_hex(3, D=14.6)
     elif kind == 'hera37':
         ants, vecs = utils._make_hex(4, D=14.6)
+    elif kind == 'ska512':
+        # SKA-Low-like core: 512 stations, random within a 500 m radius disc (seeded), nearly coplanar
+        rng = np.random.default_rng(512)
+        r, ph = 500.0 * np.sqrt(rng.uniform(0, 1, 512)), rng.uniform(0, 2 * np.pi, 512)
+        vecs = np.stack([r * np.cos(ph), r * np.sin(ph), rng.normal(0, 0.5, 512)], axis=1)
+        ants = list(range(512))
     else:
         raise ValueError(kind)
     return ants, vecs
@@ -69,6 +75,8 @@ WORKLOADS = {
                desc='HERA-128 (8128 bl), nside=128 diffuse + 1e4 point sources, 256 freqs'),
     'c2': dict(array='hera19', nside=32, Nf=64, Npt=0, nt=30,
                desc='HERA-19 hex (171 bl), nside=32 diffuse sky, 64 freqs, 30 times'),
+    'c5': dict(array='ska512', nside=256, Nf=512, Npt=0, nt=1, pol=4,
+               desc='SKA-Low-like 512 stations (130816 bl), full-pol 2x2 Jones PixelBeam, nside=256 coherency sky, 512 freqs'),
     'c3': dict(array='hera37', nside=64, Nf=128, Npt=0, nt=60, lmax=128,
                desc='HERA-37 (666 bl), a_lm sky lmax=128 on nside=64 via sph_harm + PixelBeam interp, 128 freqs, 60 times'),
 }
@@ -165,16 +173,40 @@ def build_model(inp, dev, bls, seed=0, fblock=None):
         for t, za in zip(inp['times'], inp['pt_zenaz']):
             tel.conv_cache[('points', cfg['Npt'], float(t))] = torch.as_tensor(za)
     sky = sky_model.CompositeModel(models) if len(models) > 1 else diffuse
+    if cfg.get('pol') == 4:
+        # Stokes I map + fixed fractional Q, U, V -> (2, 2) coherency sky (complex): sky_model.Stokes2Coherency
+        frac = torch.tensor([0.05, -0.03, 0.01], dtype=f32, device=dev).reshape(3, 1, 1, 1)
+        s2c = sky_model.Stokes2Coherency(params=frac)
+
+        class CohSky(utils.Module):
+            def __init__(self):
+                super().__init__(name='cohsky')
+                self.sky, self.s2c, self.device = diffuse, s2c, diffuse.device
+
+            def forward(self, prior_cache=None, **kw):
+                return self.s2c(self.sky(prior_cache=prior_cache))
+
+        sky = CohSky()
     tg = torch.as_tensor(inp['theta_grid'], device=dev)
     pg = torch.as_tensor(inp['phi_grid'], device=dev)
     b_phi, b_theta = torch.meshgrid(pg, tg, indexing='xy')
     airy = beam_model.airy_disk(b_theta.ravel() * utils.D2R, b_phi.ravel() * utils.D2R, 14.0,
                                 freqs_full.double(), square=True).to(f32)
-    beamp = torch.nn.Parameter(airy[None, None, None].contiguous())
-    R = beam_model.PixelResponse(freqs, 'rect', interp_mode='linear', theta_grid=tg, phi_grid=pg,
-                                 freq_mode='channel', powerbeam=True, device=dev)
-    beam = beam_model.PixelBeam(beamp.detach()[..., f0:f1, :], freqs, R=R, pol='e', powerbeam=True,
-                                fov=180, parameter=False)
+    if cfg.get('pol') == 4:
+        # (2, 2) Jones voltage beam: sqrt(Airy) on the diagonal, 3 % leakage terms
+        volt = airy.clamp_min(0).sqrt()
+        jones = torch.stack([torch.stack([volt, 0.03 * volt]), torch.stack([-0.03 * volt, volt])])   # (2,2,Nf,Npb)
+        beamp = torch.nn.Parameter(jones[:, :, None].contiguous())
+        R = beam_model.PixelResponse(freqs, 'rect', interp_mode='linear', theta_grid=tg, phi_grid=pg,
+                                     freq_mode='channel', powerbeam=False, realbeam=True, device=dev)
+        beam = beam_model.PixelBeam(beamp.detach()[..., f0:f1, :], freqs, R=R, pol='e', powerbeam=False,
+                                    fov=180, parameter=False)
+    else:
+        beamp = torch.nn.Parameter(airy[None, None, None].contiguous())
+        R = beam_model.PixelResponse(freqs, 'rect', interp_mode='linear', theta_grid=tg, phi_grid=pg,
+                                     freq_mode='channel', powerbeam=True, device=dev)
+        beam = beam_model.PixelBeam(beamp.detach()[..., f0:f1, :], freqs, R=R, pol='e', powerbeam=True,
+                                    fov=180, parameter=False)
     leaves.append(beamp)
     per_channel.append((beamp, 3))
     # geometry frequencies stay float64: an exactly uniform grid lets the fringe kernel use its
@@ -275,6 +307,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
     ap.add_argument('--nt', type=int, default=None, help='time steps per step (minibatch)')
+    ap.add_argument('--nf', type=int, default=None, help='override the number of channels (e.g. one rank\'s share of c5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shard', default='auto', choices=['auto', 'freq', 'bl'],
                     help='multi-GPU partition: channel blocks or baseline blocks (auto: channels when the '
@@ -299,12 +332,15 @@ def main():
 
     from bayeslim_amd import ops, dist as rdist
     cfg = WORKLOADS[args.workload]
+    if args.nf:
+        cfg = dict(cfg, Nf=args.nf, desc=cfg['desc'] + ' [%d channels]' % args.nf)
+        WORKLOADS[args.workload] = cfg
     nt = args.nt or cfg['nt']
     inp = build_inputs(args.workload, nt)
     bls = all_baselines(inp)
     shard = args.shard
     if shard == 'auto':
-        shard = 'freq' if args.workload in ('c3', 'c4') else 'bl'     # >= 33 antennas: antenna-factored kernels
+        shard = 'freq' if args.workload in ('c3', 'c4', 'c5') else 'bl'     # >= 33 antennas: antenna-factored kernels
     if shard == 'freq':
         bounds = rdist.shard_bounds(cfg['Nf'], world)
         my_bls, fblock, gdim = bls, bounds[rank], 4
