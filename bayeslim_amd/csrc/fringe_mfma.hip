@@ -154,8 +154,19 @@ struct FwdShape {
 };
 __host__ __device__ constexpr int tri_row(int TA, int idx) { int ti = 0; while (idx >= TA - ti) { idx -= TA - ti; ++ti; } return ti; }
 __host__ __device__ constexpr int tri_col(int TA, int idx) { int ti = 0; while (idx >= TA - ti) { idx -= TA - ti; ++ti; } return ti + idx; }
-template <class SH> __host__ __device__ constexpr int tile_row(int t) { return SH::CROSS ? t / 4 : tri_row(SH::TA, t); }
-template <class SH> __host__ __device__ constexpr int tile_col(int t) { return SH::CROSS ? t % 4 : tri_col(SH::TA, t); }
+// 128 antennas: the ten upper-triangular tiles in the order (0,0) (0,1) (0,2) (0,3) (3,3) (1,1) (1,2)
+// (1,3) (2,2) (2,3), so that the four waves' unit ranges touch 1, 2, 1, 2 row tiles (row-major
+// order: 1, 2, 2, 2) -- every row tile a wave touches costs 16 sign-mask v_xor per K step
+__host__ __device__ constexpr int tri4_row(int t) { return t < 4 ? 0 : (t == 4 ? 3 : (t < 8 ? 1 : 2)); }
+__host__ __device__ constexpr int tri4_col(int t) { return t < 4 ? t : (t == 4 ? 3 : (t < 8 ? t - 4 : t - 6)); }
+template <class SH> __host__ __device__ constexpr int tile_row(int t)
+{
+    return SH::CROSS ? t / 4 : (SH::TA == 4 ? tri4_row(t) : tri_row(SH::TA, t));
+}
+template <class SH> __host__ __device__ constexpr int tile_col(int t)
+{
+    return SH::CROSS ? t % 4 : (SH::TA == 4 ? tri4_col(t) : tri_col(SH::TA, t));
+}
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f)
