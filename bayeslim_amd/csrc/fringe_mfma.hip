@@ -120,7 +120,9 @@ __device__ __forceinline__ uint4 rot90(const uint4& v)
 //     products (packed f32 costs two issue slots: 2 % slower); the f64 "magic number" range
 //     reduction (1 % faster, 4 % more phase noise); a per-K-step unit deal for <= 64 antennas (no
 //     gain: those shapes are bound by operand generation); > 8192 pixels per split (slower tail,
-//     3x the f32 accumulation error); a uniform branch that skips the sign masks (spills).
+//     3x the f32 accumulation error); a uniform branch that skips the sign masks (spills); one
+//     accumulator per imaginary-part unit with a negated Li fragment (4 % slower, the freed
+//     registers only change the schedule); antenna coordinates in LDS instead of registers (2 % slower).
 // Every block covers at most MF_SPLIT_PIX pixels and STORES its result (no read-modify-write):
 // f32 accumulation inside the MFMA chain stays below eps*sqrt(512), and the pixel splits are
 // summed (and transposed into the result layout) by reduce_vis_kernel in a fixed order.
