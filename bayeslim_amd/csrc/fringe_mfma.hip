@@ -144,11 +144,13 @@ template <int TA_, bool CROSS_>
 struct FwdShape {
     static constexpr int TA = TA_;
     static constexpr bool CROSS = CROSS_;
-    static constexpr int NW = CROSS ? 8 : 4;                       // waves per block
-    static constexpr int ROWS = CROSS ? 2 * MF_NA : MF_NA;         // antenna rows of the LDS images
+    static constexpr int NW = CROSS ? 8 : 4;                       // waves per block (2-wave blocks for <= 64
+                                                                   // antennas: faster or slower with the grid size)
+    static constexpr int ROWS = CROSS ? 2 * MF_NA : 32 * TA;       // antenna rows of the LDS images (smaller
+                                                                   // arrays: more blocks per CU, 5-7 % faster)
     static constexpr int NT = CROSS ? 16 : TA * (TA + 1) / 2;      // 32x32 output tiles
-    static constexpr int GEN = CROSS ? 4 : TA;                     // antennas per thread and half panel
     static constexpr int GROWS = NW * 8;                           // antenna rows per generation sweep
+    static constexpr int GEN = ROWS / GROWS;                       // antennas per thread and half panel
     static constexpr int IMG = ROWS * MF_ROWB;                     // one image (hi or lo)
     static constexpr int BUF = 2 * IMG + 64;                       // hi + lo + sign dwords of the panel
     static constexpr size_t LDS = 2 * (size_t)BUF;
@@ -198,7 +200,9 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // generation mapping: lane = (pixel pair pp, antenna slot ag); rows of one ds_write are 2 apart
     // (80-B rows: 8 rows x 32 B land in 16 distinct 16-B granules of the 64 banks)
     const int pp = lane & 7, ag = lane >> 3;
-    const int grow = SH::CROSS ? 2 * ag + 16 * (W & 3) + (W >> 2) : 2 * ag + 16 * (W & 1) + (W >> 1);
+    // rows of one sweep: 2 apart inside a wave (bank-conflict-free writes), waves interleaved
+    const int grow = SH::NW == 8 ? 2 * ag + 16 * (W & 3) + (W >> 2)
+                   : SH::NW == 4 ? 2 * ag + 16 * (W & 1) + (W >> 1) : 2 * ag + W;
     double ax[SH::GEN], ay[SH::GEN], az[SH::GEN];
 #pragma unroll
     for (int u = 0; u < SH::GEN; ++u) {
@@ -378,8 +382,8 @@ __device__ __forceinline__ void ant_fwd_dispatch(const AntArgs& A, unsigned char
     switch (threadIdx.x >> 6) {                      // wave-uniform: every wave runs the same barriers
         case 0: ant_fwd_body<SH, 0, SIGNED>(A, smem); break;
         case 1: ant_fwd_body<SH, 1, SIGNED>(A, smem); break;
-        case 2: ant_fwd_body<SH, 2, SIGNED>(A, smem); break;
-        case 3: ant_fwd_body<SH, 3, SIGNED>(A, smem); break;
+        case 2: if constexpr (SH::NW > 2) ant_fwd_body<SH, 2, SIGNED>(A, smem); break;
+        case 3: if constexpr (SH::NW > 2) ant_fwd_body<SH, 3, SIGNED>(A, smem); break;
         case 4: if constexpr (SH::NW > 4) ant_fwd_body<SH, 4, SIGNED>(A, smem); break;
         case 5: if constexpr (SH::NW > 4) ant_fwd_body<SH, 5, SIGNED>(A, smem); break;
         case 6: if constexpr (SH::NW > 4) ant_fwd_body<SH, 6, SIGNED>(A, smem); break;
@@ -387,8 +391,10 @@ __device__ __forceinline__ void ant_fwd_dispatch(const AntArgs& A, unsigned char
     }
 }
 
+template <int TA> constexpr int fwd_threads() { return FwdShape<TA, false>::NW * 64; }
+
 template <int TA, bool SIGNED>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(fwd_threads<TA>(), 2)
 fringe_ant_fwd_kernel(AntArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -836,10 +842,10 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
         return check_launch();
     }
     switch ((Nrows + 31) / 32) {
-        case 1: RIME_FWD_PAIR((fringe_ant_fwd_kernel<1, true>), (fringe_ant_fwd_kernel<1, false>), 256, (FwdShape<1, false>::LDS)); break;
-        case 2: RIME_FWD_PAIR((fringe_ant_fwd_kernel<2, true>), (fringe_ant_fwd_kernel<2, false>), 256, (FwdShape<2, false>::LDS)); break;
-        case 3: RIME_FWD_PAIR((fringe_ant_fwd_kernel<3, true>), (fringe_ant_fwd_kernel<3, false>), 256, (FwdShape<3, false>::LDS)); break;
-        default: RIME_FWD_PAIR((fringe_ant_fwd_kernel<4, true>), (fringe_ant_fwd_kernel<4, false>), 256, (FwdShape<4, false>::LDS)); break;
+        case 1: RIME_FWD_PAIR((fringe_ant_fwd_kernel<1, true>), (fringe_ant_fwd_kernel<1, false>), (FwdShape<1, false>::NW * 64), (FwdShape<1, false>::LDS)); break;
+        case 2: RIME_FWD_PAIR((fringe_ant_fwd_kernel<2, true>), (fringe_ant_fwd_kernel<2, false>), (FwdShape<2, false>::NW * 64), (FwdShape<2, false>::LDS)); break;
+        case 3: RIME_FWD_PAIR((fringe_ant_fwd_kernel<3, true>), (fringe_ant_fwd_kernel<3, false>), (FwdShape<3, false>::NW * 64), (FwdShape<3, false>::LDS)); break;
+        default: RIME_FWD_PAIR((fringe_ant_fwd_kernel<4, true>), (fringe_ant_fwd_kernel<4, false>), (FwdShape<4, false>::NW * 64), (FwdShape<4, false>::LDS)); break;
     }
 #undef RIME_FWD_PAIR
     return check_launch();
