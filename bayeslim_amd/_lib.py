@@ -42,6 +42,8 @@ SIGNATURES = {
     'rime_gen_fringe': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rime_interp_gather_fwd': (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'rime_interp_scatter_bwd': (_i, [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'rime_beam_sky_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rime_beam_sky_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rime_alm2pix_fwd_workspace': (_sz, [_i, _i, _i, _i]),
     'rime_alm2pix_fwd': (_i, [_i, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'rime_alm2pix_bwd_workspace': (_sz, [_i, _i, _i, _i]),

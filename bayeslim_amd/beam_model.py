@@ -139,6 +139,35 @@ class PixelBeam(utils.Module):
         self.eval_prior(prior_cache)
         return beam
 
+    def response_map_and_stencil(self, zen, az, prior_cache=None):
+        """
+        For RIME's fused psky builder: the forwarded beam map (PixelResponse.beam_cache) and the
+        interpolation stencil at (zen, az) instead of the interpolated beam -- same side effects as
+        eval_response (beam cache, gradient hooks, prior).  None when the fused form does not apply:
+        anything but a 1-pol, single-model, real power beam on a plain PixelResponse without
+        pointing offsets.
+        """
+        R = self.R
+        if type(R).__call__ is not PixelResponse.__call__ or getattr(R, 'Rchi', None) is not None:
+            return None
+        if not (self.powerbeam and self.Npol == 1 and getattr(self, 'Nvec', 1) == 1):
+            return None
+        if getattr(self, 'theta_x', 0) > 0 or getattr(self, 'theta_y', 0) > 0:
+            return None
+        p = self.params if self.p0 is None else self.params + self.p0
+        if p.dim() != 5 or p.shape[2] != 1:
+            return None
+        if R.beam_cache is None:
+            R.set_beam_cache(p)
+        bc = R.beam_cache
+        if bc.is_complex() or bc.dim() != 5 or tuple(bc.shape[:3]) != (1, 1, 1):
+            return None
+        if getattr(self, '_hook_registry', None) is not None and bc.requires_grad:
+            for r in self._hook_registry:
+                bc.register_hook(r)
+        self.eval_prior(prior_cache)
+        return bc, R.get_stencil(zen, az)
+
     # -- beam x sky ----------------------------------------------------------------------
     def modelpairs(self, bls):
         """sorted unique (model1, model2) pairs and the pair index per baseline (beam_model.py:303-305)"""

@@ -149,3 +149,185 @@ extern "C" int rime_interp_scatter_bwd(int dtype, int is_complex, const void* go
     if (dtype == RIME_F64) return scatter_launch<double>(goutT, csr_ptr, csr_src, wgts, RN, Npb, Nnn, gmT, st);
     return RIME_EINVAL;
 }
+
+// ---------------------------------------------------------------------------------------
+// Fused psky builder for the 1-pol power-beam case (beam_model.py:238-269 gen_beam's interpolation,
+// beam_model.py:1681-1698 cut_sky_fov and the beam x sky product of apply_beam :313-322):
+//     psky[r, q] = ( sum_k w[q,k] bmap[r, inds[q,k]] ) * sky[r, cut[q]]       r = channel, q = (t, p)
+// instead of three passes (interpolated beam, cut sky, product) over (Nf x Nt x P) tensors.
+// cut[q] == Npix marks the zero padding of a time step.  Adjoint:
+//     T1[q, r]   = gpsky[r, q] * sky[r, cut[q]]      (transposed: the layout interp_scatter_kernel reads)
+//     gs[r, q]   = gpsky[r, q] * beam_interp[r, q]   (beam re-interpolated, not saved)
+//     gsky[r, j] = sum_t gs[r, t Ps + pos[t, j]]     (pos = inverse of cut per time step, -1 = not visible)
+// all deterministic (no atomics).
+// ---------------------------------------------------------------------------------------
+namespace rime {
+
+template <typename T, int NNN>
+__global__ void __launch_bounds__(256)
+beam_sky_fwd_kernel(const T* __restrict__ bmap, const T* __restrict__ sky, const int* __restrict__ inds,
+                    const T* __restrict__ wgts, const int* __restrict__ cut, int R, int Npb, int Npix,
+                    int Q, int Nnn, T* __restrict__ out)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const int r0 = blockIdx.y * RT, r1 = min(R, r0 + RT);
+    const int c = cut[q];
+    int id[NNN > 0 ? NNN : 1];
+    T w[NNN > 0 ? NNN : 1];
+    if constexpr (NNN > 0) {
+#pragma unroll
+        for (int k = 0; k < NNN; ++k) { id[k] = inds[(size_t)q * NNN + k]; w[k] = wgts[(size_t)q * NNN + k]; }
+    }
+    for (int r = r0; r < r1; ++r) {
+        T v = T(0);
+        if (c < Npix) {
+            const T* row = bmap + (size_t)r * Npb;
+            T b = T(0);
+            if constexpr (NNN > 0) {
+#pragma unroll
+                for (int k = 0; k < NNN; ++k) b = tfma<T>(w[k], row[id[k]], b);
+            } else {
+                for (int k = 0; k < Nnn; ++k) b = tfma<T>(wgts[(size_t)q * Nnn + k], row[inds[(size_t)q * Nnn + k]], b);
+            }
+            v = b * sky[(size_t)r * Npix + c];
+        }
+        out[(size_t)r * Q + q] = v;
+    }
+}
+
+// block = 64 points x 64 channels: a thread keeps the stencil of its point in registers and walks 16
+// channels; gps / gs are accessed along q, T1 is written along r through an LDS tile
+template <typename T, int NNN>
+__global__ void __launch_bounds__(256)
+beam_sky_bwd_kernel(const T* __restrict__ gps, const T* __restrict__ bmap, const T* __restrict__ sky,
+                    const int* __restrict__ inds, const T* __restrict__ wgts, const int* __restrict__ cut,
+                    int R, int Npb, int Npix, int Q, int Nnn, T* __restrict__ T1, T* __restrict__ gs)
+{
+    __shared__ T tile[64][65];
+    const int q0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int q = q0 + lx;
+    const int c = q < Q ? cut[q] : Npix;
+    int id[NNN > 0 ? NNN : 1];
+    T w[NNN > 0 ? NNN : 1];
+    if constexpr (NNN > 0) {
+        if (q < Q) {
+#pragma unroll
+            for (int k = 0; k < NNN; ++k) { id[k] = inds[(size_t)q * NNN + k]; w[k] = wgts[(size_t)q * NNN + k]; }
+        }
+    }
+#pragma unroll 4
+    for (int k16 = 0; k16 < 16; ++k16) {
+        const int rl = ly + 4 * k16, r = r0 + rl;
+        T t1 = T(0);
+        if (q < Q && r < R) {
+            const T g = gps[(size_t)r * Q + q];
+            T b = T(0), s = T(0);
+            if (c < Npix) {
+                const T* row = bmap + (size_t)r * Npb;
+                if constexpr (NNN > 0) {
+#pragma unroll
+                    for (int k = 0; k < NNN; ++k) b = tfma<T>(w[k], row[id[k]], b);
+                } else {
+                    for (int k = 0; k < Nnn; ++k) b = tfma<T>(wgts[(size_t)q * Nnn + k], row[inds[(size_t)q * Nnn + k]], b);
+                }
+                s = sky[(size_t)r * Npix + c];
+            }
+            gs[(size_t)r * Q + q] = g * b;
+            t1 = g * s;
+        }
+        tile[rl][lx] = t1;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k16 = 0; k16 < 16; ++k16) {
+        const int ql = ly + 4 * k16, qq = q0 + ql, r = r0 + lx;
+        if (qq < Q && r < R) T1[(size_t)qq * R + r] = tile[lx][ql];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+sky_gather_sum_kernel(const T* __restrict__ gs, const int* __restrict__ pos, int R, int Npix, int Nt, int Ps,
+                      T* __restrict__ gsky)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Npix) return;
+    const int r0 = blockIdx.y * RT, r1 = min(R, r0 + RT);
+    const size_t Q = (size_t)Nt * Ps;
+    T acc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = T(0);
+    for (int t = 0; t < Nt; ++t) {
+        const int p = pos[(size_t)t * Npix + j];
+        if (p >= 0) {
+            const size_t q = (size_t)t * Ps + p;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+                if (r0 + i < r1) acc[i] += gs[(size_t)(r0 + i) * Q + q];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+        if (r0 + i < r1) gsky[(size_t)(r0 + i) * Npix + j] = acc[i];
+}
+
+template <typename T>
+static int beam_sky_fwd_launch(const void* bmap, const void* sky, const int* inds, const void* wgts, const int* cut,
+                               int R, int Npb, int Npix, int Q, int Nnn, void* out, hipStream_t st)
+{
+    dim3 grid((Q + 255) / 256, (R + RT - 1) / RT), block(256);
+    const T* b_ = reinterpret_cast<const T*>(bmap); const T* s_ = reinterpret_cast<const T*>(sky);
+    const T* w_ = reinterpret_cast<const T*>(wgts); T* o_ = reinterpret_cast<T*>(out);
+#define RIME_BS(N) hipLaunchKernelGGL((beam_sky_fwd_kernel<T, N>), grid, block, 0, st, b_, s_, inds, w_, cut, R, Npb, Npix, Q, Nnn, o_)
+    switch (Nnn) {
+        case 1: RIME_BS(1); break;
+        case 4: RIME_BS(4); break;
+        case 9: RIME_BS(9); break;
+        case 16: RIME_BS(16); break;
+        default: RIME_BS(0); break;
+    }
+#undef RIME_BS
+    return check_launch();
+}
+
+} // namespace rime
+
+extern "C" int rime_beam_sky_fwd(int dtype, const void* bmap, const void* sky, const int* inds, const void* wgts,
+                                 const int* cut, int R, int Npb, int Npix, int Q, int Nnn, void* psky, void* stream)
+{
+    if (!bmap || !sky || !inds || !wgts || !cut || !psky) return RIME_EINVAL;
+    if (R <= 0 || Npb <= 0 || Npix <= 0 || Q <= 0 || Nnn <= 0) return RIME_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == RIME_F32) return beam_sky_fwd_launch<float>(bmap, sky, inds, wgts, cut, R, Npb, Npix, Q, Nnn, psky, st);
+    if (dtype == RIME_F64) return beam_sky_fwd_launch<double>(bmap, sky, inds, wgts, cut, R, Npb, Npix, Q, Nnn, psky, st);
+    return RIME_EINVAL;
+}
+
+extern "C" int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmap, const void* sky, const int* inds,
+                                 const void* wgts, const int* cut, const int* pos, int R, int Npb, int Npix,
+                                 int Nt, int Ps, int Nnn, void* T1, void* gs, void* gsky, void* stream)
+{
+    if (!gpsky || !bmap || !sky || !inds || !wgts || !cut || !pos || !T1 || !gs || !gsky) return RIME_EINVAL;
+    if (R <= 0 || Npb <= 0 || Npix <= 0 || Nt <= 0 || Ps <= 0 || Nnn <= 0) return RIME_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int Q = Nt * Ps;
+    dim3 g1((Q + 63) / 64, (R + 63) / 64), g2((Npix + 255) / 256, (R + RT - 1) / RT);
+#define RIME_BSB(TT, N) hipLaunchKernelGGL((beam_sky_bwd_kernel<TT, N>), g1, dim3(256), 0, st, (const TT*)gpsky, \
+        (const TT*)bmap, (const TT*)sky, inds, (const TT*)wgts, cut, R, Npb, Npix, Q, Nnn, (TT*)T1, (TT*)gs)
+#define RIME_BSB_ALL(TT) switch (Nnn) { case 1: RIME_BSB(TT, 1); break; case 4: RIME_BSB(TT, 4); break; \
+        case 9: RIME_BSB(TT, 9); break; case 16: RIME_BSB(TT, 16); break; default: RIME_BSB(TT, 0); break; }
+    if (dtype == RIME_F32) {
+        RIME_BSB_ALL(float)
+        hipLaunchKernelGGL((sky_gather_sum_kernel<float>), g2, dim3(256), 0, st, (const float*)gs, pos, R, Npix, Nt, Ps,
+                           (float*)gsky);
+    } else if (dtype == RIME_F64) {
+        RIME_BSB_ALL(double)
+        hipLaunchKernelGGL((sky_gather_sum_kernel<double>), g2, dim3(256), 0, st, (const double*)gs, pos, R, Npix, Nt, Ps,
+                           (double*)gsky);
+    } else return RIME_EINVAL;
+#undef RIME_BSB_ALL
+#undef RIME_BSB
+    return check_launch();
+}

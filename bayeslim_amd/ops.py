@@ -437,6 +437,56 @@ def interp_gather(m, stencil, out_stride=None):
     return _InterpGather.apply(m, stencil, stencil.P if out_stride is None else int(out_stride))
 
 
+class _BeamSkyProduct(torch.autograd.Function):
+    """psky[r, q] = interp(bmap)[r, q] * sky[r, cut[q]] in one pass (see rime_beam_sky_fwd)"""
+    @staticmethod
+    def forward(ctx, bmap, sky, st, cut, pos, Nt, Ps):
+        _require_cuda(bmap, sky)
+        R, Npb = bmap.shape
+        Npix = sky.shape[1]
+        assert sky.shape[0] == R and Npb == st.Npb and st.P == Nt * Ps and bmap.dtype == sky.dtype
+        b, k = bmap.detach().contiguous(), sky.detach().contiguous()
+        code, rdt = _real_dtype(b)
+        out = torch.empty((R, Nt * Ps), dtype=b.dtype, device=b.device)
+        rc = lib.rime_beam_sky_fwd(code, _ptr(b), _ptr(k), _ptr(st.inds), _ptr(st.weights(rdt)), _ptr(cut),
+                                   R, Npb, Npix, Nt * Ps, st.Nnn, _ptr(out), _stream())
+        check(rc, 'rime_beam_sky_fwd')
+        ctx.save_for_backward(b, k)
+        ctx.aux = (st, cut, pos, Nt, Ps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, k = ctx.saved_tensors
+        st, cut, pos, Nt, Ps = ctx.aux
+        R, Npb = b.shape
+        Npix = k.shape[1]
+        Q = Nt * Ps
+        code, rdt = _real_dtype(b)
+        g = g.contiguous()
+        T1 = torch.empty((Q, R), dtype=b.dtype, device=b.device)
+        gs = torch.empty((R, Q), dtype=b.dtype, device=b.device)
+        gsky = torch.empty((R, Npix), dtype=b.dtype, device=b.device)
+        rc = lib.rime_beam_sky_bwd(code, _ptr(g), _ptr(b), _ptr(k), _ptr(st.inds), _ptr(st.weights(rdt)), _ptr(cut),
+                                   _ptr(pos), R, Npb, Npix, Nt, Ps, st.Nnn, _ptr(T1), _ptr(gs), _ptr(gsky), _stream())
+        check(rc, 'rime_beam_sky_bwd')
+        gmT = torch.empty((Npb, R), dtype=b.dtype, device=b.device)
+        rc = lib.rime_interp_scatter_bwd(code, 0, _ptr(T1), _ptr(st.csr_ptr), _ptr(st.csr_src), _ptr(st.weights(rdt)),
+                                         R, Npb, Q, st.Nnn, _ptr(gmT), _stream())
+        check(rc, 'rime_interp_scatter_bwd')
+        return gmT.t(), gsky, None, None, None, None, None
+
+
+def beam_sky_product(bmap, sky, stencil, cut, pos, Nt, Ps):
+    """
+    Fused interpolate-cut-multiply of the 1-pol power-beam case: bmap (R, Npix_beam) and sky (R, Npix)
+    real, same dtype; stencil an InterpStencil over the Nt*Ps (padded) pointing angles; cut int32
+    (Nt*Ps) sky-pixel index per point (Npix = padding); pos int32 (Nt, Npix) its inverse per time step
+    (-1 = not visible).  Returns psky (R, Nt*Ps).  Differentiable w.r.t. bmap and sky.
+    """
+    return _BeamSkyProduct.apply(bmap, sky, stencil, cut, pos, int(Nt), int(Ps))
+
+
 # ---------------------------------------------------------------------------------------
 ALM_SPLIT_F16 = True        # float32: f16 hi/lo split operands on the f16 matrix cores (22 bits) instead
                             # of the exact-f32 MFMA kernels (set False to force those)

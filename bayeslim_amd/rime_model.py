@@ -31,6 +31,7 @@ class RIME(utils.Module):
         self.array = array
         self.device = device
         self.cache_eq2top = cache_eq2top
+        self.fuse_beam_sky = True       # 1-pol power beam: ops.beam_sky_product instead of interp + cut + product
         self.verbose = verbose
         self.clear_geometry_cache()
         self.setup_freqs(freqs)
@@ -208,7 +209,12 @@ class RIME(utils.Module):
         geom = ops.FringeGeometry(self.sim_blvecs.to(dev), sdir, self.freqs, bl_mp=bl_mp,
                                   Nmp=len(pairs), npix=[c.numel() for c in cuts],
                                   antpos=self.array.antvecs, bl_ants=bl_ants)
-        bg = dict(zen=zen_all, az=az_all, cut=cut_all, geom=geom, Nt=Nt, Ps=Ps)
+        # for the fused psky builder: int32 cut and its inverse per time step
+        pos = torch.full((Nt, Npix), -1, dtype=torch.int32, device=dev)
+        for j, cut in enumerate(cuts):
+            pos[j, cut] = torch.arange(cut.numel(), dtype=torch.int32, device=dev)
+        bg = dict(zen=zen_all, az=az_all, cut=cut_all, geom=geom, Nt=Nt, Ps=Ps,
+                  cut32=cut_all.to(torch.int32), pos=pos)
         self._geom_cache[gkey] = bg
         return bg
 
@@ -238,14 +244,25 @@ class RIME(utils.Module):
             if self.verbose:
                 log('{} times for {}/{} sky model | {} elapsed'.format(
                     len(self.sim_times), i + 1, len(comps), elapsed_time(start)), verbose=True)
-            # beam at the FoV-cut angles of ALL time steps: one response evaluation / gather launch
-            beam = self.beam.eval_response(bg['zen'], bg['az'], prior_cache=prior_cache)
-            # sky with one trailing zero column: padded cut indices point at it
-            sky_ext = torch.cat([sky, sky.new_zeros(sky.shape[:-1] + (1,))], dim=-1)
-            cut_sky = sky_ext.index_select(-1, bg['cut'])            # beam_model.cut_sky_fov, all times
-            ps = self.beam.apply_beam_mp(beam, cut_sky, pairs)       # (n1, n2, Nmp, Nf, Nt*Ps)
-            n1, n2, Nmp, Nf = ps.shape[:4]
             Nt, Ps = bg['Nt'], bg['Ps']
+            fused = None
+            if self.fuse_beam_sky and len(pairs) == 1 and tuple(sky.shape[:2]) == (1, 1) and not sky.is_complex():
+                fused = self.beam.response_map_and_stencil(bg['zen'], bg['az'], prior_cache=prior_cache)
+                if fused is not None and fused[0].dtype != sky.dtype:
+                    fused = None
+            if fused is not None:
+                # 1-pol power beam: interpolation, FoV cut and beam x sky in one pass (ops.beam_sky_product)
+                bc, st = fused
+                ps = ops.beam_sky_product(bc[0, 0, 0], sky[0, 0], st, bg['cut32'], bg['pos'], Nt, Ps)
+                ps = ps.reshape(1, 1, 1, ps.shape[0], Nt * Ps)
+            else:
+                # beam at the FoV-cut angles of ALL time steps: one response evaluation / gather launch
+                beam = self.beam.eval_response(bg['zen'], bg['az'], prior_cache=prior_cache)
+                # sky with one trailing zero column: padded cut indices point at it
+                sky_ext = torch.cat([sky, sky.new_zeros(sky.shape[:-1] + (1,))], dim=-1)
+                cut_sky = sky_ext.index_select(-1, bg['cut'])        # beam_model.cut_sky_fov, all times
+                ps = self.beam.apply_beam_mp(beam, cut_sky, pairs)   # (n1, n2, Nmp, Nf, Nt*Ps)
+            n1, n2, Nmp, Nf = ps.shape[:4]
             # -> (Nt, Nmp, Npp, Nf, Ps) as a strided VIEW: the fringe kernels take the strides
             ps = ps.reshape(n1 * n2, Nmp, Nf, Nt, Ps).permute(3, 1, 0, 2, 4)
             v = ops.fringe_sum(ps, bg['geom'])                       # (Npp, Nbl, Nt, Nf)
