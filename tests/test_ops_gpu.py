@@ -469,6 +469,41 @@ def test_interp_gather_complex_and_ragged_stencil(ops):
 
 
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
+@pytest.mark.parametrize('Nnn', [4, 9, 6])
+def test_beam_sky_product(ops, dtype, Nnn):
+    """fused interpolate - cut - multiply (ops.beam_sky_product) against oracle interp x cut sky,
+    forward and both gradients; ragged time steps with zero padding, sky pixels seen 0, 1 or 2 times"""
+    rng = np.random.default_rng(Nnn)
+    R, Npb, Npix, Nt, Ps = 37, 300, 500, 3, 192
+    npix_t = [150, 192, 101]
+    cuts = [np.sort(rng.choice(Npix, n, replace=False)) for n in npix_t]
+    cut = np.full((Nt, Ps), Npix, dtype=np.int64)
+    pos = np.full((Nt, Npix), -1, dtype=np.int64)
+    for t, c in enumerate(cuts):
+        cut[t, :len(c)] = c
+        pos[t, c] = np.arange(len(c))
+    inds = torch.as_tensor(rng.integers(0, Npb, (Nt * Ps, Nnn)))
+    wgts = T64(rng.normal(size=(Nt * Ps, Nnn)))
+    bmap, sky = T64(rng.normal(size=(R, Npb))), T64(rng.normal(size=(R, Npix)))
+    b_ref, s_ref = bmap.clone().requires_grad_(True), sky.clone().requires_grad_(True)
+    sky_ext = torch.cat([s_ref, torch.zeros(R, 1, dtype=torch.float64)], dim=1)
+    ref = orc.interp(b_ref, inds, wgts) * sky_ext[:, torch.as_tensor(cut.reshape(-1))]
+    gv = T64(rng.normal(size=tuple(ref.shape)))
+    (ref * gv).sum().backward()
+    rdt = torch.float64 if dtype == 'f64' else torch.float32
+    st = ops.InterpStencil(inds.cuda(), wgts.to(rdt).cuda(), Npb)
+    b, s = bmap.to(rdt).cuda().requires_grad_(True), sky.to(rdt).cuda().requires_grad_(True)
+    out = ops.beam_sky_product(b, s, st, torch.as_tensor(cut.reshape(-1), dtype=torch.int32).cuda(),
+                               torch.as_tensor(pos, dtype=torch.int32).cuda(), Nt, Ps)
+    tol = 1e-12 if dtype == 'f64' else 3e-6
+    assert relmax(out, ref) < tol
+    (out * gv.to(rdt).cuda()).sum().backward()
+    assert relmax(b.grad, b_ref.grad) < tol and relmax(s.grad, s_ref.grad) < tol
+    # padded points give exact zeros
+    assert float(out.detach().reshape(R, Nt, Ps)[:, 0, 150:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
 def test_alm2pix(ops, dtype):
     g = load_golden('sph_harm')
     a = torch.as_tensor(g['alm'])
