@@ -239,7 +239,7 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False):
     """enable the antenna-factored matrix-core kernels when the baseline set suits them"""
     Nant = int(antpos.shape[0])
     bl_ants = [(int(a), int(b)) for a, b in bl_ants]
-    if Nant > MFMA_MAX_ANTS or len(bl_ants) != self.Nbl:
+    if Nant > MFMA_MAX_ANTS or len(bl_ants) != self.Nbl or self.Nt > 65535:      # (reduce kernels: t on grid.z)
         return
     # worth it when the array needs at least two 32-antenna tiles and most pairs are requested
     # (measured against the baseline-formulation kernels: 128 antennas / 8128 baselines 4.8x (fwd)
