@@ -1,9 +1,9 @@
-// fringe_mfma.hip -- antenna-factored fringe sum on the matrix cores (gfx950), forward.
+// fringe_mfma.hip -- antenna-factored fringe sum on the matrix cores (gfx950), forward and backward.
 //
 // For baselines that are antenna pairs, b_ij = r_j - r_i, the fringe factorises:
 //     exp(2 pi i nu b_ij.s / c) = E_j conj(E_i),   E_a[f,p] = exp(2 pi i nu_f r_a.s_p / c)
 // so for every (time, channel) the visibilities of ALL pairs are one Hermitian rank-P update
-//     V[i,j] = sum_p conj(E_i[p]) * (A[p] E_j[p]),        A = psky[t,f,:]  (1-pol, real)
+//     V[i,j] = sum_p conj(E_i[p]) * (A[p] E_j[p]),        A = one real plane of psky[t,f,:]
 // i.e. a complex GEMM with M = N = Nant, K = P, batched over (t, f) -- the "dense
 // (Nvis x Npix) . Npix contraction" of the north star, at 1/Nant of the exponentials of the
 // baseline formulation.  (Reference arithmetic replaced: the same lines as fringe.hip,
@@ -15,9 +15,10 @@
 // (t, f) so that the f16 range is used (`scale` input).
 //
 // Work decomposition: block = one (t, f, pixel split); 4 waves; the upper-triangular 32x32 tiles
-// of the Nant x Nant (<= 128 x 128) output are dealt to the waves; per panel of 16 pixels the
+// of the Nant x Nant (<= 128 x 128) output are dealt to the waves; per panel of 32 pixels the
 // block generates the operand images once into LDS and every wave runs its MFMAs from LDS
-// fragments (details at the kernels).
+// fragments (details at the kernels).  Larger arrays: groups of 128 antennas, diagonal blocks (this
+// kernel) + cross blocks (8 waves, 16 tiles); multi-pol / complex psky: one launch per real plane.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <type_traits>
@@ -83,17 +84,6 @@ __device__ __forceinline__ void split2_plain(float a, float b, uint32_t& hi, uin
 
 __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_cast(f16x8, v); }
 
-// (Lr, Li) -> (-Li, Lr) for each of the four packed pairs: left operand of the imaginary part
-__device__ __forceinline__ uint4 rot90(const uint4& v)
-{
-    uint4 r;
-    r.x = __builtin_amdgcn_alignbit(v.x, v.x, 16) ^ 0x00008000u;
-    r.y = __builtin_amdgcn_alignbit(v.y, v.y, 16) ^ 0x00008000u;
-    r.z = __builtin_amdgcn_alignbit(v.z, v.z, 16) ^ 0x00008000u;
-    r.w = __builtin_amdgcn_alignbit(v.w, v.w, 16) ^ 0x00008000u;
-    return r;
-}
-
 // ---------------------------------------------------------------------------------------
 // forward kernel
 //
@@ -105,11 +95,12 @@ __device__ __forceinline__ uint4 rot90(const uint4& v)
 //   * symmetric weighting: L = B = sqrt(|psky| scale) E, so ONE operand image pair (f16 hi, lo) is
 //     generated per (antenna, pixel) instead of two; the sign of psky is applied as an XOR mask on
 //     the row-tile fragments (per wave: 16 v_xor per distinct row tile and panel);
-//   * re and im live in separate K-planes ([antenna][16 px re | 16 px im]), K = 16 pixels per
+//   * re and im live in separate K-planes ([antenna][32 px re | 32 px im]), K = 16 pixels per
 //     MFMA.  Vr = Lr.Br + Li.Bi,  Vi = Lr.Bi - Li.Br with the two Vi products kept in separate
 //     accumulators and subtracted in the epilogue: no operand rotation / negation work at all;
 //   * the 10 upper-triangular 32x32 tiles are dealt to the 4 waves as 20 (tile, re|im) units,
-//     5 each (30 MFMAs per wave and panel; a 3/3/2/2 deal of whole tiles idles 17 % of the pipe);
+//     5 each (30 MFMAs per wave and K step; a 3/3/2/2 deal of whole tiles idles 17 % of the pipe),
+//     in a tile order that lets two of the four waves touch a single row tile;
 //   * a thread generates 2 adjacent pixels x TA antennas whose coordinates (pre-multiplied by
 //     sign nu/c) stay in registers: per pair 3 f64 FMA + fract + cvt + sin + cos + mul and half
 //     a hi/lo split; packed (p, p+1) f16 pairs go out as conflict-free ds_write_b32;
@@ -127,8 +118,8 @@ __device__ __forceinline__ uint4 rot90(const uint4& v)
 // f32 accumulation inside the MFMA chain stays below eps*sqrt(512), and the pixel splits are
 // summed (and transposed into the result layout) by reduce_vis_kernel in a fixed order.
 // History (C4 shape, 128 antennas, 256 channels x 2 times, 98304 px): interleaved (re,im) K layout
-// with separate L/B images, rot90 on the fly and whole-tile deal: 13.4 ms; this kernel: 11.3 ms
-// (matrix pipe busy 51 -> 57 %, the rest is operand generation on the VALU).
+// with separate L/B images, rot90 on the fly and whole-tile deal: 13.4 ms; this kernel: 10.7 ms
+// (matrix pipe busy 46 -> 55 %, 39 % operand generation on the VALU, ~5 % idle).
 // ---------------------------------------------------------------------------------------
 #ifndef RIME_MF_KP
 #define RIME_MF_KP 32
