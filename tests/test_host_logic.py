@@ -290,3 +290,18 @@ def test_antenna_block_tables():
     assert ops._antenna_blocks([(130, 2), (2, 130)], 140) is not None
     assert ops._antenna_blocks([(1, 2), (1, 2)], 4) is None
     assert ops._antenna_blocks([(2, 130), (2, 130)], 140) is None
+
+
+def test_eq2top_device_matches_host():
+    """the torch restatement of the LST rotation (used when the sky angles live on the GPU) agrees with
+    the numpy one to rounding"""
+    from bayeslim_amd import telescope_model
+    rng = np.random.default_rng(0)
+    ra, dec = rng.uniform(0, 360, 5000), np.rad2deg(np.arcsin(rng.uniform(-1, 1, 5000)))
+    for jd in (2459861.0, 2459861.37, 2460000.123456):
+        zen, az = telescope_model.eq2top((21.42827, -30.72148), jd, ra, dec)
+        za = telescope_model.eq2top_device((21.42827, -30.72148), jd, torch.as_tensor(ra), torch.as_tensor(dec))
+        assert za.dtype == torch.float64 and za.shape == (2, 5000)
+        assert np.abs(za[0].numpy() - zen).max() < 1e-9
+        daz = np.abs(za[1].numpy() - az)
+        assert np.minimum(daz, 360 - daz).max() < 1e-8          # (wraps at 0 / 360)
