@@ -62,7 +62,7 @@ class FringeGeometry:
     pixel count; freqs (Nf,) [Hz]; bl_models: optional list of model-pair index per baseline.
     """
     def __init__(self, blvecs, sdir, freqs, bl_mp=None, Nmp=1, conj=False, npix=None,
-                 antpos=None, bl_ants=None, mfma='auto'):
+                 antpos=None, bl_ants=None, mfma='auto', ant_like=None):
         _require_cuda(blvecs, sdir)
         dev = blvecs.device
         self.blvecs = blvecs.detach().to(torch.float64).contiguous()
@@ -94,7 +94,13 @@ class FringeGeometry:
             self.uniform, self.df = 1, 0.0
         # antenna factorisation (matrix-core path): baselines given as antenna-index pairs
         self.ant = None
-        if antpos is not None and bl_ants is not None and mfma in ('auto', True):
+        if ant_like is not None and ant_like.ant is not None and ant_like.Nbl == self.Nbl:
+            # same baseline set as an existing geometry (another time minibatch): share its pair tables
+            tiles = ant_like.ant['tiles']
+            self.ant = dict(ant_like.ant, mfma_flops=self.Nt * self.Nf * (self.Pstride // 16) * tiles * 12 * 32768)
+            if self.Nt > 65535:
+                self.ant = None
+        elif antpos is not None and bl_ants is not None and mfma in ('auto', True):
             self._setup_antenna_path(antpos, bl_ants, force=(mfma is True))
         # model-pair grouping
         self.Nmp = int(Nmp)
@@ -276,7 +282,7 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False):
     # executed matrix-core work per pass (forward == backward): per 16 pixels, 12 MFMAs of
     # 2*32*32*16 flop on each 32x32 antenna tile of every block
     mfma_flops = self.Nt * self.Nf * (self.Pstride // 16) * tiles * 12 * 32768
-    self.ant = dict(blocks=blocks, Nant=Nant, mfma_flops=mfma_flops)
+    self.ant = dict(blocks=blocks, Nant=Nant, tiles=tiles, mfma_flops=mfma_flops)
 
 
 FringeGeometry._setup_antenna_path = _setup_antenna_path

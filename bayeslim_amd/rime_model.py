@@ -43,6 +43,7 @@ class RIME(utils.Module):
         self._zenaz_cache = {}      # key -> (zen, az) float64 on the compute device
         self._npix_cache = {}       # key -> pixels surviving the FoV cut
         self._geom_cache = {}       # (bl group, time group, sky name, Npix) -> FringeGeometry
+        self._ant_like = {}         # bl group -> first FringeGeometry built for it (shares its pair tables)
         self._mp_cache = {}         # bl group -> (modelpairs, pair index per baseline)
 
     def push(self, device):
@@ -103,7 +104,7 @@ class RIME(utils.Module):
                 self.data_bl_groups[k] = dbl
                 pos = {r: i for i, r in reversed(list(enumerate(sim_red)))}
                 self._sim2data[k] = torch.as_tensor([pos[r] for r in data_red], device=self.device)
-        self._geom_cache, self._mp_cache = {}, {}
+        self._geom_cache, self._mp_cache, self._ant_like = {}, {}, {}
         self._set_group()
 
     # -- time groups (rime_model.py:228-251) -------------------------------------------------
@@ -206,9 +207,14 @@ class RIME(utils.Module):
         # antenna positions + antenna-index pairs let the fringe op take its matrix-core path
         idx = self.array._ant_idx
         bl_ants = [(idx[b[0]], idx[b[1]]) for b in self.sim_bls]
+        # pair tables of the matrix-core path depend on the baseline group only: built once, shared by
+        # the geometries of all time minibatches
+        like = self._ant_like.get(self.bl_group_id)
         geom = ops.FringeGeometry(self.sim_blvecs.to(dev), sdir, self.freqs, bl_mp=bl_mp,
                                   Nmp=len(pairs), npix=[c.numel() for c in cuts],
-                                  antpos=self.array.antvecs, bl_ants=bl_ants)
+                                  antpos=self.array.antvecs, bl_ants=bl_ants, ant_like=like)
+        if like is None:
+            self._ant_like[self.bl_group_id] = geom
         # for the fused psky builder: int32 cut and its inverse per time step
         pos = torch.full((Nt, Npix), -1, dtype=torch.int32, device=dev)
         for j, cut in enumerate(cuts):
