@@ -320,7 +320,7 @@ split_rows_kernel(const float* __restrict__ X, int R, int L, int Rpad, int neg_o
     float scale = 1.0f;
     if (r < R) {
         const float m = __uint_as_float(rowmax[r]);
-        if (m > 0.f) scale = exp2f(floorf(log2f(8192.0f / m)));            // max|x| * scale in [2^12, 2^13]
+        if (m > 0.f) scale = exp2f(fminf(fmaxf(floorf(log2f(8192.0f / m)), -100.f), 100.f));   // max|x| * scale in [2^12, 2^13]
     }
     if (blockIdx.y == 0 && tid == 0) inv_scale[r] = (r < R) ? 1.0f / scale : 0.f;
     const int g0 = blockIdx.y * (SPLIT_SEG / 8), g1 = min(nsteps * 2, g0 + SPLIT_SEG / 8);

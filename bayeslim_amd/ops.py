@@ -175,7 +175,8 @@ MFMA_MAX_ANTS = 2048      # table memory only: 136 blocks x 128 KB at 2048 anten
 def _pow2_scale(amax):
     """power of two s with amax * s in [2^13, 2^14]; 1 where amax == 0 (exact to apply and undo)"""
     safe = torch.where(amax > 0, amax, torch.ones_like(amax))
-    return torch.where(amax > 0, torch.exp2(torch.floor(torch.log2(16384.0 / safe))), torch.ones_like(amax))
+    e = torch.floor(torch.log2(16384.0 / safe)).clamp(-100.0, 100.0)      # denormal-sized rows: no inf scale
+    return torch.where(amax > 0, torch.exp2(e), torch.ones_like(amax))
 
 
 def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
