@@ -44,6 +44,9 @@ SIGNATURES = {
     'rime_interp_scatter_bwd': (_i, [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'rime_beam_sky_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rime_beam_sky_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'rime_chisq_workspace': (_sz, []),
+    'rime_chisq_fwd': (_i, [_i, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
+    'rime_chisq_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     'rime_alm2pix_fwd_workspace': (_sz, [_i, _i, _i, _i]),
     'rime_alm2pix_fwd': (_i, [_i, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'rime_alm2pix_bwd_workspace': (_sz, [_i, _i, _i, _i]),

@@ -494,6 +494,46 @@ def beam_sky_product(bmap, sky, stencil, cut, pos, Nt, Ps):
     return _BeamSkyProduct.apply(bmap, sky, stencil, cut, pos, int(Nt), int(Ps))
 
 
+class _Chisq(torch.autograd.Function):
+    """chi^2 = sum icov |pred - data|^2 and its backward in one pass each (see rime_chisq_fwd)"""
+    @staticmethod
+    def forward(ctx, pred, data, icov):
+        _require_cuda(pred)
+        assert pred.is_complex(), 'prediction must be complex'
+        p = pred.detach().contiguous()
+        code, rdt = _real_dtype(p)
+        d = None if data is None else data.detach().to(p.dtype).expand_as(p).contiguous()
+        w = None if icov is None else icov.detach().to(rdt).expand_as(p).contiguous()
+        out = torch.empty((), dtype=rdt, device=p.device)
+        ws = torch.empty(int(lib.rime_chisq_workspace()), dtype=torch.uint8, device=p.device)
+        rc = lib.rime_chisq_fwd(code, _ptr(torch.view_as_real(p)), _ptr(torch.view_as_real(d)) if d is not None else None,
+                                _ptr(w) if w is not None else None, p.numel(), _ptr(out), _ptr(ws), ws.numel(), _stream())
+        check(rc, 'rime_chisq_fwd')
+        ctx.saved = (p, d, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, d, w = ctx.saved
+        code, rdt = _real_dtype(p)
+        gp = torch.empty_like(p)
+        gg = g.detach().to(rdt).reshape(1).contiguous()
+        rc = lib.rime_chisq_bwd(code, _ptr(torch.view_as_real(p)), _ptr(torch.view_as_real(d)) if d is not None else None,
+                                _ptr(w) if w is not None else None, _ptr(gg), p.numel(),
+                                _ptr(torch.view_as_real(gp)), _stream())
+        check(rc, 'rime_chisq_bwd')
+        return gp, None, None
+
+
+def chisq(pred, data=None, icov=None):
+    """
+    sum_i icov_i |pred_i - data_i|^2 (real scalar) for a complex prediction; data complex or None (0),
+    icov real (inverse variance, diagonal) or None (1), both broadcastable to pred.  Differentiable
+    w.r.t. pred.  The fused form of LogProb.forward_chisq's residual + apply_icov(cov_axis=None) + sum.
+    """
+    return _Chisq.apply(pred, data, icov)
+
+
 # ---------------------------------------------------------------------------------------
 ALM_SPLIT_F16 = True        # float32: f16 hi/lo split operands on the f16 matrix cores (22 bits) instead
                             # of the exact-f32 MFMA kernels (set False to force those)

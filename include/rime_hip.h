@@ -230,6 +230,20 @@ size_t rime_alm2pix_bwd_workspace(int dtype, int R, int Ncoeff, int Npix);
 int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, double y_scale, int R, int Ncoeff,
                      int Npix, void* galm, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Likelihood epilogue:  chi^2 = sum_i icov[i] * |pred[i] - data[i]|^2  over a complex visibility tensor
+ * (N complex elements, interleaved), and its backward gpred[i] = 2 g icov[i] (pred[i] - data[i]).
+ * Replaces `res = prediction - data; apply_icov(res, icov, cov_axis=None); torch.sum(...)` of
+ * LogProb.forward_chisq (optim.py:1019-1027, apply_icov :1889-1894) -- SURVEY section 8(f) item 4.
+ *   data NULL -> 0; icov T [N] real or NULL -> 1; out T [1]; g T [1] (device scalar: upstream gradient)
+ * Deterministic two-pass reduction (double partial sums in a caller-owned workspace).
+ * ------------------------------------------------------------------------------------- */
+size_t rime_chisq_workspace(void);
+int rime_chisq_fwd(int dtype, const void* pred, const void* data, const void* icov, size_t N,
+                   void* out, void* workspace, size_t workspace_bytes, void* stream);
+int rime_chisq_bwd(int dtype, const void* pred, const void* data, const void* icov, const void* g,
+                   size_t N, void* gpred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -364,3 +364,15 @@ def rime_forward(sky, zenaz, beam_fn, blvecs, bl_models, freqs, powerbeam=True, 
         psky = apply_beam(beam, cut_sky, bl_models, powerbeam)
         out.append(prod_and_sum(psky, blvecs, zc, ac, freqs, sim2data_idx))
     return torch.stack(out, dim=3)
+
+
+def apply_icov_diag(res, icov=None):
+    """optim.apply_icov with cov_axis=None (optim.py:1889-1894): conj(res) * res [* icov], elementwise"""
+    out = res.conj() * res
+    return out if icov is None else out * icov
+
+
+def chisq(pred, data, icov=None):
+    """LogProb.forward_chisq's value (optim.py:1019-1027): sum of apply_icov(pred - data), real part"""
+    tot = torch.sum(apply_icov_diag(pred - data, icov))
+    return tot.real if torch.is_complex(tot) else tot

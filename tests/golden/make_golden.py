@@ -598,10 +598,40 @@ def gen_prod_and_sum(ba):
          sum_sky=vis[0], sim2data_idx=idx, sum_sky_inflated=vis[1])
 
 
+def gen_chisq(ba):
+    """diagonal-inverse-covariance chi-square of a visibility residual: optim.apply_icov with
+    cov_axis=None (optim.py:1836-1915) as LogProb.forward_chisq uses it (optim.py:1019-1027), value
+    and gradient w.r.t. the prediction"""
+    import importlib
+    optim = importlib.import_module('bayeslim.optim')
+    rng = np.random.default_rng(7)
+    shape = (2, 2, 13, 3, 5)
+    pred = torch.as_tensor(rng.normal(size=shape) + 1j * rng.normal(size=shape))
+    data = torch.as_tensor(rng.normal(size=shape) + 1j * rng.normal(size=shape))
+    icov = torch.as_tensor(rng.uniform(0.1, 3.0, size=shape))
+    out = {}
+    for tag, ic in (('icov', icov), ('noicov', None)):
+        p = pred.clone().requires_grad_(True)
+        res = p - data
+        chisq = optim.apply_icov(res, ic, None)
+        tot = torch.sum(chisq)
+        tot = tot.real if torch.is_complex(tot) else tot
+        tot.backward()
+        out['chisq_' + tag] = chisq
+        out['sum_' + tag] = tot
+        out['gpred_' + tag] = p.grad
+    save('chisq', pred=pred, data=data, icov=icov, **out)
+
+
 def main():
     torch.set_default_dtype(torch.float64)
     torch.manual_seed(0)
     ba = bootstrap_reference()
+    if len(sys.argv) > 1:                       # e.g. `make_golden.py gen_chisq`: regenerate selected files only
+        for name in sys.argv[1:]:
+            globals()[name](ba)
+        return
+    gen_chisq(ba)
     gen_fringe_cases(ba)
     gen_apply_beam_cases(ba)
     gen_interp_cases(ba)

@@ -566,3 +566,40 @@ def test_alm2pix_mfma_shapes(ops, R, lmax, Npix):
 def test_ops_refuse_cpu_tensors(ops):
     with pytest.raises(RuntimeError):
         ops.alm2pix(torch.zeros(2, 3, dtype=torch.complex64), torch.zeros(3, 4, dtype=torch.complex64))
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_chisq_epilogue(ops, dtype):
+    """fused chi-square (residual, diagonal inverse covariance, sum) and its backward against the golden
+    vectors of the imported reference (optim.apply_icov, cov_axis=None) and, at a larger size with
+    broadcast icov / no data, against the oracle; bitwise reproducible"""
+    g = load_golden('chisq')
+    cdt = torch.complex128 if dtype == 'f64' else torch.complex64
+    rdt = torch.float64 if dtype == 'f64' else torch.float32
+    tol = 1e-12 if dtype == 'f64' else 3e-6
+    data, icov = torch.as_tensor(g['data']).to(cdt).cuda(), torch.as_tensor(g['icov']).to(rdt).cuda()
+    for tag, ic in (('icov', icov), ('noicov', None)):
+        pred = torch.as_tensor(g['pred']).to(cdt).cuda().requires_grad_(True)
+        c = ops.chisq(pred, data, ic)
+        assert abs(float(c.detach()) - float(g['sum_' + tag])) < tol * abs(float(g['sum_' + tag]))
+        (3.0 * c).backward()
+        assert relmax(pred.grad, 3.0 * g['gpred_' + tag]) < tol
+    rng = np.random.default_rng(0)
+    shape = (1, 1, 301, 7, 129)
+    p64 = torch.as_tensor(rng.normal(size=shape) + 1j * rng.normal(size=shape))
+    ic64 = T64(rng.uniform(0.5, 2.0, size=(1, 1, 301, 1, 129)))                 # broadcast over time
+    pr = p64.clone().requires_grad_(True)
+    ref = orc.chisq(pr, torch.zeros_like(pr), ic64)
+    ref.backward()
+    x = p64.to(cdt).cuda().requires_grad_(True)
+    c = ops.chisq(x, None, ic64.to(rdt).cuda())
+    assert abs(float(c.detach()) - float(ref.detach())) < tol * float(ref.detach())
+    c.backward()
+    assert relmax(x.grad, pr.grad) < tol
+    assert float(ops.chisq(x.detach(), None, ic64.to(rdt).cuda())) == float(c.detach())    # deterministic reduction
+    # the reference-named entry point: (chisq, res) of LogProb.forward_chisq
+    from bayeslim_amd import optim
+    c2, res = optim.forward_chisq(x.detach(), None, ic64.to(rdt).cuda())
+    assert res is None and float(c2) == float(c.detach())
+    c3, res3 = optim.forward_chisq(x.detach(), torch.zeros_like(x.detach()), ic64.to(rdt).cuda(), sum_chisq=False)
+    assert res3.shape == x.shape and abs(float(c3.sum()) - float(c.detach())) < 1e-5 * float(c.detach())

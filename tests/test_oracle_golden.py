@@ -278,3 +278,17 @@ def test_healpix_pix2ang_self_consistency():
         # equal-area pixelisation: mean of z is 0 and of z^2 is 1/3 up to O(1/nside^2)
         z = np.cos(th)
         assert abs(z.mean()) < 1e-12 and abs((z ** 2).mean() - 1 / 3) < 0.5 / nside ** 2 + 1e-12
+
+
+def test_chisq_diag_icov():
+    """chi-square epilogue (optim.apply_icov cov_axis=None + sum) against the imported reference"""
+    g = load_golden('chisq')
+    pred = torch.as_tensor(g['pred']).requires_grad_(True)
+    data, icov = torch.as_tensor(g['data']), torch.as_tensor(g['icov'])
+    for tag, ic in (('icov', icov), ('noicov', None)):
+        pred.grad = None
+        assert np.abs(orc.apply_icov_diag(pred - data, ic).detach().numpy() - g['chisq_' + tag]).max() < 1e-12
+        tot = orc.chisq(pred, data, ic)
+        assert abs(float(tot.detach()) - float(g['sum_' + tag])) < 1e-10 * abs(float(g['sum_' + tag]))
+        tot.backward()
+        assert np.abs(pred.grad.numpy() - g['gpred_' + tag]).max() < 1e-12
