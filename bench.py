@@ -303,8 +303,8 @@ def cpu_baseline(inp, nbl_sample=48, bl_batch=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
     ap.add_argument('--nt', type=int, default=None, help='time steps per step (minibatch)')
     ap.add_argument('--nf', type=int, default=None, help='override the number of channels (e.g. one rank\'s share of c5)')
