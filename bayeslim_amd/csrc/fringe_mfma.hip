@@ -113,7 +113,9 @@ __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_
 //     gain: those shapes are bound by operand generation); > 8192 pixels per split (slower tail,
 //     3x the f32 accumulation error); a uniform branch that skips the sign masks (spills); one
 //     accumulator per imaginary-part unit with a negated Li fragment (4 % slower, the freed
-//     registers only change the schedule); antenna coordinates in LDS instead of registers (2 % slower).
+//     registers only change the schedule); antenna coordinates in LDS instead of registers (2 % slower);
+//     one LDS buffer with two barriers per 32- or 64-pixel panel and a rolling pixel prefetch (1-2 %
+//     slower).
 // Every block covers at most MF_SPLIT_PIX pixels and STORES its result (no read-modify-write):
 // f32 accumulation inside the MFMA chain stays below eps*sqrt(512), and the pixel splits are
 // summed (and transposed into the result layout) by reduce_vis_kernel in a fixed order.
