@@ -363,6 +363,23 @@ def fringe_sum(psky, geom):
     return _FringeSum.apply(psky, geom)
 
 
+def fringe_adjoint(gvis, geom, Npp=None, dtype=None):
+    """
+    The adjoint of fringe_sum for a REAL psky, without autograd:  out[t, 0, q, f, p] = Re sum_b
+    conj(F[b, t, f, p]) gvis[q, b, t, f] -- the map-making direction (visibilities -> pixels,
+    imaging.make_map).  gvis (Npp, Nbl, Nt, Nf) complex; returns (Nt, 1, Npp, Nf, Pstride) real.
+    """
+    _require_cuda(gvis)
+    assert gvis.is_complex() and gvis.dim() == 4 and geom.Nmp == 1
+    g = gvis.detach().contiguous()
+    Npp = g.shape[0] if Npp is None else Npp
+    assert tuple(g.shape) == (Npp, geom.Nbl, geom.Nt, geom.Nf)
+    rdt = torch.float32 if g.dtype == torch.complex64 else torch.float64
+    out = torch.empty((geom.Nt, 1, Npp, geom.Nf, geom.Pstride), dtype=rdt, device=g.device)
+    _fringe_call(geom, True, torch.view_as_real(g), out, Npp, False, _dense_strides(out))
+    return out
+
+
 def gen_fringe(blvecs, sdir, freqs, conj=False, dtype=torch.float32):
     """materialised fringe (Nbl, Nf, P) complex; blvecs (Nbl,3), sdir (3,P) float64 on the GPU"""
     _require_cuda(blvecs, sdir)

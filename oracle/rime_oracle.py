@@ -376,3 +376,25 @@ def chisq(pred, data, icov=None):
     """LogProb.forward_chisq's value (optim.py:1019-1027): sum of apply_icov(pred - data), real part"""
     tot = torch.sum(apply_icov_diag(pred - data, icov))
     return tot.real if torch.is_complex(tot) else tot
+
+
+def build_A(blvecs, zen, az, freqs, beam=None):
+    """imaging matrix of one time step, (Nbl, Nf, P): conj(fringe) [* beam] (imaging.py:251-296)"""
+    A = gen_fringe(blvecs, zen, az, freqs, conj=True)
+    return A if beam is None else A * beam
+
+
+def make_map(v, w, A):
+    """dirty map Re sum_b A (v w), (..., Nf, P) (imaging.py:717-736)"""
+    return torch.einsum('vfp,...vf->...fp', A, (v * w).to(A.dtype)).real
+
+
+def compute_Am(A, m):
+    """conj(A) @ m: the RIME forward of a map, (..., Nbl, Nf) (imaging.py:755-774)"""
+    return torch.einsum('vfp,...fp->...vf', A.conj(), m.to(A.dtype))
+
+
+def compute_Pm(A, w, m, D=None):
+    """P m = D A^T w (conj(A) m), (..., Nf, P) (imaging.py:777-815)"""
+    Pm = torch.einsum('vfp,...vf->...fp', A, w * compute_Am(A, m)).real
+    return Pm if D is None else Pm * D

@@ -623,6 +623,34 @@ def gen_chisq(ba):
     save('chisq', pred=pred, data=data, icov=icov, **out)
 
 
+def gen_imaging(ba):
+    """map-making arithmetic of imaging.py on one time step: A = conj(fringe) * beam as VisMapper.build_A
+    builds it (imaging.py:251-296), then make_map (:717-736), compute_Am (:755-774) and compute_Pm
+    (:777-815) -- the adjoint / forward uses of the RIME fringe"""
+    import importlib
+    imaging = importlib.import_module('bayeslim.imaging')
+    rng = np.random.default_rng(11)
+    Nant, Nf, P = 9, 6, 140
+    ant = rng.normal(0, 40.0, (Nant, 3)); ant[:, 2] *= 0.02
+    pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
+    blvecs = np.stack([ant[j] - ant[i] for i, j in pairs])
+    freqs = np.linspace(120e6, 180e6, Nf)
+    zen, az = random_dirs(rng, P, zen_max=89.0)
+    antpos = ba.utils.AntposDict(list(range(Nant)), ant)
+    arr = ba.telescope_model.ArrayModel(antpos, freqs=torch.as_tensor(freqs), cache_s=False)
+    beam = torch.as_tensor(np.exp(-0.5 * (zen / 25.0) ** 2)[None, :] * (1.0 + 0.05 * rng.normal(size=(Nf, P))))
+    A = arr.gen_fringe(torch.as_tensor(blvecs), torch.as_tensor(zen), torch.as_tensor(az), conj=True) * beam
+    Nbl = len(pairs)
+    v = torch.as_tensor(rng.normal(size=(2, Nbl, Nf)) + 1j * rng.normal(size=(2, Nbl, Nf)))     # two maps
+    w = torch.as_tensor(rng.uniform(0.2, 2.0, size=(Nbl, Nf)))
+    m = torch.as_tensor(rng.normal(size=(2, Nf, P)))
+    D = torch.as_tensor(rng.uniform(0.5, 1.5, size=(Nf, P)))
+    save('imaging', antpos=ant, pairs=np.asarray(pairs), blvecs=blvecs, freqs=freqs, zen=zen, az=az, beam=beam,
+         v=v, w=w, m=m, D=D, A_checksum=torch.stack([A.real.sum(), A.imag.sum(), (A.abs() ** 2).sum()]),
+         dirty=imaging.make_map(v, w, A), Am=imaging.compute_Am(A, m.to(A.dtype)),   # (a real m raises in einsum)
+         Pm=imaging.compute_Pm(A, w, m, D=D))
+
+
 def main():
     torch.set_default_dtype(torch.float64)
     torch.manual_seed(0)
@@ -632,6 +660,7 @@ def main():
             globals()[name](ba)
         return
     gen_chisq(ba)
+    gen_imaging(ba)
     gen_fringe_cases(ba)
     gen_apply_beam_cases(ba)
     gen_interp_cases(ba)

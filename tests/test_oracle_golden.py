@@ -292,3 +292,15 @@ def test_chisq_diag_icov():
         assert abs(float(tot.detach()) - float(g['sum_' + tag])) < 1e-10 * abs(float(g['sum_' + tag]))
         tot.backward()
         assert np.abs(pred.grad.numpy() - g['gpred_' + tag]).max() < 1e-12
+
+
+def test_imaging_functions():
+    """map-making arithmetic (imaging.make_map / compute_Am / compute_Pm on A = conj(fringe) * beam)"""
+    g = load_golden('imaging')
+    T = lambda k: torch.as_tensor(g[k])
+    A = orc.build_A(T('blvecs'), T('zen'), T('az'), T('freqs'), T('beam'))
+    chk = torch.stack([A.real.sum(), A.imag.sum(), (A.abs() ** 2).sum()]).numpy()
+    assert np.abs(chk - g['A_checksum']).max() < 1e-9 * np.abs(g['A_checksum']).max()
+    assert np.abs(orc.make_map(T('v'), T('w'), A).numpy() - g['dirty']).max() < 1e-11 * np.abs(g['dirty']).max()
+    assert np.abs(orc.compute_Am(A, T('m')).numpy() - g['Am']).max() < 1e-11 * np.abs(g['Am']).max()
+    assert np.abs(orc.compute_Pm(A, T('w'), T('m'), T('D')).numpy() - g['Pm']).max() < 1e-11 * np.abs(g['Pm']).max()
