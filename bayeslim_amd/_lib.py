@@ -47,6 +47,8 @@ SIGNATURES = {
     'rime_chisq_workspace': (_sz, []),
     'rime_chisq_fwd': (_i, [_i, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     'rime_chisq_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    'rime_apply_cal_fwd': (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _vp, _vp]),
+    'rime_apply_cal_bwd': (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _vp, _vp, _vp, _vp]),
     'rime_alm2pix_fwd_workspace': (_sz, [_i, _i, _i, _i]),
     'rime_alm2pix_fwd': (_i, [_i, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'rime_alm2pix_bwd_workspace': (_sz, [_i, _i, _i, _i]),

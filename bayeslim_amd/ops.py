@@ -552,6 +552,84 @@ def chisq(pred, data=None, icov=None):
 
 
 # ---------------------------------------------------------------------------------------
+def _antenna_incidence(idx, Nant, dtype):
+    """dense 0/1 [Nant, Nbl] matrix of which baselines an antenna slot takes part in (cached on idx)"""
+    tag = getattr(idx, '_rime_incidence', None)
+    if tag is not None and tag[0] == (idx._version, Nant, dtype):
+        return tag[1]
+    M = torch.zeros(Nant, idx.numel(), dtype=dtype, device=idx.device)
+    M[idx.long(), torch.arange(idx.numel(), device=idx.device)] = 1
+    try:
+        idx._rime_incidence = ((idx._version, Nant, dtype), M)
+    except Exception:
+        pass
+    return M
+
+
+class _ApplyCal(torch.autograd.Function):
+    """V' = G1 V G2^dagger in one pass over the visibilities; backward in one pass + two incidence products"""
+    @staticmethod
+    def forward(ctx, vis, gains, a1, a2, diag):
+        _require_cuda(vis, gains, a1, a2)
+        assert vis.is_complex() and gains.is_complex(), 'complex visibilities and gains'
+        NP = vis.shape[0]
+        assert vis.ndim == 5 and gains.ndim == 5 and vis.shape[:2] == (NP, NP) and gains.shape[:2] == (NP, NP)
+        assert NP in (1, 2), 'Npol must be 1 or 2'
+        _, _, Nbl, Nt, Nf = vis.shape
+        Nant, Ntg, Nfg = gains.shape[2:]
+        assert Ntg in (1, Nt) and Nfg in (1, Nf), 'gains must match or broadcast over time / channel'
+        assert a1.dtype == torch.int32 and a2.dtype == torch.int32 and a1.numel() == Nbl and a2.numel() == Nbl
+        v = vis.detach().contiguous()
+        g = gains.detach().to(v.dtype).contiguous()
+        code, _ = _real_dtype(v)
+        st = (Nant * Ntg * Nfg, Ntg * Nfg, Nfg if Ntg > 1 else 0, 1 if Nfg > 1 else 0)
+        out = torch.empty_like(v)
+        rc = lib.rime_apply_cal_fwd(code, NP, int(bool(diag)), _ptr(torch.view_as_real(v)), _ptr(torch.view_as_real(g)),
+                                    _ptr(a1), _ptr(a2), Nbl, Nt, Nf, Nant, *st, _ptr(torch.view_as_real(out)), _stream())
+        check(rc, 'rime_apply_cal_fwd')
+        ctx.saved = (v, g, a1, a2, st, bool(diag), gains.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        v, g, a1, a2, st, diag, gdt = ctx.saved
+        NP, _, Nbl, Nt, Nf = v.shape
+        Nant, Ntg, Nfg = g.shape[2:]
+        code, rdt = _real_dtype(v)
+        go = gout.detach().to(v.dtype).contiguous()
+        gvis = torch.empty_like(v)
+        d = torch.empty((2,) + tuple(v.shape), dtype=v.dtype, device=v.device)
+        rc = lib.rime_apply_cal_bwd(code, NP, int(diag), _ptr(torch.view_as_real(v)), _ptr(torch.view_as_real(g)),
+                                    _ptr(torch.view_as_real(go)), _ptr(a1), _ptr(a2), Nbl, Nt, Nf, Nant, *st,
+                                    _ptr(torch.view_as_real(gvis)), _ptr(torch.view_as_real(d[0])),
+                                    _ptr(torch.view_as_real(d[1])), _stream())
+        check(rc, 'rime_apply_cal_bwd')
+        ggains = None
+        if ctx.needs_input_grad[1]:
+            dr = torch.view_as_real(d).reshape(2, NP * NP, Nbl, Nt * Nf * 2)
+            gg = torch.matmul(_antenna_incidence(a1, Nant, rdt), dr[0])
+            gg += torch.matmul(_antenna_incidence(a2, Nant, rdt), dr[1])
+            gg = torch.view_as_complex(gg.reshape(NP, NP, Nant, Nt, Nf, 2))
+            if Ntg == 1 and Nt > 1:
+                gg = gg.sum(3, keepdim=True)
+            if Nfg == 1 and Nf > 1:
+                gg = gg.sum(4, keepdim=True)
+            ggains = gg.to(gdt)
+        return (gvis if ctx.needs_input_grad[0] else None), ggains, None, None, None
+
+
+def apply_cal(vis, gains, a1, a2, diag=False):
+    """
+    V'[p, q, b, t, f] = sum G1[p, r] V[r, s] conj(G2[q, s]) with G1 = gains[:, :, a1[b]], G2 = gains[:, :, a2[b]]
+    (calibration._apply_cal, calibration.py:2412-2487, complex visibilities).  vis (Np, Np, Nbl, Nt, Nf)
+    complex; gains (Np, Np, Nant, Nt | 1, Nf | 1) complex; a1, a2 int32 [Nbl] on the GPU.  diag: only the
+    diagonal products, off-diagonal results zero (the reference's '2pol' mode).  Differentiable w.r.t.
+    vis and gains.
+    """
+    return _ApplyCal.apply(vis, gains, a1, a2, diag)
+
+
+# ---------------------------------------------------------------------------------------
 ALM_SPLIT_F16 = True        # float32: f16 hi/lo split operands on the f16 matrix cores (22 bits) instead
                             # of the exact-f32 MFMA kernels (set False to force those)
 

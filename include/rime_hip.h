@@ -244,6 +244,27 @@ int rime_chisq_fwd(int dtype, const void* pred, const void* data, const void* ic
 int rime_chisq_bwd(int dtype, const void* pred, const void* data, const void* icov, const void* g,
                    size_t N, void* gpred, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Gain application  V' = G1 V G2^dagger  per (baseline, time, channel) -- the post-RIME calibration
+ * step, calibration._apply_cal (calibration.py:2412-2487; complex visibilities, no undo / covariance),
+ * SURVEY section 8(f) item 3.  NP = 1 (1-pol) or 2; diag != 0 with NP = 2 is the reference's '2pol' mode
+ * (diagonal products only, off-diagonal results zero: linalg.diag_matmul, linalg.py:116-149).
+ *   vis, out, gout, gvis, d1, d2   T [NP][NP][Nbl][Nt][Nf][2]   contiguous, interleaved complex
+ *   gains                          complex T, element (p, q, a, t, f) at complex offset
+ *                                  (p*NP+q)*gst_p + a*gst_a + t*gst_t + f*gst_f  (0 strides broadcast)
+ *   a1, a2                         int32 [Nbl]   antenna slots of each baseline (< Nant)
+ * Backward (torch's conjugate-gradient convention): gvis = G1^dagger gout G2 and the PER-BASELINE gain
+ * gradients d1 = gout (V G2^dagger)^dagger (belongs to antenna a1), d2 = gout^dagger (G1 V) (to a2); the
+ * caller reduces d1 / d2 over the baselines of each antenna (and over broadcast axes).
+ * ------------------------------------------------------------------------------------- */
+int rime_apply_cal_fwd(int dtype, int NP, int diag, const void* vis, const void* gains, const int* a1,
+                       const int* a2, int Nbl, int Nt, int Nf, int Nant, long long gst_p, long long gst_a,
+                       long long gst_t, long long gst_f, void* out, void* stream);
+int rime_apply_cal_bwd(int dtype, int NP, int diag, const void* vis, const void* gains, const void* gout,
+                       const int* a1, const int* a2, int Nbl, int Nt, int Nf, int Nant, long long gst_p,
+                       long long gst_a, long long gst_t, long long gst_f, void* gvis, void* d1, void* d2,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -398,3 +398,23 @@ def compute_Pm(A, w, m, D=None):
     """P m = D A^T w (conj(A) m), (..., Nf, P) (imaging.py:777-815)"""
     Pm = torch.einsum('vfp,...vf->...fp', A, w * compute_Am(A, m)).real
     return Pm if D is None else Pm * D
+
+
+def apply_cal(vis, gains, g1_idx, g2_idx, cal_2pol=False):
+    """
+    calibration._apply_cal for complex visibilities without undo / covariance
+    (calibration.py:2412-2487): V'_pq = G_p V_pq G_q^dagger.  vis (Np, Np, Nbl, Nt, Nf); gains
+    (Np, Np, Nant, Nt|1, Nf|1); 1-pol and 2-pol (cal_2pol: diagonal products only, off-diagonals of
+    the result zero -- linalg.diag_matmul :116-149); 4-pol full 2x2 products.
+    """
+    g1 = gains.index_select(2, torch.as_tensor(g1_idx))
+    g2 = gains.index_select(2, torch.as_tensor(g2_idx))
+    if vis.shape[0] == 1:
+        return g1 * g2.conj() * vis
+    if cal_2pol:
+        G = g1 * g2.conj()
+        out = torch.zeros_like(vis)
+        out[0, 0] = G[0, 0] * vis[0, 0]
+        out[1, 1] = G[1, 1] * vis[1, 1]
+        return out
+    return torch.einsum('ab...,bc...,dc...->ad...', g1, vis, g2.conj())

@@ -651,6 +651,45 @@ def gen_imaging(ba):
          Pm=imaging.compute_Pm(A, w, m, D=D))
 
 
+def gen_apply_cal(ba):
+    """gain application G_p V G_q^dagger of calibration._apply_cal (calibration.py:2412-2487), 'com'
+    visibilities, 1-pol / 2-pol (diagonal) / 4-pol, with gradients w.r.t. visibilities and gains.
+    calibration.py does not parse under Python 3.10 (a py>=3.11 construct at :2279), so the function
+    is executed from its own source lines, read from the reference checkout at generation time."""
+    src = open(os.path.join(REF, 'calibration.py')).read().split('\n')
+    i0 = next(i for i, l in enumerate(src) if l.startswith('def _apply_cal('))
+    i1 = next(i for i in range(i0 + 1, len(src)) if src[i].startswith('def '))
+    ns = {'torch': torch, 'linalg': ba.linalg, 'np': np}
+    exec(compile('\n'.join(src[i0:i1]), 'calibration.py:_apply_cal', 'exec'), ns)
+    apply_cal = ns['_apply_cal']
+    rng = np.random.default_rng(13)
+    Nant, Nt, Nf = 6, 3, 4
+    pairs = [(i, j) for i in range(Nant) for j in range(i, Nant)]
+    pairs = pairs[::2] + [(3, 1), (5, 0)]
+    g1_idx = torch.as_tensor([p[0] for p in pairs])
+    g2_idx = torch.as_tensor([p[1] for p in pairs])
+    Nbl = len(pairs)
+
+    def rc(*shape):
+        return torch.as_tensor(rng.normal(size=shape) + 1j * rng.normal(size=shape))
+
+    out = dict(g1_idx=g1_idx, g2_idx=g2_idx)
+    for tag, npol, two, gshape in [('1pol', 1, False, (1, 1, Nant, Nt, Nf)), ('1pol_bcast', 1, False, (1, 1, Nant, 1, Nf)),
+                                    ('2pol', 2, True, (2, 2, Nant, Nt, Nf)), ('4pol', 2, False, (2, 2, Nant, Nt, Nf))]:
+        vis = rc(npol, npol, Nbl, Nt, Nf).requires_grad_(True)
+        gains = rc(*gshape)
+        if two:                                   # diagonal gains: off-diagonals are dropped by diag_matmul
+            gains[0, 1] = 0
+            gains[1, 0] = 0
+        gains.requires_grad_(True)
+        vout, _ = apply_cal(vis, gains, g1_idx, g2_idx, cal_2pol=two)
+        cot = rc(*vout.shape)
+        (vout * cot.conj()).real.sum().backward()
+        out.update({'vis_' + tag: vis, 'gains_' + tag: gains, 'vout_' + tag: vout, 'cot_' + tag: cot,
+                    'gvis_' + tag: vis.grad, 'ggains_' + tag: gains.grad})
+    save('apply_cal', **out)
+
+
 def main():
     torch.set_default_dtype(torch.float64)
     torch.manual_seed(0)
@@ -661,6 +700,7 @@ def main():
         return
     gen_chisq(ba)
     gen_imaging(ba)
+    gen_apply_cal(ba)
     gen_fringe_cases(ba)
     gen_apply_beam_cases(ba)
     gen_interp_cases(ba)

@@ -304,3 +304,16 @@ def test_imaging_functions():
     assert np.abs(orc.make_map(T('v'), T('w'), A).numpy() - g['dirty']).max() < 1e-11 * np.abs(g['dirty']).max()
     assert np.abs(orc.compute_Am(A, T('m')).numpy() - g['Am']).max() < 1e-11 * np.abs(g['Am']).max()
     assert np.abs(orc.compute_Pm(A, T('w'), T('m'), T('D')).numpy() - g['Pm']).max() < 1e-11 * np.abs(g['Pm']).max()
+
+
+def test_apply_cal():
+    """gain application G_p V G_q^dagger against the reference function, value and both gradients"""
+    g = load_golden('apply_cal')
+    for tag, two in (('1pol', False), ('1pol_bcast', False), ('2pol', True), ('4pol', False)):
+        vis = torch.as_tensor(g['vis_' + tag]).requires_grad_(True)
+        gains = torch.as_tensor(g['gains_' + tag]).requires_grad_(True)
+        out = orc.apply_cal(vis, gains, g['g1_idx'], g['g2_idx'], cal_2pol=two)
+        assert np.abs(out.detach().numpy() - g['vout_' + tag]).max() < 1e-12
+        (out * torch.as_tensor(g['cot_' + tag]).conj()).real.sum().backward()
+        assert np.abs(vis.grad.numpy() - g['gvis_' + tag]).max() < 1e-12
+        assert np.abs(gains.grad.numpy() - g['ggains_' + tag]).max() < 1e-11
