@@ -115,7 +115,10 @@ __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_
 //     accumulator per imaginary-part unit with a negated Li fragment (4 % slower, the freed
 //     registers only change the schedule); antenna coordinates in LDS instead of registers (2 % slower);
 //     one LDS buffer with two barriers per 32- or 64-pixel panel and a rolling pixel prefetch (1-2 %
-//     slower).
+//     slower); same-wave interleave of the next panel's generation with the MFMAs (the ~3 VALU slots
+//     that hide under each MFMA of the same wave, forced with sched_group_barrier on a branch-free
+//     generate): 40 spilled registers at 2 waves per SIMD, and with 1 wave per SIMD (accumulators in
+//     AGPRs, no spills) LDS latency and barriers are exposed: 13.0-13.5 ms against 10.7.
 // Every block covers at most MF_SPLIT_PIX pixels and STORES its result (no read-modify-write):
 // f32 accumulation inside the MFMA chain stays below eps*sqrt(512), and the pixel splits are
 // summed (and transposed into the result layout) by reduce_vis_kernel in a fixed order.
