@@ -96,8 +96,9 @@ class FringeGeometry:
         self.ant = None
         if ant_like is not None and ant_like.ant is not None and ant_like.Nbl == self.Nbl:
             # same baseline set as an existing geometry (another time minibatch): share its pair tables
-            tiles = ant_like.ant['tiles']
-            self.ant = dict(ant_like.ant, mfma_flops=self.Nt * self.Nf * (self.Pstride // 16) * tiles * 12 * 32768)
+            per16 = self.Nt * self.Nf * (self.Pstride // 16) * 32768
+            self.ant = dict(ant_like.ant, mfma_flops_fwd=per16 * ant_like.ant['mfma_fwd'],
+                            mfma_flops_bwd=per16 * ant_like.ant['mfma_bwd'])
             if self.Nt > 65535:
                 self.ant = None
         elif antpos is not None and bl_ants is not None and mfma in ('auto', True):
@@ -264,26 +265,30 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False):
     if not torch.allclose(pos[i2] - pos[i1], self.blvecs, rtol=0, atol=1e-9):
         return
     dev = self.blvecs.device
-    blocks, tiles = [], 0
+    blocks, tiles, mfma_fwd = [], 0, 0
     for (gi, gj) in sorted(tabs):
         direct, conj = tabs[(gi, gj)]
         pi = pos[gi * MFMA_GROUP:min((gi + 1) * MFMA_GROUP, Nant)]
         if gi == gj:
             rows, TA = pi.contiguous(), (pi.shape[0] + 31) // 32
             tiles += TA * (TA + 1) // 2
+            mfma_fwd += 12 * (TA * (TA - 1) // 2) + 7 * TA      # diagonal tiles: symmetric products folded
         else:
             pj = pos[gj * MFMA_GROUP:min((gj + 1) * MFMA_GROUP, Nant)]
             rows = torch.zeros(2 * MFMA_GROUP, 3, dtype=torch.float64, device=pos.device)
             rows[:pi.shape[0]] = pi
             rows[MFMA_GROUP:MFMA_GROUP + pj.shape[0]] = pj
             tiles += 16
+            mfma_fwd += 12 * 16
         blocks.append(dict(pos=rows, nrows=int(rows.shape[0]), cross=int(gi != gj),
                            direct=torch.as_tensor(direct.reshape(-1), device=dev),
                            conj=torch.as_tensor(conj.reshape(-1), device=dev)))
-    # executed matrix-core work per pass (forward == backward): per 16 pixels, 12 MFMAs of
-    # 2*32*32*16 flop on each 32x32 antenna tile of every block
-    mfma_flops = self.Nt * self.Nf * (self.Pstride // 16) * tiles * 12 * 32768
-    self.ant = dict(blocks=blocks, Nant=Nant, tiles=tiles, mfma_flops=mfma_flops)
+    # executed matrix-core work per pass: per 16 pixels, 12 MFMAs of 2*32*32*16 flop on each 32x32
+    # antenna tile of every block (3 hi/lo products x 4 real products); the forward runs 7 on the
+    # diagonal tiles of a diagonal block
+    per16 = self.Nt * self.Nf * (self.Pstride // 16) * 32768
+    self.ant = dict(blocks=blocks, Nant=Nant, tiles=tiles, mfma_fwd=mfma_fwd, mfma_bwd=12 * tiles,
+                    mfma_flops_fwd=per16 * mfma_fwd, mfma_flops_bwd=per16 * 12 * tiles)
 
 
 FringeGeometry._setup_antenna_path = _setup_antenna_path
@@ -299,7 +304,7 @@ def _fringe_call(geom, backward, inp, out, Npp, cplx, strides=None):
         if prof is not None:
             e1.record()
             prof.append(('fringe_ant_bwd_kernel' if backward else 'fringe_ant_fwd_kernel', e0, e1, geom.elements,
-                         geom.ant['mfma_flops'] * nlaunch))
+                         geom.ant['mfma_flops_bwd' if backward else 'mfma_flops_fwd'] * nlaunch))
         return
     code, rdt = _real_dtype(inp)
     fn = lib.rime_fringe_sum_bwd if backward else lib.rime_fringe_sum_fwd

@@ -415,7 +415,8 @@ def main():
         algorithmic = elems * flop_per_elem / (ms * 1e-3) / 1e12
         if mflops > 0:
             # antenna-factored kernels: bounded by the f16 matrix cores; count the MFMA flops they
-            # execute (3 hi/lo cross products on the upper-triangular antenna tiles)
+            # execute (3 hi/lo cross products on the upper-triangular antenna tiles; the forward folds the
+            # symmetric products of the diagonal tiles: 7 instead of 12 MFMAs there)
             achieved, peak, pipe = mflops / (ms * 1e-3) / 1e12, F16_MFMA_PEAK_TFLOPS, 'f16 MFMA (v_mfma_f32_32x32x16_f16), executed flops'
         else:
             achieved, peak, pipe = algorithmic, FP32_PEAK_TFLOPS, 'fp32 vector ALU (== fp32 MFMA dense peak), algorithmic flops'

@@ -21,7 +21,7 @@ psky = (torch.randn(Nt, 1, 1, Nf, P, device='cuda') * 1e-3).requires_grad_(True)
 gm = ops.FringeGeometry(blvecs, sdir, freqs, antpos=torch.as_tensor(ant).cuda(), bl_ants=pairs, mfma=True)
 gv = ops.FringeGeometry(blvecs, sdir, freqs)
 print('Nant %d Nbl %d Nf %d P %d Nt %d: %d blocks, %.3g executed MFMA flop/pass' % (
-    Nant, len(pairs), Nf, P, Nt, len(gm.ant['blocks']), gm.ant['mfma_flops']))
+    Nant, len(pairs), Nf, P, Nt, len(gm.ant['blocks']), gm.ant['mfma_flops_fwd']))
 
 
 def timeit(geom, reps=3):
@@ -40,7 +40,7 @@ def timeit(geom, reps=3):
 
 fm, bm, vm, gmg = timeit(gm)
 fv, bv, vv, gvg = timeit(gv)
-print('matrix cores : fwd %.2f ms  bwd %.2f ms  (%.0f TFLOP/s executed fwd)' % (fm, bm, gm.ant['mfma_flops'] / fm / 1e9))
+print('matrix cores : fwd %.2f ms  bwd %.2f ms  (%.0f TFLOP/s executed fwd)' % (fm, bm, gm.ant['mfma_flops_fwd'] / fm / 1e9))
 print('vector ALU   : fwd %.2f ms  bwd %.2f ms' % (fv, bv))
 print('agreement    : vis %.2e  grad %.2e (of max)' % (float((vm - vv).abs().max() / vv.abs().max()),
                                                       float((gmg - gvg).abs().max() / gvg.abs().max())))
