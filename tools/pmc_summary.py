@@ -1,0 +1,67 @@
+"""
+Summarise rocprofv3 --pmc passes (one counter_collection.csv per pass) into per-kernel means.
+usage: python tools/pmc_summary.py OUT.json PASS_DIR [PASS_DIR ...]
+Per dispatch the rows of a counter (one per hardware instance / dimension) are summed; per kernel the
+dispatches of its larger half by duration are averaged (the C4 step launches every fringe kernel on
+the diffuse component and on the 10x smaller point-source component).  FETCH_SIZE / WRITE_SIZE are in
+KB; on gfx950 FETCH_SIZE counts 64-B requests as 32 B (MI355X_MICROARCH.md): hbm bytes = (2 FETCH +
+WRITE) * 1024.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace('void ', '').replace('rime::', '')
+    return name.split('(')[0]
+
+
+def main():
+    out, dirs = sys.argv[1], sys.argv[2:]
+    per = defaultdict(lambda: defaultdict(dict))      # kernel -> counter -> dispatch -> value
+    dur = defaultdict(dict)                            # kernel -> dispatch -> ns
+    for d in dirs:
+        for path in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            tag = os.path.basename(os.path.normpath(d))
+            for row in csv.DictReader(open(path)):
+                k, c = short(row['Kernel_Name']), row['Counter_Name']
+                did = (tag, row['Dispatch_Id'])
+                per[k][c][did] = per[k][c].get(did, 0.0) + float(row['Counter_Value'])
+                if row.get('Start_Timestamp') and row.get('End_Timestamp'):
+                    dur[k][did] = float(row['End_Timestamp']) - float(row['Start_Timestamp'])
+    res = {}
+    for k in per:
+        if not any(s in k for s in ('fringe', 'reduce_vis', 'transpose_gvis', 'interp', 'beam_sky', 'sky_gather')):
+            continue
+        entry = {}
+        for c, vals in per[k].items():
+            ids = sorted(vals, key=lambda i: dur[k].get(i, 0.0), reverse=True)
+            big = ids[:max(1, len(ids) // 2)]
+            entry[c] = sum(vals[i] for i in big) / len(big)
+            if c in ('FETCH_SIZE', 'WRITE_SIZE'):
+                entry[c + '_all_launches'] = sum(vals.values()) / len(vals)
+            entry.setdefault('duration_ms', sum(dur[k].get(i, 0.0) for i in big) / len(big) / 1e6)
+            entry['launches_averaged'] = len(big)
+        if 'FETCH_SIZE' in entry and 'WRITE_SIZE' in entry:
+            # bench.py's avg_launch_ms is the mean over ALL launches of a kernel: so is hbm_bytes_per_launch
+            entry['hbm_bytes_per_launch'] = (2 * entry['FETCH_SIZE_all_launches'] + entry['WRITE_SIZE_all_launches']) * 1024
+            entry['hbm_bytes_per_launch_larger_half'] = (2 * entry['FETCH_SIZE'] + entry['WRITE_SIZE']) * 1024
+        if 'GRBM_GUI_ACTIVE' in entry and 'SQ_VALU_MFMA_BUSY_CYCLES' in entry:
+            simd_cycles = entry['GRBM_GUI_ACTIVE'] / 8 * 1024          # 8 XCD copies of the clock; 256 CUs x 4 SIMDs
+            entry['clock_GHz'] = entry['GRBM_GUI_ACTIVE'] / 8 / (entry['duration_ms'] * 1e6)
+            entry['mfma_busy_frac_of_simd_cycles'] = entry['SQ_VALU_MFMA_BUSY_CYCLES'] / simd_cycles
+            if 'SQ_ACTIVE_INST_VALU' in entry and 'SQ_INSTS_MFMA' in entry:
+                # SQ_ACTIVE_INST_VALU counts 4-cycle issue slots, an MFMA takes one of them
+                entry['valu_issue_frac_of_simd_cycles'] = (entry['SQ_ACTIVE_INST_VALU'] - entry['SQ_INSTS_MFMA']) * 4 / simd_cycles
+        res[k] = entry
+    json.dump(res, open(out, 'w'), indent=1)
+    for k, e in res.items():
+        print(k, {c: (round(v, 4) if isinstance(v, float) else v) for c, v in e.items()})
+
+
+if __name__ == '__main__':
+    main()
