@@ -205,13 +205,14 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     const int tid = threadIdx.x, lane = tid & 63;
     // 1-D grid, channel fastest: blocks that run together share (t, split), i.e. the same pointing
     // vectors (L2 hits), and no grid dimension hits the 65535 cap
-    const int f = blockIdx.x % A.Nf, ts = blockIdx.x / A.Nf;
-    const int t = ts / A.S, split = ts % A.S;
+    const int f = __builtin_amdgcn_readfirstlane(blockIdx.x % A.Nf), ts = blockIdx.x / A.Nf;
+    const int t = __builtin_amdgcn_readfirstlane(ts / A.S), split = __builtin_amdgcn_readfirstlane(ts % A.S);
 
     const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
     const float scl = A.scale[t * A.Nf + f];
     const float* arow = A.psky + (size_t)t * A.st_t + (size_t)f * A.st_f;
     const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
+    const int st_p = __builtin_amdgcn_readfirstlane((int)A.st_p);
 
     // generation mapping: lane = (pixel pair pp, antenna slot ag); rows of one ds_write are 2 apart
     // (80-B rows: 8 rows x 32 B land in 16 distinct 16-B granules of the 64 banks)
@@ -237,18 +238,24 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
         for (int e = 0; e < 16; ++e) { acc[s][0][e] = 0.f; acc[s][1][e] = 0.f; }
 
     const int npanel = A.Pstride / MF_KP;
-    const int pbeg = split * A.panels_per_split;
-    const int pend = min(npanel, pbeg + A.panels_per_split);
+    const int pbeg = __builtin_amdgcn_readfirstlane(split * A.panels_per_split);
+    const int pend = __builtin_amdgcn_readfirstlane(min(npanel, pbeg + A.panels_per_split));
     if (pbeg >= pend) return;                        // uniform over the block
 
+    // panel fetch: wave-uniform bases (scalar address arithmetic) + constant 32-bit lane offsets;
+    // psky is read as two dwords with the runtime pixel stride (a branch on the stride makes the
+    // compiler issue both variants with 64-bit vector multiplies: 17 % of the loop's VALU work)
     double2 sx[MF_NH], sy[MF_NH], sz[MF_NH]; float2 av[MF_NH];
+    const uint32_t lo_s = 16u * pp, lo_a0 = 8u * pp * (uint32_t)st_p, lo_a1 = lo_a0 + 4u * (uint32_t)st_p;
+    const double* sdy = sd + A.Pstride;
+    const double* sdz = sd + 2 * (size_t)A.Pstride;
     auto fetch = [&](int panel, int hf) {
-        const int p = panel * MF_KP + 16 * hf + 2 * pp;
-        sx[hf] = *reinterpret_cast<const double2*>(sd + p);
-        sy[hf] = *reinterpret_cast<const double2*>(sd + A.Pstride + p);
-        sz[hf] = *reinterpret_cast<const double2*>(sd + 2 * (size_t)A.Pstride + p);
-        if (A.st_p == 1) av[hf] = *reinterpret_cast<const float2*>(arow + p);
-        else av[hf] = make_float2(arow[(size_t)p * A.st_p], arow[(size_t)(p + 1) * A.st_p]);
+        const int p0 = panel * MF_KP + 16 * hf;      // uniform
+        sx[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sd + p0) + lo_s);
+        sy[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sdy + p0) + lo_s);
+        sz[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sdz + p0) + lo_s);
+        const char* ab = reinterpret_cast<const char*>(arow + (size_t)p0 * st_p);
+        av[hf] = make_float2(*reinterpret_cast<const float*>(ab + lo_a0), *reinterpret_cast<const float*>(ab + lo_a1));
     };
     auto generate = [&](unsigned char* buf, int next_panel) {
 #pragma unroll
