@@ -164,13 +164,21 @@ __host__ __device__ constexpr int tri_col(int TA, int idx) { int ti = 0; while (
 // order: 1, 2, 2, 2) -- every row tile a wave touches costs 16 sign-mask v_xor per K step
 __host__ __device__ constexpr int tri4_row(int t) { return t < 4 ? 0 : (t == 4 ? 3 : (t < 8 ? 1 : 2)); }
 __host__ __device__ constexpr int tri4_col(int t) { return t < 4 ? t : (t == 4 ? 3 : (t < 8 ? t - 4 : t - 6)); }
+// 33..64 antennas: the three tiles in the order (0,1) (0,0) (1,1) and the unit ranges [0,1) [1,2) [2,4)
+// [4,6): 6, 6, 7, 7 MFMAs per wave and K step (two units per wave in row-major order: 7, 12, 7, 0)
 template <class SH> __host__ __device__ constexpr int tile_row(int t)
 {
-    return SH::CROSS ? t / 4 : (SH::TA == 4 ? tri4_row(t) : tri_row(SH::TA, t));
+    return SH::CROSS ? t / 4 : (SH::TA == 4 ? tri4_row(t) : (SH::TA == 2 ? (t == 2 ? 1 : 0) : tri_row(SH::TA, t)));
 }
 template <class SH> __host__ __device__ constexpr int tile_col(int t)
 {
-    return SH::CROSS ? t % 4 : (SH::TA == 4 ? tri4_col(t) : tri_col(SH::TA, t));
+    return SH::CROSS ? t % 4 : (SH::TA == 4 ? tri4_col(t) : (SH::TA == 2 ? (t == 1 ? 0 : 1) : tri_col(SH::TA, t)));
+}
+// units [unit_begin(w), unit_begin(w + 1)) belong to wave w
+template <class SH> __host__ __device__ constexpr int unit_begin(int w)
+{
+    if (!SH::CROSS && SH::TA == 2) return w <= 2 ? w : (w == 3 ? 4 : 6);
+    return SH::UPW * w < SH::NU ? SH::UPW * w : SH::NU;
 }
 
 template <class SH> __host__ __device__ constexpr bool is_diag(int t) { return !SH::CROSS && tile_row<SH>(t) == tile_col<SH>(t); }
@@ -199,7 +207,7 @@ __device__ __forceinline__ void static_for(F&& f)
 template <class SH, int W, bool SIGNED>
 __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* smem)
 {
-    constexpr int NU = SH::NU, UPW = SH::UPW, U0 = UPW * W;
+    constexpr int NU = SH::NU, UPW = SH::UPW, U0 = unit_begin<SH>(W), UE = unit_begin<SH>(W + 1);   // this wave's units: [U0, UE)
     constexpr int MF_IMG = SH::IMG, MF_BUF = SH::BUF;
     constexpr int BROW = SH::CROSS ? 4 : 0;          // image row-tile offset of the column (B) side
     const int tid = threadIdx.x, lane = tid & 63;
@@ -296,7 +304,6 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
             if constexpr (SIGNED) { v.x ^= sg.x; v.y ^= sg.y; v.z ^= sg.z; v.w ^= sg.w; }
             return v;
         };
-        constexpr int UE = (U0 + UPW < NU) ? U0 + UPW : NU;          // this wave's units: [U0, UE)
         constexpr int T0 = U0 >> 1, T1 = (UE + 1) >> 1;               // its tiles: [T0, T1)
         // K step outermost: only one K step's row fragments are live at a time (16 registers fewer)
 #pragma unroll
@@ -394,7 +401,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
 #pragma unroll
     for (int s = 0; s < UPW; ++s) {
         const int u = U0 + s;
-        if (u < NU) {
+        if (u < UE) {
             const int ti = tile_row<SH>(u >> 1), tj = tile_col<SH>(u >> 1), im = u & 1;
             f32x16 val;
 #pragma unroll
