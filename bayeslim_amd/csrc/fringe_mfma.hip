@@ -593,6 +593,11 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                 float ec[16], es[16];                        // E of antennas 32 tj + (e&3) + 8 (e>>2) + 4 h
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
+                    if (32 * tj + 16 * ks >= A.Nant) {           // uniform: 16 padding antennas (G columns and rows are zero)
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) { ec[8 * ks + jj] = 0.f; es[8 * ks + jj] = 0.f; }
+                        continue;
+                    }
                     uint4 Erh, Erl, Eih, Eil;
                     uint32_t* erh = reinterpret_cast<uint32_t*>(&Erh); uint32_t* erl = reinterpret_cast<uint32_t*>(&Erl);
                     uint32_t* eih = reinterpret_cast<uint32_t*>(&Eih); uint32_t* eil = reinterpret_cast<uint32_t*>(&Eil);
@@ -724,6 +729,7 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
         for (int tj = 0; tj < 4; ++tj) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if (MF_NA + 32 * tj + 16 * ks >= A.Nant) continue;      // uniform: 16 padding antennas of group J (zero G columns)
                 uint4 Erh, Erl, Eih, Eil, Nrh, Nrl;
                 uint32_t* erh = reinterpret_cast<uint32_t*>(&Erh); uint32_t* erl = reinterpret_cast<uint32_t*>(&Erl);
                 uint32_t* eih = reinterpret_cast<uint32_t*>(&Eih); uint32_t* eil = reinterpret_cast<uint32_t*>(&Eil);
