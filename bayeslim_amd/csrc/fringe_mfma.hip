@@ -101,6 +101,8 @@ __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_
 //   * the 10 upper-triangular 32x32 tiles are dealt to the 4 waves as 20 (tile, re|im) units,
 //     5 each (a 3/3/2/2 deal of whole tiles idles 17 % of the pipe), in a tile order that lets two
 //     of the four waves touch a single row tile; every wave gets both units of one diagonal tile;
+//   * 33..64 antennas: a wave generates one 16-pixel half of the panel for every second row octet
+//     (half the pointing-vector loads and registers) and skips octets that are all padding (6-7 %);
 //   * diagonal tiles multiply an image by itself, so their lo x hi products are the transposes of
 //     the hi x lo ones and Li.Br is the transpose of Lr.Bi: 7 MFMAs per K step instead of 12 (25
 //     per wave and K step instead of 30), the transposes taken once in the epilogue through LDS
@@ -228,10 +230,17 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // rows of one sweep: 2 apart inside a wave (bank-conflict-free writes), waves interleaved
     const int grow = SH::NW == 8 ? 2 * ag + 16 * (W & 3) + (W >> 2)
                    : SH::NW == 4 ? 2 * ag + 16 * (W & 1) + (W >> 1) : 2 * ag + W;
-    double ax[SH::GEN], ay[SH::GEN], az[SH::GEN];
+    // 33..64 antennas (OCT): a wave generates ONE 16-pixel half of the panel (W & 1) for the rows
+    // 16 k + (W >> 1) + 2 ag, k = 0..3, and skips the k whose 8 rows are all padding: 37 antennas cost
+    // 3 sweeps per wave instead of 4 (padding rows of the images are never written: they only reach
+    // the result rows / columns of padding antennas, which have no baseline slot)
+    constexpr bool OCT = !SH::CROSS && SH::TA == 2;
+    constexpr int NGEN = OCT ? SH::ROWS / 16 : SH::GEN;
+    const int nk = OCT ? min(NGEN, (A.Nant - (W >> 1) + 15) / 16) : NGEN;     // uniform
+    double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
-    for (int u = 0; u < SH::GEN; ++u) {
-        const int an = SH::GROWS * u + grow;
+    for (int u = 0; u < NGEN; ++u) {
+        const int an = OCT ? 16 * u + (W >> 1) + 2 * ag : SH::GROWS * u + grow;
         const bool ok = an < A.Nant;
         ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
         ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
@@ -266,6 +275,33 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
         av[hf] = make_float2(*reinterpret_cast<const float*>(ab + lo_a0), *reinterpret_cast<const float*>(ab + lo_a1));
     };
     auto generate = [&](unsigned char* buf, int next_panel) {
+        if constexpr (OCT) {
+            constexpr int hf = W & 1;
+            const float w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
+            if (SIGNED && W < 2 && lane < 8)
+                *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
+                    ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
+#pragma unroll
+            for (int u = 0; u < NGEN; ++u) {
+                if (u < nk) {
+                    const double ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
+                    const double ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
+                    const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                    const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
+                    const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+                    uint32_t rh, rl, ih, il;
+                    split2(w0 * c0, w1 * c1, rh, rl);
+                    split2(w0 * s0, w1 * s1, ih, il);
+                    unsigned char* o = buf + (16 * u + (W >> 1) + 2 * ag) * MF_ROWB + pp * 4 + 32 * hf;
+                    *reinterpret_cast<uint32_t*>(o) = rh;
+                    *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+                    *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+                    *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+                }
+            }
+            fetch(next_panel, hf);
+            return;
+        }
 #pragma unroll
         for (int hf = 0; hf < MF_NH; ++hf) {
             const float w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
@@ -360,8 +396,11 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // two panels per trip: buffer addresses are compile-time offsets
     unsigned char* const buf0 = smem;
     unsigned char* const buf1 = smem + MF_BUF;
+    if constexpr (OCT) fetch(pbeg, W & 1);
+    else {
 #pragma unroll
-    for (int hf = 0; hf < MF_NH; ++hf) fetch(pbeg, hf);
+        for (int hf = 0; hf < MF_NH; ++hf) fetch(pbeg, hf);
+    }
     generate(buf0, min(pbeg + 1, pend - 1));
     __syncthreads();
 #if defined(RIME_ABL_NOGEN)        /* lab ablations (tools/fringe_mfma_lab.hip): never defined in the library build */
