@@ -49,6 +49,19 @@ class _AllGatherCat(torch.autograd.Function):
         world = len(counts)
         rank = dist.get_rank(group)
         nmax = max(counts)
+        ctx.counts, ctx.rank, ctx.dim = counts, rank, dim
+        if min(counts) == nmax and x.shape[dim] == nmax:
+            # equal blocks: one collective into a [world, ...] buffer, then a single re-layout (none at all
+            # when every axis before `dim` has length 1, i.e. the baseline-sharded visibility tensor)
+            xin = x.contiguous()
+            buf = torch.view_as_real(xin) if xin.is_complex() else xin
+            out = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
+            dist.all_gather_into_tensor(out.view(-1), buf.reshape(-1), group=group)     # flat: backends differ on shapes
+            if xin.is_complex():
+                out = torch.view_as_complex(out)
+            shape = list(x.shape)
+            shape[dim] = world * nmax
+            return out.movedim(0, dim).reshape(shape)
         pad = x
         if x.shape[dim] < nmax:
             padshape = list(x.shape)
@@ -63,7 +76,6 @@ class _AllGatherCat(torch.autograd.Function):
         else:
             parts = [torch.empty_like(pad) for _ in range(world)]
             dist.all_gather(parts, pad, group=group)
-        ctx.counts, ctx.rank, ctx.dim = counts, rank, dim
         return torch.cat([p.narrow(dim, 0, c) for p, c in zip(parts, counts)], dim=dim)
 
     @staticmethod
@@ -100,6 +112,14 @@ def all_gather_block_grads(param, dim, bounds, group=None):
     if param.grad is None:
         param.grad = torch.zeros_like(param)
     nmax = max(b - a for a, b in bounds)
+    g = param.grad
+    if (min(b - a for a, b in bounds) == nmax and g.is_contiguous() and not g.is_complex()
+            and all(n == 1 for n in g.shape[:dim]) and bounds[0][0] == 0 and bounds[-1][1] == g.shape[dim]):
+        # equal blocks that are contiguous runs of the gradient in rank order: in-place all-gather
+        flat = g.view(-1)
+        n = flat.numel() // world
+        dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n], group=group)
+        return
     blk = param.grad.narrow(dim, s, e - s)
     if e - s < nmax:
         padshape = list(blk.shape)

@@ -25,9 +25,11 @@ def _free_port():
     return p
 
 
-def _problem():
+def _problem(even=False):
     rng = np.random.default_rng(0)
     Nbl, Nf, P, Nt = 7, 5, 40, 2            # 7 baselines over 2 ranks: ragged shards (4 + 3)
+    if even:
+        Nbl, Nf = 6, 4                      # equal blocks: the single-buffer all-gather paths
     T = lambda x: torch.as_tensor(x, dtype=torch.float64)
     blvecs = T(rng.normal(0, 30, (Nbl, 3)))
     freqs = T(np.linspace(120e6, 180e6, Nf))
@@ -46,11 +48,11 @@ def _simulate(blvecs, freqs, zen, az, sky, beam):
     return torch.stack(out, dim=3)           # (1, 1, Nbl, Nt, Nf)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, even=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        blvecs, freqs, zen, az, sky, beam = _problem()
+        blvecs, freqs, zen, az, sky, beam = _problem(even)
         sky = sky.clone().requires_grad_(True)
         beam = beam.clone().requires_grad_(True)
         bounds = rdist.shard_bounds(len(blvecs), world)
@@ -70,12 +72,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_forward_backward_equals_single_process():
+@pytest.mark.parametrize('even', [False, True])
+def test_sharded_forward_backward_equals_single_process(even):
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, even)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
@@ -83,7 +86,7 @@ def test_sharded_forward_backward_equals_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     # single-process reference
-    blvecs, freqs, zen, az, sky, beam = _problem()
+    blvecs, freqs, zen, az, sky, beam = _problem(even)
     sky = sky.clone().requires_grad_(True)
     beam = beam.clone().requires_grad_(True)
     full = _simulate(blvecs, freqs, zen, az, sky, beam)
@@ -96,11 +99,11 @@ def test_sharded_forward_backward_equals_single_process():
         assert tot == 3.0
 
 
-def _worker_freq(rank, world, port, q):
+def _worker_freq(rank, world, port, q, even=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        blvecs, freqs, zen, az, sky, beam = _problem()
+        blvecs, freqs, zen, az, sky, beam = _problem(even)
         sky = sky.clone().requires_grad_(True)          # replicated full parameters
         beam = beam.clone().requires_grad_(True)
         bounds = rdist.shard_bounds(len(freqs), world)  # 5 channels over 2 ranks: 3 + 2
@@ -116,19 +119,20 @@ def _worker_freq(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_frequency_sharded_forward_backward_equals_single_process():
+@pytest.mark.parametrize('even', [False, True])
+def test_frequency_sharded_forward_backward_equals_single_process(even):
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_freq, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_freq, args=(r, world, port, q, even)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    blvecs, freqs, zen, az, sky, beam = _problem()
+    blvecs, freqs, zen, az, sky, beam = _problem(even)
     sky = sky.clone().requires_grad_(True)
     beam = beam.clone().requires_grad_(True)
     full = _simulate(blvecs, freqs, zen, az, sky, beam)
