@@ -174,7 +174,10 @@ template <class SH> __host__ __device__ constexpr int tile_row(int t)
 }
 template <class SH> __host__ __device__ constexpr int tile_col(int t)
 {
-    return SH::CROSS ? t % 4 : (SH::TA == 4 ? tri4_col(t) : (SH::TA == 2 ? (t == 1 ? 0 : 1) : tri_col(SH::TA, t)));
+    // 65..96 antennas: (0,1) (0,0) (0,2) (1,1) (1,2) (2,2) -- off-diagonal and diagonal tiles alternate, so the
+    // three-unit ranges cost 16, 15, 13, 13 MFMAs per K step (row-major order: 13, 18, 13, 13)
+    return SH::CROSS ? t % 4 : (SH::TA == 4 ? tri4_col(t) : (SH::TA == 2 ? (t == 1 ? 0 : 1)
+                              : (SH::TA == 3 && t < 2 ? 1 - t : tri_col(SH::TA, t))));
 }
 // units [unit_begin(w), unit_begin(w + 1)) belong to wave w
 template <class SH> __host__ __device__ constexpr int unit_begin(int w)
