@@ -536,7 +536,9 @@ fringe_ant_fwd_cross_kernel(AntArgs A)
 // No atomics.  History at the C4 shape: interleaved (re,im) K layout with rot90 of the G fragments
 // on the fly: 11.1 ms; this kernel 10.3 ms.  Tried and dropped: the tile count as a template
 // parameter (the accumulator zero-fill folds into the first MFMAs, 103 -> 22 v_mov, but the
-// schedule spills 9 registers: 3 % slower).
+// schedule spills 9 registers: 3 % slower; with a sched_barrier between row tiles it does not spill and
+// runs 13 % fewer VALU instructions -- at the same speed: moves and integer adds ride in the MFMA
+// shadow, the f64 phase and sin/cos instructions are what the matrix pipe waits for).
 // ---------------------------------------------------------------------------------------
 struct AntBwdArgs {
     const double* antpos; const double* sdir; const double* freqs;
@@ -619,6 +621,8 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
     const int tbeg = split * A.tiles_per_split;
     const int tend = min(ntile, tbeg + A.tiles_per_split);
 
+    uint32_t gl0 = (h * 32 + (lane & 31)) * 16, gl1 = gl0 + 3 * MB_PLANE;
+    asm volatile("" : "+v"(gl1));                     // opaque: keeps gl1 a second base register
     for (int pt = tbeg + wave; pt < tend; pt += 8) {
         const int p = pt * 32 + (lane & 31);
         const double sx = sd[p], sy = sd[A.Pstride + p], sz = sd[2 * (size_t)A.Pstride + p];
@@ -659,13 +663,15 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
 #pragma unroll
                     for (int ti = 0; ti < 4; ++ti) {
                         if (ti <= tj) {
-                            const int off = (((tri_index(ti, tj) * 2 + ks) * 2 + h) * 32 + (lane & 31)) * 16;
-                            const uint4 Grh = *reinterpret_cast<const uint4*>(g_img + 0 * MB_PLANE + off);
-                            const uint4 Gih = *reinterpret_cast<const uint4*>(g_img + 1 * MB_PLANE + off);
-                            const uint4 Gnh = *reinterpret_cast<const uint4*>(g_img + 2 * MB_PLANE + off);
-                            const uint4 Grl = *reinterpret_cast<const uint4*>(g_img + 3 * MB_PLANE + off);
-                            const uint4 Gil = *reinterpret_cast<const uint4*>(g_img + 4 * MB_PLANE + off);
-                            const uint4 Gnl = *reinterpret_cast<const uint4*>(g_img + 5 * MB_PLANE + off);
+                            // two lane bases + 16-bit immediates reach all six planes (left alone, the compiler
+                            // keeps 19 per-tile bases and adds the plane offsets: 62 v_add per pixel tile)
+                            const int tk = (tri_index(ti, tj) * 2 + ks) * 1024;
+                            const uint4 Grh = *reinterpret_cast<const uint4*>(g_img + gl0 + 0 * MB_PLANE + tk);
+                            const uint4 Gih = *reinterpret_cast<const uint4*>(g_img + gl0 + 1 * MB_PLANE + tk);
+                            const uint4 Gnh = *reinterpret_cast<const uint4*>(g_img + gl0 + 2 * MB_PLANE + tk);
+                            const uint4 Grl = *reinterpret_cast<const uint4*>(g_img + gl1 + 0 * MB_PLANE + tk);
+                            const uint4 Gil = *reinterpret_cast<const uint4*>(g_img + gl1 + 1 * MB_PLANE + tk);
+                            const uint4 Gnl = *reinterpret_cast<const uint4*>(g_img + gl1 + 2 * MB_PLANE + tk);
                             accR[ti] = RIME_MFMA(Grh, Erh, accR[ti]);
                             accI[ti] = RIME_MFMA(Grh, Eih, accI[ti]);
                             accR[ti] = RIME_MFMA(Gih, Eih, accR[ti]);
