@@ -212,7 +212,7 @@ __device__ __forceinline__ void static_for(F&& f)
 template <class SH, int W, bool SIGNED>
 __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* smem)
 {
-    constexpr int NU = SH::NU, UPW = SH::UPW, U0 = unit_begin<SH>(W), UE = unit_begin<SH>(W + 1);   // this wave's units: [U0, UE)
+    constexpr int UPW = SH::UPW, U0 = unit_begin<SH>(W), UE = unit_begin<SH>(W + 1);   // this wave's units: [U0, UE)
     constexpr int MF_IMG = SH::IMG, MF_BUF = SH::BUF;
     constexpr int BROW = SH::CROSS ? 4 : 0;          // image row-tile offset of the column (B) side
     const int tid = threadIdx.x, lane = tid & 63;

@@ -153,7 +153,7 @@ extern "C" int rime_interp_scatter_bwd(int dtype, int is_complex, const void* go
 // ---------------------------------------------------------------------------------------
 // Fused psky builder for the 1-pol power-beam case (beam_model.py:238-269 gen_beam's interpolation,
 // beam_model.py:1681-1698 cut_sky_fov and the beam x sky product of apply_beam :313-322):
-//     psky[r, q] = ( sum_k w[q,k] bmap[r, inds[q,k]] ) * sky[r, cut[q]]       r = channel, q = (t, p)
+//     psky[r, q] = ( sum_k w[q,k] bmapT[inds[q,k], r] ) * sky[r, cut[q]]      r = channel, q = (t, p)
 // instead of three passes (interpolated beam, cut sky, product) over (Nf x Nt x P) tensors.
 // cut[q] == Npix marks the zero padding of a time step.  Adjoint:
 //     T1[q, r]   = gpsky[r, q] * sky[r, cut[q]]      (transposed: the layout interp_scatter_kernel reads)
@@ -163,78 +163,92 @@ extern "C" int rime_interp_scatter_bwd(int dtype, int is_complex, const void* go
 // ---------------------------------------------------------------------------------------
 namespace rime {
 
+// Both kernels work on tiles of 64 points x 64 channels in two phases.  Interpolation phase: a lane owns 4
+// consecutive channels of one point and the beam map is read NODE-MAJOR (bmapT [Npb][R]), so one vector
+// load fetches a node's value for 4 channels and a wave instruction covers 4 points x 64 channels: 4x fewer
+// gather instructions than one lane per point walking the channels of a channel-major map (these kernels
+// are bound by the address rate of the texture path, not by bytes).  The interpolated tile goes through LDS
+// to the product phase, whose lanes run along the points: psky / gpsky / gs rows are contiguous there.
+template <typename T> struct vec4 { T x, y, z, w; };
+
 template <typename T, int NNN>
-__global__ void __launch_bounds__(256)
-beam_sky_fwd_kernel(const T* __restrict__ bmap, const T* __restrict__ sky, const int* __restrict__ inds,
-                    const T* __restrict__ wgts, const int* __restrict__ cut, int R, int Npb, int Npix,
-                    int Q, int Nnn, T* __restrict__ out)
+__device__ __forceinline__ void interp_tile(const T* __restrict__ bmapT, const int* __restrict__ inds,
+                                            const T* __restrict__ wgts, const int* __restrict__ cut, int R, int Npix,
+                                            int Q, int Nnn, int q0, int r0, T (*tile)[65])
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
-    const int r0 = blockIdx.y * RT, r1 = min(R, r0 + RT);
-    const int c = cut[q];
-    int id[NNN > 0 ? NNN : 1];
-    T w[NNN > 0 ? NNN : 1];
-    if constexpr (NNN > 0) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int qs = lane >> 4, rq = lane & 15;
+    const int r = r0 + 4 * rq;
+    const bool vec_ok = (R & 3) == 0 && r + 3 < R;
 #pragma unroll
-        for (int k = 0; k < NNN; ++k) { id[k] = inds[(size_t)q * NNN + k]; w[k] = wgts[(size_t)q * NNN + k]; }
-    }
-    for (int r = r0; r < r1; ++r) {
-        T v = T(0);
-        if (c < Npix) {
-            const T* row = bmap + (size_t)r * Npb;
-            T b = T(0);
-            if constexpr (NNN > 0) {
+    for (int j = 0; j < 4; ++j) {
+        const int ql = 16 * w + 4 * j + qs, q = q0 + ql;
+        T b0 = T(0), b1 = T(0), b2 = T(0), b3 = T(0);
+        if (q < Q && cut[q] < Npix) {
+            const int nn = NNN > 0 ? NNN : Nnn;
 #pragma unroll
-                for (int k = 0; k < NNN; ++k) b = tfma<T>(w[k], row[id[k]], b);
-            } else {
-                for (int k = 0; k < Nnn; ++k) b = tfma<T>(wgts[(size_t)q * Nnn + k], row[inds[(size_t)q * Nnn + k]], b);
+            for (int k = 0; k < nn; ++k) {
+                const T wk = wgts[(size_t)q * nn + k];
+                const T* src = bmapT + (size_t)inds[(size_t)q * nn + k] * R + r;
+                if (vec_ok) {
+                    const vec4<T> v = *reinterpret_cast<const vec4<T>*>(src);
+                    b0 = tfma<T>(wk, v.x, b0); b1 = tfma<T>(wk, v.y, b1); b2 = tfma<T>(wk, v.z, b2); b3 = tfma<T>(wk, v.w, b3);
+                } else {
+                    if (r < R) b0 = tfma<T>(wk, src[0], b0);
+                    if (r + 1 < R) b1 = tfma<T>(wk, src[1], b1);
+                    if (r + 2 < R) b2 = tfma<T>(wk, src[2], b2);
+                    if (r + 3 < R) b3 = tfma<T>(wk, src[3], b3);
+                }
             }
-            v = b * sky[(size_t)r * Npix + c];
         }
-        out[(size_t)r * Q + q] = v;
+        tile[ql][4 * rq] = b0; tile[ql][4 * rq + 1] = b1; tile[ql][4 * rq + 2] = b2; tile[ql][4 * rq + 3] = b3;
     }
 }
 
-// block = 64 points x 64 channels: a thread keeps the stencil of its point in registers and walks 16
-// channels; gps / gs are accessed along q, T1 is written along r through an LDS tile
 template <typename T, int NNN>
 __global__ void __launch_bounds__(256)
-beam_sky_bwd_kernel(const T* __restrict__ gps, const T* __restrict__ bmap, const T* __restrict__ sky,
-                    const int* __restrict__ inds, const T* __restrict__ wgts, const int* __restrict__ cut,
-                    int R, int Npb, int Npix, int Q, int Nnn, T* __restrict__ T1, T* __restrict__ gs)
+beam_sky_fwd_kernel(const T* __restrict__ bmapT, const T* __restrict__ sky, const int* __restrict__ inds,
+                    const T* __restrict__ wgts, const int* __restrict__ cut, int R, int Npb, int Npix,
+                    int Q, int Nnn, T* __restrict__ out)
 {
     __shared__ T tile[64][65];
     const int q0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    interp_tile<T, NNN>(bmapT, inds, wgts, cut, R, Npix, Q, Nnn, q0, r0, tile);
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int q = q0 + lx;
+    if (q >= Q) return;
+    const int c = cut[q];
+#pragma unroll 4
+    for (int k16 = 0; k16 < 16; ++k16) {
+        const int rl = ly + 4 * k16, r = r0 + rl;
+        if (r < R) out[(size_t)r * Q + q] = c < Npix ? tile[lx][rl] * sky[(size_t)r * Npix + c] : T(0);
+    }
+}
+
+// gs is written and gpsky read along q; T1 is written along r through a second LDS tile
+template <typename T, int NNN>
+__global__ void __launch_bounds__(256)
+beam_sky_bwd_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const T* __restrict__ sky,
+                    const int* __restrict__ inds, const T* __restrict__ wgts, const int* __restrict__ cut,
+                    int R, int Npb, int Npix, int Q, int Nnn, T* __restrict__ T1, T* __restrict__ gs)
+{
+    __shared__ T tileb[64][65];
+    __shared__ T tile[64][65];
+    const int q0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    interp_tile<T, NNN>(bmapT, inds, wgts, cut, R, Npix, Q, Nnn, q0, r0, tileb);
+    __syncthreads();
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int q = q0 + lx;
     const int c = q < Q ? cut[q] : Npix;
-    int id[NNN > 0 ? NNN : 1];
-    T w[NNN > 0 ? NNN : 1];
-    if constexpr (NNN > 0) {
-        if (q < Q) {
-#pragma unroll
-            for (int k = 0; k < NNN; ++k) { id[k] = inds[(size_t)q * NNN + k]; w[k] = wgts[(size_t)q * NNN + k]; }
-        }
-    }
 #pragma unroll 4
     for (int k16 = 0; k16 < 16; ++k16) {
         const int rl = ly + 4 * k16, r = r0 + rl;
         T t1 = T(0);
         if (q < Q && r < R) {
             const T g = gps[(size_t)r * Q + q];
-            T b = T(0), s = T(0);
-            if (c < Npix) {
-                const T* row = bmap + (size_t)r * Npb;
-                if constexpr (NNN > 0) {
-#pragma unroll
-                    for (int k = 0; k < NNN; ++k) b = tfma<T>(w[k], row[id[k]], b);
-                } else {
-                    for (int k = 0; k < Nnn; ++k) b = tfma<T>(wgts[(size_t)q * Nnn + k], row[inds[(size_t)q * Nnn + k]], b);
-                }
-                s = sky[(size_t)r * Npix + c];
-            }
-            gs[(size_t)r * Q + q] = g * b;
+            const T s = c < Npix ? sky[(size_t)r * Npix + c] : T(0);
+            gs[(size_t)r * Q + q] = g * tileb[lx][rl];
             t1 = g * s;
         }
         tile[rl][lx] = t1;
@@ -277,7 +291,7 @@ template <typename T>
 static int beam_sky_fwd_launch(const void* bmap, const void* sky, const int* inds, const void* wgts, const int* cut,
                                int R, int Npb, int Npix, int Q, int Nnn, void* out, hipStream_t st)
 {
-    dim3 grid((Q + 255) / 256, (R + RT - 1) / RT), block(256);
+    dim3 grid((Q + 63) / 64, (R + 63) / 64), block(256);
     const T* b_ = reinterpret_cast<const T*>(bmap); const T* s_ = reinterpret_cast<const T*>(sky);
     const T* w_ = reinterpret_cast<const T*>(wgts); T* o_ = reinterpret_cast<T*>(out);
 #define RIME_BS(N) hipLaunchKernelGGL((beam_sky_fwd_kernel<T, N>), grid, block, 0, st, b_, s_, inds, w_, cut, R, Npb, Npix, Q, Nnn, o_)

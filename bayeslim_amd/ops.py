@@ -474,7 +474,8 @@ class _BeamSkyProduct(torch.autograd.Function):
         R, Npb = bmap.shape
         Npix = sky.shape[1]
         assert sky.shape[0] == R and Npb == st.Npb and st.P == Nt * Ps and bmap.dtype == sky.dtype
-        b, k = bmap.detach().contiguous(), sky.detach().contiguous()
+        # the kernels gather from a node-major map [Npix_beam, R]: a node's value for 4 channels is one vector load
+        b, k = bmap.detach().t().contiguous(), sky.detach().contiguous()
         code, rdt = _real_dtype(b)
         out = torch.empty((R, Nt * Ps), dtype=b.dtype, device=b.device)
         rc = lib.rime_beam_sky_fwd(code, _ptr(b), _ptr(k), _ptr(st.inds), _ptr(st.weights(rdt)), _ptr(cut),
@@ -488,7 +489,7 @@ class _BeamSkyProduct(torch.autograd.Function):
     def backward(ctx, g):
         b, k = ctx.saved_tensors
         st, cut, pos, Nt, Ps = ctx.aux
-        R, Npb = b.shape
+        Npb, R = b.shape
         Npix = k.shape[1]
         Q = Nt * Ps
         code, rdt = _real_dtype(b)

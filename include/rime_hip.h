@@ -193,17 +193,18 @@ int rime_interp_scatter_bwd(int dtype, int is_complex, const void* goutT,
 
 /* ---------------------------------------------------------------------------------------
  * Fused psky builder (1-pol power beam, one beam model):
- *   psky[r, q] = ( sum_k wgts[q,k] * bmap[r, inds[q,k]] ) * sky[r, cut[q]],   r = channel, q = (t, p)
+ *   psky[r, q] = ( sum_k wgts[q,k] * bmapT[inds[q,k], r] ) * sky[r, cut[q]],  r = channel, q = (t, p)
  * = PixelBeam.gen_beam's interpolation (beam_model.py:238-269) + cut_sky_fov (:1681-1698) + the
  * beam x sky product of apply_beam (:313-322) in one pass; cut[q] == Npix marks zero padding.
- *   bmap T [R, Npb]; sky T [R, Npix]; inds i32 / wgts T [Q = Nt*Ps, Nnn]; cut i32 [Q]; psky T [R, Q]
+ *   bmapT T [Npb, R] (the beam map NODE-MAJOR: a node's channels are contiguous, so the gathers are vector
+ *   loads); sky T [R, Npix]; inds i32 / wgts T [Q = Nt*Ps, Nnn]; cut i32 [Q]; psky T [R, Q]
  * Backward: T1 [Q, R] = gpsky * sky_cut (transposed: the input layout of rime_interp_scatter_bwd, which
  * then yields the beam-map gradient), gs [R, Q] scratch, gsky [R, Npix] = sum over time steps through
  * pos i32 [Nt, Npix] (index of sky pixel j inside time step t's cut, or -1).  No atomics.
  * ------------------------------------------------------------------------------------- */
-int rime_beam_sky_fwd(int dtype, const void* bmap, const void* sky, const int* inds, const void* wgts,
+int rime_beam_sky_fwd(int dtype, const void* bmapT, const void* sky, const int* inds, const void* wgts,
                       const int* cut, int R, int Npb, int Npix, int Q, int Nnn, void* psky, void* stream);
-int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmap, const void* sky, const int* inds,
+int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmapT, const void* sky, const int* inds,
                       const void* wgts, const int* cut, const int* pos, int R, int Npb, int Npix,
                       int Nt, int Ps, int Nnn, void* T1, void* gs, void* gsky, void* stream);
 
