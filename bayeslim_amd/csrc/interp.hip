@@ -157,8 +157,8 @@ extern "C" int rime_interp_scatter_bwd(int dtype, int is_complex, const void* go
 // instead of three passes (interpolated beam, cut sky, product) over (Nf x Nt x P) tensors.
 // cut[q] == Npix marks the zero padding of a time step.  Adjoint:
 //     T1[q, r]   = gpsky[r, q] * sky[r, cut[q]]      (transposed: the layout interp_scatter_kernel reads)
-//     gs[r, q]   = gpsky[r, q] * beam_interp[r, q]   (beam re-interpolated, not saved)
-//     gsky[r, j] = sum_t gs[r, t Ps + pos[t, j]]     (pos = inverse of cut per time step, -1 = not visible)
+//     gsky[r, j] = sum_t gpsky[r, q] * beam_interp[r, q],  q = t Ps + pos[t, j]
+//                  (beam re-interpolated, not saved; pos = inverse of cut per time step, -1 = not visible)
 // all deterministic (no atomics).
 // ---------------------------------------------------------------------------------------
 namespace rime {
@@ -171,10 +171,11 @@ namespace rime {
 // to the product phase, whose lanes run along the points: psky / gpsky / gs rows are contiguous there.
 template <typename T> struct vec4 { T x, y, z, w; };
 
+// points of the tile: q0 + ql (valid when inside Q and not a padding slot of the cut), or qlist[ql] (< 0: none)
 template <typename T, int NNN>
 __device__ __forceinline__ void interp_tile(const T* __restrict__ bmapT, const int* __restrict__ inds,
                                             const T* __restrict__ wgts, const int* __restrict__ cut, int R, int Npix,
-                                            int Q, int Nnn, int q0, int r0, T (*tile)[65])
+                                            int Q, int Nnn, int q0, int r0, T (*tile)[65], const int* qlist = nullptr)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int qs = lane >> 4, rq = lane & 15;
@@ -182,9 +183,9 @@ __device__ __forceinline__ void interp_tile(const T* __restrict__ bmapT, const i
     const bool vec_ok = (R & 3) == 0 && r + 3 < R;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int ql = 16 * w + 4 * j + qs, q = q0 + ql;
+        const int ql = 16 * w + 4 * j + qs, q = qlist ? qlist[ql] : q0 + ql;
         T b0 = T(0), b1 = T(0), b2 = T(0), b3 = T(0);
-        if (q < Q && cut[q] < Npix) {
+        if (qlist ? q >= 0 : (q < Q && cut[q] < Npix)) {
             const int nn = NNN > 0 ? NNN : Nnn;
 #pragma unroll
             for (int k = 0; k < nn; ++k) {
@@ -226,32 +227,21 @@ beam_sky_fwd_kernel(const T* __restrict__ bmapT, const T* __restrict__ sky, cons
     }
 }
 
-// gs is written and gpsky read along q; T1 is written along r through a second LDS tile
-template <typename T, int NNN>
+// adjoint, beam side: T1[q, r] = gpsky[r, q] * sky[r, cut[q]] -- read along q, written along r through LDS
+template <typename T>
 __global__ void __launch_bounds__(256)
-beam_sky_bwd_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const T* __restrict__ sky,
-                    const int* __restrict__ inds, const T* __restrict__ wgts, const int* __restrict__ cut,
-                    int R, int Npb, int Npix, int Q, int Nnn, T* __restrict__ T1, T* __restrict__ gs)
+beam_sky_bwd_kernel(const T* __restrict__ gps, const T* __restrict__ sky, const int* __restrict__ cut,
+                    int R, int Npix, int Q, T* __restrict__ T1)
 {
-    __shared__ T tileb[64][65];
     __shared__ T tile[64][65];
     const int q0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-    interp_tile<T, NNN>(bmapT, inds, wgts, cut, R, Npix, Q, Nnn, q0, r0, tileb);
-    __syncthreads();
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int q = q0 + lx;
     const int c = q < Q ? cut[q] : Npix;
 #pragma unroll 4
     for (int k16 = 0; k16 < 16; ++k16) {
         const int rl = ly + 4 * k16, r = r0 + rl;
-        T t1 = T(0);
-        if (q < Q && r < R) {
-            const T g = gps[(size_t)r * Q + q];
-            const T s = c < Npix ? sky[(size_t)r * Npix + c] : T(0);
-            gs[(size_t)r * Q + q] = g * tileb[lx][rl];
-            t1 = g * s;
-        }
-        tile[rl][lx] = t1;
+        tile[rl][lx] = (c < Npix && r < R) ? gps[(size_t)r * Q + q] * sky[(size_t)r * Npix + c] : T(0);
     }
     __syncthreads();
 #pragma unroll 4
@@ -261,30 +251,52 @@ beam_sky_bwd_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, cons
     }
 }
 
-template <typename T>
+// adjoint, sky side: gsky[r, j] = sum_t gpsky[r, q] * beam_interp[r, q], q = t Ps + pos[t, j] -- a tile of 64 sky
+// pixels x 64 channels walks the time steps, re-interpolating the beam for the pixels visible at t (the
+// (Nf x Nt P) product gpsky * beam is never written: it would be one more write and one more read of the largest
+// tensor of the step)
+template <typename T, int NNN>
 __global__ void __launch_bounds__(256)
-sky_gather_sum_kernel(const T* __restrict__ gs, const int* __restrict__ pos, int R, int Npix, int Nt, int Ps,
-                      T* __restrict__ gsky)
+sky_grad_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const int* __restrict__ inds,
+                const T* __restrict__ wgts, const int* __restrict__ pos, int R, int Npix, int Nt, int Ps, int Nnn,
+                T* __restrict__ gsky)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= Npix) return;
-    const int r0 = blockIdx.y * RT, r1 = min(R, r0 + RT);
+    __shared__ T tile[64][65];
+    __shared__ int qsel[64];
+    const int j0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int j = j0 + lx;
     const size_t Q = (size_t)Nt * Ps;
-    T acc[RT];
+    T acc[16];
 #pragma unroll
-    for (int i = 0; i < RT; ++i) acc[i] = T(0);
+    for (int k16 = 0; k16 < 16; ++k16) acc[k16] = T(0);
     for (int t = 0; t < Nt; ++t) {
-        const int p = pos[(size_t)t * Npix + j];
-        if (p >= 0) {
-            const size_t q = (size_t)t * Ps + p;
+        int mine = -1;
+        if (threadIdx.x < 64) {
+            const int p = j < Npix ? pos[(size_t)t * Npix + j] : -1;
+            mine = p >= 0 ? t * Ps + p : -1;
+            qsel[threadIdx.x] = mine;
+        }
+        if (!__syncthreads_or(mine >= 0)) continue;      // none of the 64 pixels is above the horizon at t (uniform)
+        interp_tile<T, NNN>(bmapT, inds, wgts, nullptr, R, Npix, 0, Nnn, 0, r0, tile, qsel);
+        __syncthreads();
+        const int q = qsel[lx];
+        if (q >= 0) {
 #pragma unroll
-            for (int i = 0; i < RT; ++i)
-                if (r0 + i < r1) acc[i] += gs[(size_t)(r0 + i) * Q + q];
+            for (int k16 = 0; k16 < 16; ++k16) {
+                const int rl = ly + 4 * k16, r = r0 + rl;
+                if (r < R) acc[k16] = tfma<T>(gps[(size_t)r * Q + q], tile[lx][rl], acc[k16]);
+            }
+        }
+        __syncthreads();
+    }
+    if (j < Npix) {
+#pragma unroll
+        for (int k16 = 0; k16 < 16; ++k16) {
+            const int r = r0 + ly + 4 * k16;
+            if (r < R) gsky[(size_t)r * Npix + j] = acc[k16];
         }
     }
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-        if (r0 + i < r1) gsky[(size_t)(r0 + i) * Npix + j] = acc[i];
 }
 
 template <typename T>
@@ -319,29 +331,29 @@ extern "C" int rime_beam_sky_fwd(int dtype, const void* bmap, const void* sky, c
     return RIME_EINVAL;
 }
 
-extern "C" int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmap, const void* sky, const int* inds,
+extern "C" int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmapT, const void* sky, const int* inds,
                                  const void* wgts, const int* cut, const int* pos, int R, int Npb, int Npix,
-                                 int Nt, int Ps, int Nnn, void* T1, void* gs, void* gsky, void* stream)
+                                 int Nt, int Ps, int Nnn, void* T1, void* gsky, void* stream)
 {
-    if (!gpsky || !bmap || !sky || !inds || !wgts || !cut || !pos || !T1 || !gs || !gsky) return RIME_EINVAL;
+    if (!gpsky || !bmapT || !sky || !inds || !wgts || !cut || !pos || !T1 || !gsky) return RIME_EINVAL;
     if (R <= 0 || Npb <= 0 || Npix <= 0 || Nt <= 0 || Ps <= 0 || Nnn <= 0) return RIME_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int Q = Nt * Ps;
-    dim3 g1((Q + 63) / 64, (R + 63) / 64), g2((Npix + 255) / 256, (R + RT - 1) / RT);
-#define RIME_BSB(TT, N) hipLaunchKernelGGL((beam_sky_bwd_kernel<TT, N>), g1, dim3(256), 0, st, (const TT*)gpsky, \
-        (const TT*)bmap, (const TT*)sky, inds, (const TT*)wgts, cut, R, Npb, Npix, Q, Nnn, (TT*)T1, (TT*)gs)
-#define RIME_BSB_ALL(TT) switch (Nnn) { case 1: RIME_BSB(TT, 1); break; case 4: RIME_BSB(TT, 4); break; \
-        case 9: RIME_BSB(TT, 9); break; case 16: RIME_BSB(TT, 16); break; default: RIME_BSB(TT, 0); break; }
+    dim3 g1((Q + 63) / 64, (R + 63) / 64), g2((Npix + 63) / 64, (R + 63) / 64);
+#define RIME_SG(TT, N) hipLaunchKernelGGL((sky_grad_kernel<TT, N>), g2, dim3(256), 0, st, (const TT*)gpsky, (const TT*)bmapT, \
+        inds, (const TT*)wgts, pos, R, Npix, Nt, Ps, Nnn, (TT*)gsky)
+#define RIME_SG_ALL(TT) switch (Nnn) { case 1: RIME_SG(TT, 1); break; case 4: RIME_SG(TT, 4); break; \
+        case 9: RIME_SG(TT, 9); break; case 16: RIME_SG(TT, 16); break; default: RIME_SG(TT, 0); break; }
     if (dtype == RIME_F32) {
-        RIME_BSB_ALL(float)
-        hipLaunchKernelGGL((sky_gather_sum_kernel<float>), g2, dim3(256), 0, st, (const float*)gs, pos, R, Npix, Nt, Ps,
-                           (float*)gsky);
+        hipLaunchKernelGGL((beam_sky_bwd_kernel<float>), g1, dim3(256), 0, st, (const float*)gpsky, (const float*)sky, cut,
+                           R, Npix, Q, (float*)T1);
+        RIME_SG_ALL(float)
     } else if (dtype == RIME_F64) {
-        RIME_BSB_ALL(double)
-        hipLaunchKernelGGL((sky_gather_sum_kernel<double>), g2, dim3(256), 0, st, (const double*)gs, pos, R, Npix, Nt, Ps,
-                           (double*)gsky);
+        hipLaunchKernelGGL((beam_sky_bwd_kernel<double>), g1, dim3(256), 0, st, (const double*)gpsky, (const double*)sky, cut,
+                           R, Npix, Q, (double*)T1);
+        RIME_SG_ALL(double)
     } else return RIME_EINVAL;
-#undef RIME_BSB_ALL
-#undef RIME_BSB
+#undef RIME_SG_ALL
+#undef RIME_SG
     return check_launch();
 }

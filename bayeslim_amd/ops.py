@@ -495,10 +495,9 @@ class _BeamSkyProduct(torch.autograd.Function):
         code, rdt = _real_dtype(b)
         g = g.contiguous()
         T1 = torch.empty((Q, R), dtype=b.dtype, device=b.device)
-        gs = torch.empty((R, Q), dtype=b.dtype, device=b.device)
         gsky = torch.empty((R, Npix), dtype=b.dtype, device=b.device)
         rc = lib.rime_beam_sky_bwd(code, _ptr(g), _ptr(b), _ptr(k), _ptr(st.inds), _ptr(st.weights(rdt)), _ptr(cut),
-                                   _ptr(pos), R, Npb, Npix, Nt, Ps, st.Nnn, _ptr(T1), _ptr(gs), _ptr(gsky), _stream())
+                                   _ptr(pos), R, Npb, Npix, Nt, Ps, st.Nnn, _ptr(T1), _ptr(gsky), _stream())
         check(rc, 'rime_beam_sky_bwd')
         gmT = torch.empty((Npb, R), dtype=b.dtype, device=b.device)
         rc = lib.rime_interp_scatter_bwd(code, 0, _ptr(T1), _ptr(st.csr_ptr), _ptr(st.csr_src), _ptr(st.weights(rdt)),

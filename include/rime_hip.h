@@ -199,14 +199,14 @@ int rime_interp_scatter_bwd(int dtype, int is_complex, const void* goutT,
  *   bmapT T [Npb, R] (the beam map NODE-MAJOR: a node's channels are contiguous, so the gathers are vector
  *   loads); sky T [R, Npix]; inds i32 / wgts T [Q = Nt*Ps, Nnn]; cut i32 [Q]; psky T [R, Q]
  * Backward: T1 [Q, R] = gpsky * sky_cut (transposed: the input layout of rime_interp_scatter_bwd, which
- * then yields the beam-map gradient), gs [R, Q] scratch, gsky [R, Npix] = sum over time steps through
- * pos i32 [Nt, Npix] (index of sky pixel j inside time step t's cut, or -1).  No atomics.
+ * then yields the beam-map gradient); gsky [R, Npix] = sum over time steps of gpsky * (re-interpolated beam)
+ * through pos i32 [Nt, Npix] (index of sky pixel j inside time step t's cut, or -1).  No atomics.
  * ------------------------------------------------------------------------------------- */
 int rime_beam_sky_fwd(int dtype, const void* bmapT, const void* sky, const int* inds, const void* wgts,
                       const int* cut, int R, int Npb, int Npix, int Q, int Nnn, void* psky, void* stream);
 int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmapT, const void* sky, const int* inds,
                       const void* wgts, const int* cut, const int* pos, int R, int Npb, int Npix,
-                      int Nt, int Ps, int Nnn, void* T1, void* gs, void* gsky, void* stream);
+                      int Nt, int Ps, int Nnn, void* T1, void* gsky, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a_lm -> pixel transform:  out[r, j] = sum_c ( are[r,c] * Yre[c,j] - aim[r,c] * Yim[c,j] )
