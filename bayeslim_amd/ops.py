@@ -226,18 +226,23 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
                 out[pp][..., 1] += tmp[..., 0]
     else:
         # inp: gvis as real (Npp, Nbl, Nt, Nf, 2); out: gpsky float32 view with psky's strides
-        scale = _pow2_scale(inp.abs().amax(dim=(1, 4))).contiguous()               # (Npp, Nt, Nf)
         nbytes = lib.rime_fringe_ant_bwd_workspace(Nbl, Nt, Nf)
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+        gvt = ws[:Nt * Nf * 2 * Nbl * 4].view(torch.float32).view(Nt * Nf, 2 * Nbl)    # what bwd_prepare writes
         for pp in range(Npp):
             for c in range(m):
                 g = inp[pp] if c == 0 else torch.stack([inp[pp][..., 1], -inp[pp][..., 0]], dim=-1).contiguous()
                 rc = lib.rime_fringe_ant_bwd_prepare(_ptr(g), Nbl, Nt, Nf, _ptr(ws), ws.numel(), _stream())
                 check(rc, 'rime_fringe_ant_bwd_prepare')
+                if c == 0:
+                    # max |gvis| per (t, f) from the transposed copy: a contiguous row reduction (the same
+                    # reduction over the (Nbl, Nt, Nf, 2) layout is strided and 4x slower); -i g has the same maxima
+                    lo, hi = torch.aminmax(gvt, dim=-1)
+                    scale_pp = _pow2_scale(torch.maximum(hi, -lo)).contiguous()    # (Nt * Nf)
                 dst = ctypes.c_void_p(out.data_ptr() + 4 * (pp * st_pp + c))
                 for k, blk in enumerate(a['blocks']):
                     rc = lib.rime_fringe_ant_bwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], *geo,
-                                                       _ptr(scale[pp]), _ptr(blk['direct']), _ptr(blk['conj']),
+                                                       _ptr(scale_pp), _ptr(blk['direct']), _ptr(blk['conj']),
                                                        *shape, int(k > 0), dst, _ptr(ws), ws.numel(), _stream())
                     check(rc, 'rime_fringe_ant_bwd_block')
     return Npp * m
