@@ -538,7 +538,8 @@ fringe_ant_fwd_cross_kernel(AntArgs A)
 // parameter (the accumulator zero-fill folds into the first MFMAs, 103 -> 22 v_mov, but the
 // schedule spills 9 registers: 3 % slower; with a sched_barrier between row tiles it does not spill and
 // runs 13 % fewer VALU instructions -- at the same speed: moves and integer adds ride in the MFMA
-// shadow, the f64 phase and sin/cos instructions are what the matrix pipe waits for).
+// shadow, the f64 phase and sin/cos instructions are what the matrix pipe waits for.  But replacing
+// v_cvt_f32_f64 of the fraction by v_alignbit + add + compare + select is 5 % SLOWER in both kernels).
 // ---------------------------------------------------------------------------------------
 struct AntBwdArgs {
     const double* antpos; const double* sdir; const double* freqs;
