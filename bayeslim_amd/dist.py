@@ -18,8 +18,14 @@ sums gradients on device 0.  Here:
     buffer per dtype so the ring runs over few, large messages.
 """
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
+
+
+# RIME_DIST_SIMPLE=1: always use the list-based all_gather + copies (debugging aid for a new fabric / backend)
+_SIMPLE = os.environ.get('RIME_DIST_SIMPLE', '0') == '1'
 
 
 def shard_bounds(n, world_size):
@@ -50,7 +56,7 @@ class _AllGatherCat(torch.autograd.Function):
         rank = dist.get_rank(group)
         nmax = max(counts)
         ctx.counts, ctx.rank, ctx.dim = counts, rank, dim
-        if min(counts) == nmax and x.shape[dim] == nmax:
+        if min(counts) == nmax and x.shape[dim] == nmax and not _SIMPLE:
             # equal blocks: one collective into a [world, ...] buffer, then a single re-layout (none at all
             # when every axis before `dim` has length 1, i.e. the baseline-sharded visibility tensor)
             xin = x.contiguous()
@@ -113,7 +119,7 @@ def all_gather_block_grads(param, dim, bounds, group=None):
         param.grad = torch.zeros_like(param)
     nmax = max(b - a for a, b in bounds)
     g = param.grad
-    if (min(b - a for a, b in bounds) == nmax and g.is_contiguous() and not g.is_complex()
+    if (not _SIMPLE and min(b - a for a, b in bounds) == nmax and g.is_contiguous() and not g.is_complex()
             and all(n == 1 for n in g.shape[:dim]) and bounds[0][0] == 0 and bounds[-1][1] == g.shape[dim]):
         # equal blocks that are contiguous runs of the gradient in rank order: in-place all-gather
         flat = g.view(-1)
