@@ -570,6 +570,147 @@ def gen_rime_c5_mini(ba):
          vis=V, gvis=gw, g_sky_params=grads[0], g_beam_params=grads[1])
 
 
+def fib_sky(Npix, cut=True):
+    """quasi-uniform (Fibonacci lattice) directions, optionally cut at dec < 59.27852 (tests/test_sky.py:18)"""
+    k = np.arange(Npix) + 0.5
+    dec = np.rad2deg(np.arcsin(1 - 2 * k / Npix))
+    ra = (k * 137.50776405) % 360.0
+    if cut:
+        keep = dec < 59.27852
+        ra, dec = ra[keep], dec[keep]
+    return torch.as_tensor(ra), torch.as_tensor(dec)
+
+
+def gen_rime_mfma_arrays(ba):
+    """
+    Arrays large enough (>= 33 antennas) that the build's antenna-factored matrix-core kernels serve
+    them: hex-37 (666 baselines) and a 70-antenna random array (2415 baselines); diffuse pixel sky,
+    rect-linear interpolated PixelBeam, visibilities + gradients w.r.t. sky pixels and beam map.
+    """
+    for tag, Nf, Npix, seed in [('hex37', 4, 500, 21), ('rand70', 3, 400, 22)]:
+        freqs = torch.linspace(120e6, 180e6, Nf)
+        times = 2459861.0 + np.arange(2) * 10.0 / 1440
+        rng = np.random.default_rng(seed)
+        if tag == 'hex37':
+            arr = hex_array(ba, 4, freqs)
+        else:
+            vecs = np.stack([rng.uniform(-150, 150, 70), rng.uniform(-150, 150, 70), rng.normal(0, 0.5, 70)], 1)
+            arr = ba.telescope_model.ArrayModel(ba.utils.AntposDict(list(range(70)), vecs), freqs=freqs,
+                                                cache_s=True, redtol=1.0)
+        tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+        ra, dec = fib_sky(Npix)
+        px_area = 4 * np.pi / Npix
+        Rs = ba.sky_model.PixelSkyResponse(freqs, cosmo=object())
+        sp = torch.as_tensor(rng.normal(size=(1, 1, Nf, len(ra))))
+        sky = ba.sky_model.PixelSky(sp.clone(), torch.stack([ra, dec]), px_area, R=Rs,
+                                    parameter=True, name='pixsky')
+        beam, tg, pg = airy_pixbeam(ba, freqs, parameter=True)
+        ants = arr.ants
+        sim_bls = [(ants[i], ants[j]) for i in range(len(ants)) for j in range(i + 1, len(ants))]
+        rime = ba.rime_model.RIME(sky, tel, beam, arr, sim_bls, times, freqs)
+        zenaz = fill_eq2top(tel, sky.name, ra, dec, times)
+        V, gw, grads = run_rime(ba, rime, [sky.params, beam.params])
+        save('rime_%s_mini' % tag, freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(arr.ants),
+             sim_bls=np.array(sim_bls), ra=ra, dec=dec, zenaz=zenaz, px_area=np.array(px_area),
+             sky_params=sp, beam_params=beam.params.detach(), theta_grid=tg, phi_grid=pg,
+             vis=V, gvis=gw, g_sky_params=grads[0], g_beam_params=grads[1])
+
+
+def gen_rime_composite(ba):
+    """
+    Diffuse pixel sky + point sources through ONE beam: the sky of the headline benchmark.  The
+    reference's RIME.forward raises on a multi-component sky (torch.sum over a list,
+    rime_model.py:377), so the golden is two reference RIMEs -- one per component, sharing the beam
+    parameter -- with their visibilities added (SURVEY.md section 3.1 note); gradients flow through
+    the sum.  Two array sizes: hex-7 (vector-ALU kernels in the build) and hex-37 (matrix-core kernels).
+    """
+    for tag, N in [('hex7', 2), ('hex37', 4)]:
+        Nf = 4
+        freqs = torch.linspace(120e6, 180e6, Nf)
+        times = 2459861.0 + np.arange(2) * 10.0 / 1440
+        rng = np.random.default_rng(23 + N)
+        arr = hex_array(ba, N, freqs)
+        tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+        Npix = 400
+        ra, dec = fib_sky(Npix)
+        px_area = 4 * np.pi / Npix
+        Rs = ba.sky_model.PixelSkyResponse(freqs, cosmo=object())
+        sp = torch.as_tensor(np.abs(rng.normal(size=(1, 1, Nf, len(ra)))))
+        diffuse = ba.sky_model.PixelSky(sp.clone(), torch.stack([ra, dec]), px_area, R=Rs,
+                                        parameter=True, name='diffuse')
+        Nsrc = 25
+        Rp = ba.sky_model.PointSkyResponse(freqs, freq_mode='powerlaw', f0=freqs[0])
+        pp = torch.ones(1, 1, 2, Nsrc)
+        pp[..., 0, :] = torch.as_tensor(rng.uniform(0.01, 0.05, Nsrc))
+        pp[..., 1, :] = -2.2
+        pra = torch.as_tensor(lst_of(times[0]) + rng.uniform(-60, 60, Nsrc))
+        pdec = torch.as_tensor(LAT + rng.uniform(-50, 50, Nsrc))
+        points = ba.sky_model.PointSky(pp.clone(), torch.stack([pra, pdec]), R=Rp, parameter=True,
+                                       name='points')
+        beam, tg, pg = airy_pixbeam(ba, freqs, parameter=True)
+        ants = arr.ants
+        sim_bls = [(ants[i], ants[j]) for i in range(len(ants)) for j in range(i + 1, len(ants))]
+        zenaz = fill_eq2top(tel, 'diffuse', ra, dec, times)
+        pt_zenaz = fill_eq2top(tel, 'points', pra, pdec, times)
+        r1 = ba.rime_model.RIME(diffuse, tel, beam, arr, sim_bls, times, freqs)
+        r2 = ba.rime_model.RIME(points, tel, beam, arr, sim_bls, times, freqs)
+        V = r1().data + r2().data
+        g = np.random.default_rng(77)
+        gw = torch.as_tensor(g.normal(size=tuple(V.shape)) + 1j * g.normal(size=tuple(V.shape)))
+        loss = (V * gw.conj()).real.sum()
+        params = [diffuse.params, points.params, beam.params]
+        grads = torch.autograd.grad(loss, params)
+        save('rime_composite_%s' % tag, freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(arr.ants),
+             sim_bls=np.array(sim_bls), ra=ra, dec=dec, zenaz=zenaz, px_area=np.array(px_area),
+             sky_params=sp, pt_params=pp, pt_ra=pra, pt_dec=pdec, pt_zenaz=pt_zenaz,
+             beam_params=beam.params.detach(), theta_grid=tg, phi_grid=pg,
+             vis=V.detach(), gvis=gw, g_sky_params=grads[0], g_pt_params=grads[1], g_beam_params=grads[2])
+
+
+def gen_rime_two_models(ba):
+    """
+    hex-37 with TWO antenna beam models (1-pol, non-power real voltage beams; ant2beam alternates),
+    i.e. four beam-model pairs (0,0) (0,1) (1,0) (1,1) (beam_model.py:303-327): the case the build
+    must serve on its matrix-core kernels with per-antenna beams; visibilities + gradients.
+    """
+    Nf = 4
+    freqs = torch.linspace(120e6, 180e6, Nf)
+    times = 2459861.0 + np.arange(2) * 10.0 / 1440
+    rng = np.random.default_rng(31)
+    arr = hex_array(ba, 4, freqs)
+    tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+    Npix = 400
+    ra, dec = fib_sky(Npix)
+    px_area = 4 * np.pi / Npix
+    Rs = ba.sky_model.PixelSkyResponse(freqs, cosmo=object())
+    sp = torch.as_tensor(rng.normal(size=(1, 1, Nf, len(ra))))
+    sky = ba.sky_model.PixelSky(sp.clone(), torch.stack([ra, dec]), px_area, R=Rs, parameter=True, name='pixsky')
+    tg = torch.arange(0, 91, 5.0)
+    pg = torch.arange(0, 360, 10.0)
+    b_phi, b_theta = torch.meshgrid(pg, tg, indexing='xy')
+    b_phi, b_theta = b_phi.ravel(), b_theta.ravel()
+    airy = npy(ba.beam_model.airy_disk(b_theta * ba.utils.D2R, b_phi * ba.utils.D2R, 14.0, freqs, square=False))
+    amp = airy[None, None, None] * np.array([1.0, 0.85]).reshape(1, 1, 2, 1, 1)
+    amp = amp * (1.0 + 0.1 * rng.normal(size=(1, 1, 2, Nf, amp.shape[-1])))
+    bp = torch.as_tensor(amp).clone()
+    R = ba.beam_model.PixelResponse(freqs, 'rect', interp_mode='linear', theta=b_theta, phi=b_phi,
+                                    theta_grid=tg, phi_grid=pg, freq_mode='channel',
+                                    powerbeam=False, realbeam=True, comp_params=False)
+    ants = arr.ants
+    ant2beam = {a: (i % 2) for i, a in enumerate(ants)}
+    beam = ba.beam_model.PixelBeam(bp.clone(), freqs, R=R, ant2beam=ant2beam, pol='e', powerbeam=False,
+                                   fov=180, parameter=True)
+    beam.ant2beam = ant2beam
+    sim_bls = [(ants[i], ants[j]) for i in range(len(ants)) for j in range(i + 1, len(ants))]
+    rime = ba.rime_model.RIME(sky, tel, beam, arr, sim_bls, times, freqs)
+    zenaz = fill_eq2top(tel, 'pixsky', ra, dec, times)
+    V, gw, grads = run_rime(ba, rime, [sky.params, beam.params])
+    save('rime_two_models_hex37', freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(arr.ants),
+         sim_bls=np.array(sim_bls), ra=ra, dec=dec, zenaz=zenaz, px_area=np.array(px_area),
+         sky_params=sp, beam_params=bp, ant2beam=np.array([ant2beam[a] for a in ants]),
+         theta_grid=tg, phi_grid=pg, vis=V, gvis=gw, g_sky_params=grads[0], g_beam_params=grads[1])
+
+
 def gen_prod_and_sum(ba):
     """RIME._prod_and_sum in isolation (rime_model.py:391-440), with and without sim2data"""
     rng = np.random.default_rng(60)
@@ -711,6 +852,9 @@ def main():
     gen_rime_c2_mini(ba)
     gen_rime_c3_mini(ba)
     gen_rime_c5_mini(ba)
+    gen_rime_mfma_arrays(ba)
+    gen_rime_composite(ba)
+    gen_rime_two_models(ba)
 
 
 if __name__ == '__main__':

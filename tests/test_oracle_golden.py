@@ -268,6 +268,61 @@ def test_rime_c5_mini():
     _grad_check(vis, g, [I, bp], ['g_sky_params', 'g_beam_params'])
 
 
+def _pixbeam_fn(g, bp, powerbeam=True):
+    tg, pg = T(g['theta_grid']), T(g['phi_grid'])
+
+    def beam_fn(z, a):
+        inds, w = orc.rect_interp_weights(tg, pg, z, a, 'linear')
+        return orc.interp(orc.pixel_response_forward(bp, powerbeam=powerbeam), inds, w)
+    return beam_fn
+
+
+def test_rime_arrays_served_by_matrix_cores():
+    """hex-37 and a 70-antenna random array: the reference outputs the build's MFMA kernels are pinned to"""
+    for tag, nbl in [('hex37', 666), ('rand70', 2415)]:
+        g = load_golden('rime_%s_mini' % tag)
+        freqs = T(g['freqs'])
+        sp = T(g['sky_params']).clone().requires_grad_(True)
+        bp = T(g['beam_params']).clone().requires_grad_(True)
+        vis = orc.rime_forward(sp * float(g['px_area']), T(g['zenaz']), _pixbeam_fn(g, bp), _blvecs(g),
+                               [(0, 0)] * nbl, freqs)
+        assert vis.shape == g['vis'].shape and vis.shape[2] == nbl
+        assert maxrel(vis.detach().numpy(), g['vis']) < 1e-11, tag
+        _grad_check(vis, g, [sp, bp], ['g_sky_params', 'g_beam_params'])
+
+
+def test_rime_composite_sky():
+    """diffuse + point sources = two reference RIMEs summed (the reference cannot run both in one)"""
+    for tag in ('hex7', 'hex37'):
+        g = load_golden('rime_composite_' + tag)
+        freqs = T(g['freqs'])
+        sp = T(g['sky_params']).clone().requires_grad_(True)
+        pp = T(g['pt_params']).clone().requires_grad_(True)
+        bp = T(g['beam_params']).clone().requires_grad_(True)
+        nbl = len(g['sim_bls'])
+        beam_fn = _pixbeam_fn(g, bp)
+        v1 = orc.rime_forward(sp * float(g['px_area']), T(g['zenaz']), beam_fn, _blvecs(g), [(0, 0)] * nbl, freqs)
+        v2 = orc.rime_forward(orc.point_powerlaw(pp, freqs, freqs[0]), T(g['pt_zenaz']), beam_fn, _blvecs(g),
+                              [(0, 0)] * nbl, freqs)
+        vis = v1 + v2
+        assert maxrel(vis.detach().numpy(), g['vis']) < 1e-11, tag
+        _grad_check(vis, g, [sp, pp, bp], ['g_sky_params', 'g_pt_params', 'g_beam_params'])
+
+
+def test_rime_two_beam_models():
+    g = load_golden('rime_two_models_hex37')
+    freqs = T(g['freqs'])
+    sp = T(g['sky_params']).clone().requires_grad_(True)
+    bp = T(g['beam_params']).clone().requires_grad_(True)
+    a2b, ants = g['ant2beam'], g['ants'].tolist()
+    models = [(int(a2b[ants.index(i)]), int(a2b[ants.index(j)])) for i, j in g['sim_bls']]
+    assert len(set(models)) == 4
+    vis = orc.rime_forward(sp * float(g['px_area']), T(g['zenaz']), _pixbeam_fn(g, bp, powerbeam=False),
+                           _blvecs(g), models, freqs, powerbeam=False)
+    assert maxrel(vis.detach().numpy(), g['vis']) < 1e-11
+    _grad_check(vis, g, [sp, bp], ['g_sky_params', 'g_beam_params'])
+
+
 def test_healpix_pix2ang_self_consistency():
     """parity unpinned (healpy absent): internal checks only"""
     for nside in (1, 2, 8, 32):
