@@ -51,6 +51,7 @@ struct AntArgs {
     int S, panels_per_split;
     long long st_t, st_f, st_p;   // element strides of psky: time, channel, pixel (2 = one plane of a complex buffer)
     double sign;
+    float imsign;              // complex single-pass blocks: +1, or -1 to contract with conj(psky) (swapped groups)
 };
 
 __device__ __forceinline__ uint32_t pack_rtz(float a, float b)
@@ -143,21 +144,30 @@ constexpr int MF_ROWB = 4 * MF_KP + 16;         // [re KP x f16][im KP x f16][pa
 // Block shapes.  Diagonal block: one group of <= 128 antennas against itself, upper-triangular
 // tiles, 4 waves.  Cross block (arrays with more than 128 antennas): group I (image rows 0..127,
 // the sign-carrying L side) against group J (rows 128..255), all 16 tiles, 8 waves, 1 block per CU.
-template <int TA_, bool CROSS_>
+template <int TI_, int TJ_, bool CROSS_>
 struct FwdShape {
-    static constexpr int TA = TA_;
+    static constexpr int TA = TI_;                                 // diagonal block: tiles per side
+    static constexpr int TI = TI_, TJ = CROSS_ ? TJ_ : TI_;        // cross block: row tiles (group I) x column tiles (group J)
     static constexpr bool CROSS = CROSS_;
-    static constexpr int NW = CROSS ? 8 : 4;                       // waves per block (2-wave blocks for <= 64
+    static constexpr int NT = CROSS ? TI * TJ : TA * (TA + 1) / 2; // 32x32 output tiles
+    static constexpr int NU = 2 * NT;
+    // a single tile has two (re | im) units for four waves: the two K steps of a panel go to different
+    // waves and the partial tiles are added in the epilogue
+    static constexpr bool KSPLIT = NT == 1;
+    static constexpr int NW = NT >= 8 ? 8 : 4;                     // waves per block (2-wave blocks for <= 64
                                                                    // antennas: faster or slower with the grid size)
-    static constexpr int ROWS = CROSS ? 2 * MF_NA : 32 * TA;       // antenna rows of the LDS images (smaller
+    static constexpr int ROWS = CROSS ? 32 * (TI + TJ) : 32 * TA;  // antenna rows of the LDS images (smaller
                                                                    // arrays: more blocks per CU, 5-7 % faster)
-    static constexpr int NT = CROSS ? 16 : TA * (TA + 1) / 2;      // 32x32 output tiles
     static constexpr int GROWS = NW * 8;                           // antenna rows per generation sweep
     static constexpr int GEN = ROWS / GROWS;                       // antennas per thread and half panel
+    static constexpr int GEN_I = CROSS ? 32 * TI / GROWS : 0;      // sweeps that belong to group I (cross blocks)
     static constexpr int IMG = ROWS * MF_ROWB;                     // one image (hi or lo)
     static constexpr int BUF = 2 * IMG + 64;                       // hi + lo + sign dwords of the panel
-    static constexpr size_t LDS = 2 * (size_t)BUF;
-    static constexpr int NU = 2 * NT, UPW = (NU + NW - 1) / NW;
+    // epilogue scratch: four 32 x 33 float transposition tiles (+ two 16 x 64 float exchange tiles when K is split)
+    static constexpr size_t EPI = 4 * 33 * 32 * 4 + (KSPLIT ? 2 * 16 * 64 * 4 : 0);
+    static constexpr size_t LDS = 2 * (size_t)BUF < EPI ? EPI : 2 * (size_t)BUF;
+    static constexpr int UPW = KSPLIT ? 1 : (NU + NW - 1) / NW;
+    static_assert(ROWS % GROWS == 0 && (!CROSS || (32 * TI) % GROWS == 0), "generation sweeps must tile the image rows");
 };
 __host__ __device__ constexpr int tri_row(int TA, int idx) { int ti = 0; while (idx >= TA - ti) { idx -= TA - ti; ++ti; } return ti; }
 __host__ __device__ constexpr int tri_col(int TA, int idx) { int ti = 0; while (idx >= TA - ti) { idx -= TA - ti; ++ti; } return ti + idx; }
@@ -170,18 +180,19 @@ __host__ __device__ constexpr int tri4_col(int t) { return t < 4 ? t : (t == 4 ?
 // [4,6): 6, 6, 7, 7 MFMAs per wave and K step (two units per wave in row-major order: 7, 12, 7, 0)
 template <class SH> __host__ __device__ constexpr int tile_row(int t)
 {
-    return SH::CROSS ? t / 4 : (SH::TA == 4 ? tri4_row(t) : (SH::TA == 2 ? (t == 2 ? 1 : 0) : tri_row(SH::TA, t)));
+    return SH::CROSS ? t / SH::TJ : (SH::TA == 4 ? tri4_row(t) : (SH::TA == 2 ? (t == 2 ? 1 : 0) : tri_row(SH::TA, t)));
 }
 template <class SH> __host__ __device__ constexpr int tile_col(int t)
 {
     // 65..96 antennas: (0,1) (0,0) (0,2) (1,1) (1,2) (2,2) -- off-diagonal and diagonal tiles alternate, so the
     // three-unit ranges cost 16, 15, 13, 13 MFMAs per K step (row-major order: 13, 18, 13, 13)
-    return SH::CROSS ? t % 4 : (SH::TA == 4 ? tri4_col(t) : (SH::TA == 2 ? (t == 1 ? 0 : 1)
+    return SH::CROSS ? t % SH::TJ : (SH::TA == 4 ? tri4_col(t) : (SH::TA == 2 ? (t == 1 ? 0 : 1)
                               : (SH::TA == 3 && t < 2 ? 1 - t : tri_col(SH::TA, t))));
 }
 // units [unit_begin(w), unit_begin(w + 1)) belong to wave w
 template <class SH> __host__ __device__ constexpr int unit_begin(int w)
 {
+    if (SH::KSPLIT) return w >> 1;                 // waves (0, 1): unit 0, waves (2, 3): unit 1; K step = w & 1
     if (!SH::CROSS && SH::TA == 2) return w <= 2 ? w : (w == 3 ? 4 : 6);
     return SH::UPW * w < SH::NU ? SH::UPW * w : SH::NU;
 }
@@ -209,12 +220,18 @@ __device__ __forceinline__ void static_for(F&& f)
 
 #define RIME_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag(a), as_frag(b), c, 0, 0, 0)
 
-template <class SH, int W, bool SIGNED>
+// CPLX (cross blocks only): psky is complex and the block contracts it in ONE pass with asymmetric
+// weighting -- group I rows hold L = 2^7 E, group J rows hold B = (psky scale / 2^7) E (a complex product,
+// two more FMAs per generated value), so V = L^H B needs the same MFMAs as one real plane and no sign
+// masks.  (Diagonal blocks would need two images of the same antennas; they take the two real passes.)
+template <class SH, int W, bool SIGNED, bool CPLX>
 __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* smem)
 {
-    constexpr int UPW = SH::UPW, U0 = unit_begin<SH>(W), UE = unit_begin<SH>(W + 1);   // this wave's units: [U0, UE)
+    static_assert(!CPLX || (SH::CROSS && !SIGNED), "complex single pass: cross blocks, no sign masks");
+    constexpr int UPW = SH::UPW, U0 = unit_begin<SH>(W);                                // this wave's units: [U0, UE)
+    constexpr int UE = SH::KSPLIT ? U0 + 1 : unit_begin<SH>(W + 1);
     constexpr int MF_IMG = SH::IMG, MF_BUF = SH::BUF;
-    constexpr int BROW = SH::CROSS ? 4 : 0;          // image row-tile offset of the column (B) side
+    constexpr int BROW = SH::CROSS ? SH::TI : 0;     // image row-tile offset of the column (B) side
     const int tid = threadIdx.x, lane = tid & 63;
     // 1-D grid, channel fastest: blocks that run together share (t, split), i.e. the same pointing
     // vectors (L2 hits), and no grid dimension hits the 65535 cap
@@ -265,7 +282,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // panel fetch: wave-uniform bases (scalar address arithmetic) + constant 32-bit lane offsets;
     // psky is read as two dwords with the runtime pixel stride (a branch on the stride makes the
     // compiler issue both variants with 64-bit vector multiplies: 17 % of the loop's VALU work)
-    double2 sx[MF_NH], sy[MF_NH], sz[MF_NH]; float2 av[MF_NH];
+    double2 sx[MF_NH], sy[MF_NH], sz[MF_NH]; float2 av[MF_NH]; float2 aw[CPLX ? MF_NH : 1];   // aw: imaginary plane
     const uint32_t lo_s = 16u * pp, lo_a0 = 8u * pp * (uint32_t)st_p, lo_a1 = lo_a0 + 4u * (uint32_t)st_p;
     const double* sdy = sd + A.Pstride;
     const double* sdz = sd + 2 * (size_t)A.Pstride;
@@ -276,6 +293,8 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
         sz[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sdz + p0) + lo_s);
         const char* ab = reinterpret_cast<const char*>(arow + (size_t)p0 * st_p);
         av[hf] = make_float2(*reinterpret_cast<const float*>(ab + lo_a0), *reinterpret_cast<const float*>(ab + lo_a1));
+        if constexpr (CPLX)
+            aw[hf] = make_float2(*reinterpret_cast<const float*>(ab + lo_a0 + 4), *reinterpret_cast<const float*>(ab + lo_a1 + 4));
     };
     auto generate = [&](unsigned char* buf, int next_panel) {
         if constexpr (OCT) {
@@ -303,6 +322,36 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                 }
             }
             fetch(next_panel, hf);
+            return;
+        }
+        if constexpr (CPLX) {
+            const float sb = scl * (1.0f / 128.0f), si = sb * A.imsign;
+#pragma unroll
+            for (int hf = 0; hf < MF_NH; ++hf) {
+                const float ar0 = av[hf].x * sb, ar1 = av[hf].y * sb, ai0 = aw[hf].x * si, ai1 = aw[hf].y * si;
+#pragma unroll
+                for (int u = 0; u < SH::GEN; ++u) {
+                    const double ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
+                    const double ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
+                    const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                    const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
+                    const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+                    uint32_t rh, rl, ih, il;
+                    if (u < SH::GEN_I) {             // group I: L = 2^7 E
+                        split2(128.0f * c0, 128.0f * c1, rh, rl);
+                        split2(128.0f * s0, 128.0f * s1, ih, il);
+                    } else {                         // group J: B = psky E (complex product)
+                        split2(fmaf(ar0, c0, -ai0 * s0), fmaf(ar1, c1, -ai1 * s1), rh, rl);
+                        split2(fmaf(ar0, s0, ai0 * c0), fmaf(ar1, s1, ai1 * c1), ih, il);
+                    }
+                    unsigned char* o = buf + goff + u * SH::GROWS * MF_ROWB + 32 * hf;
+                    *reinterpret_cast<uint32_t*>(o) = rh;
+                    *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+                    *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+                    *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+                }
+                fetch(next_panel, hf);
+            }
             return;
         }
 #pragma unroll
@@ -347,6 +396,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
         // K step outermost: only one K step's row fragments are live at a time (16 registers fewer)
 #pragma unroll
         for (int ks = 0; ks < MF_NH; ++ks) {
+            if constexpr (SH::KSPLIT) { if (ks != (W & 1)) continue; }
             uint4 Lrh, Lih, Lrl, Lil;                                 // sign-applied row-tile fragments
             static_for<T0, T1>([&](auto tc) {
                 constexpr int tile = decltype(tc)::value;
@@ -448,6 +498,19 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
             f32x16 val;
 #pragma unroll
             for (int e = 0; e < 16; ++e) val[e] = im ? acc[s][0][e] - acc[s][1][e] : acc[s][0][e];
+            if constexpr (SH::KSPLIT) {
+                // the odd wave of a pair hands its K step's partial tile to the even one ([e][lane] floats
+                // behind the four transposition tiles)
+                float* ex = reinterpret_cast<float*>(smem) + 4 * (32 * 33) + (W >> 1) * (16 * 64);
+                if constexpr ((W & 1) == 1) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ex[e * 64 + lane] = val[e];
+                }
+                __syncthreads();
+                if constexpr ((W & 1) == 1) return;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) val[e] += ex[e * 64 + lane];
+            }
             if (is_diag<SH>(u >> 1)) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) tr[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 33 + col] = val[e];
@@ -484,38 +547,42 @@ __device__ __forceinline__ bool row_is_signed(const AntArgs& A)
     return A.rowmin[t * A.Nf + f] < 0.f;
 }
 
-template <class SH, bool SIGNED>
+template <class SH, bool SIGNED, bool CPLX>
 __device__ __forceinline__ void ant_fwd_dispatch(const AntArgs& A, unsigned char* smem)
 {
-    if (row_is_signed(A) != SIGNED) return;          // uniform over the block
+    if constexpr (!CPLX) { if (row_is_signed(A) != SIGNED) return; }        // uniform over the block
     switch (threadIdx.x >> 6) {                      // wave-uniform: every wave runs the same barriers
-        case 0: ant_fwd_body<SH, 0, SIGNED>(A, smem); break;
-        case 1: ant_fwd_body<SH, 1, SIGNED>(A, smem); break;
-        case 2: if constexpr (SH::NW > 2) ant_fwd_body<SH, 2, SIGNED>(A, smem); break;
-        case 3: if constexpr (SH::NW > 2) ant_fwd_body<SH, 3, SIGNED>(A, smem); break;
-        case 4: if constexpr (SH::NW > 4) ant_fwd_body<SH, 4, SIGNED>(A, smem); break;
-        case 5: if constexpr (SH::NW > 4) ant_fwd_body<SH, 5, SIGNED>(A, smem); break;
-        case 6: if constexpr (SH::NW > 4) ant_fwd_body<SH, 6, SIGNED>(A, smem); break;
-        default: if constexpr (SH::NW > 4) ant_fwd_body<SH, 7, SIGNED>(A, smem); break;
+        case 0: ant_fwd_body<SH, 0, SIGNED, CPLX>(A, smem); break;
+        case 1: ant_fwd_body<SH, 1, SIGNED, CPLX>(A, smem); break;
+        case 2: if constexpr (SH::NW > 2) ant_fwd_body<SH, 2, SIGNED, CPLX>(A, smem); break;
+        case 3: if constexpr (SH::NW > 2) ant_fwd_body<SH, 3, SIGNED, CPLX>(A, smem); break;
+        case 4: if constexpr (SH::NW > 4) ant_fwd_body<SH, 4, SIGNED, CPLX>(A, smem); break;
+        case 5: if constexpr (SH::NW > 4) ant_fwd_body<SH, 5, SIGNED, CPLX>(A, smem); break;
+        case 6: if constexpr (SH::NW > 4) ant_fwd_body<SH, 6, SIGNED, CPLX>(A, smem); break;
+        default: if constexpr (SH::NW > 4) ant_fwd_body<SH, 7, SIGNED, CPLX>(A, smem); break;
     }
 }
 
-template <int TA> constexpr int fwd_threads() { return FwdShape<TA, false>::NW * 64; }
+template <int TA> constexpr int fwd_threads() { return FwdShape<TA, TA, false>::NW * 64; }
 
 template <int TA, bool SIGNED>
 __global__ void __launch_bounds__(fwd_threads<TA>(), 2)
 fringe_ant_fwd_kernel(AntArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    ant_fwd_dispatch<FwdShape<TA, false>, SIGNED>(A, smem);
+    ant_fwd_dispatch<FwdShape<TA, TA, false>, SIGNED, false>(A, smem);
 }
 
-template <bool SIGNED>
-__global__ void __launch_bounds__(512, 1)
+// cross blocks: TI x TJ tiles, (1,1) (1,2) (2,2) (4,4); 8 waves for the 16-tile shape
+template <int TI, int TJ> constexpr int cross_threads() { return FwdShape<TI, TJ, true>::NW * 64; }
+template <int TI, int TJ> constexpr int cross_minwaves() { return FwdShape<TI, TJ, true>::NW == 8 ? 1 : 2; }
+
+template <int TI, int TJ, bool SIGNED, bool CPLX>
+__global__ void __launch_bounds__((cross_threads<TI, TJ>()), (cross_minwaves<TI, TJ>()))
 fringe_ant_fwd_cross_kernel(AntArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    ant_fwd_dispatch<FwdShape<4, true>, SIGNED>(A, smem);
+    ant_fwd_dispatch<FwdShape<TI, TJ, true>, SIGNED, CPLX>(A, smem);
 }
 
 
@@ -551,8 +618,10 @@ struct AntBwdArgs {
     int Nant, Nbl, Nt, Nf, Pstride;
     int S, tiles_per_split;    // pixel tiles (32 px) per block
     int accumulate;            // add to gpsky instead of overwriting (blocks after the first)
+    int rows_i;                // cross blocks: antpos rows of group I (group J follows)
     long long st_t, st_f, st_p;
     double sign;
+    float imsign;              // complex psky: sign of the imaginary-plane gradient (-1: block contracted conj(psky))
 };
 
 constexpr int MB_TILES = 10;                        // upper-triangular 32x32 tiles of a 128x128 matrix
@@ -561,6 +630,10 @@ constexpr size_t MB_LDS = 6 * (size_t)MB_PLANE + MF_NA * 3 * sizeof(double);
 
 __device__ __forceinline__ int tri_index(int ti, int tj) { return ti * 4 - ti * (ti - 1) / 2 + (tj - ti); }
 
+// CPLX: psky is complex (interleaved).  With Z = sum_ij conj(F_ij) g_ij = conj(sum_i conj(E_i) T_i) the two
+// gradient planes are Re Z and Im Z: the same T, a second lane-local contraction (Ei Tr - Er Ti) -- the
+// imaginary plane costs 32 FMAs per pixel tile and wave instead of a second pass.
+template <bool CPLX>
 __global__ void __launch_bounds__(512, 2)
 fringe_ant_bwd_kernel(AntBwdArgs A)
 {
@@ -632,7 +705,7 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { accR[q][e] = 0.f; accI[q][e] = 0.f; }
-        float part = 0.f;
+        float part = 0.f, parti = 0.f;
 #pragma unroll
         for (int tjr = 0; tjr < 4; ++tjr) {
             const int tj = 3 - tjr;                          // descending: row tile tj completes here
@@ -693,13 +766,24 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                 for (int e = 0; e < 16; ++e) {
                     part = fmaf(ec[e], accR[tj][e], part);
                     part = fmaf(es[e], accI[tj][e], part);
+                    if constexpr (CPLX) {
+                        parti = fmaf(es[e], accR[tj][e], parti);
+                        parti = fmaf(-ec[e], accI[tj][e], parti);
+                    }
                 }
             }
         }
         part += __shfl_xor(part, 32, 64);
+        if constexpr (CPLX) parti += __shfl_xor(parti, 32, 64);
         if (h == 0) {
             float* o = orow + (size_t)p * A.st_p;
-            *o = A.accumulate ? *o + part * inv : part * inv;
+            if constexpr (CPLX) {
+                const float im = parti * inv * A.imsign;
+                float2* o2 = reinterpret_cast<float2*>(o);
+                *o2 = A.accumulate ? make_float2(o2->x + part * inv, o2->y + im) : make_float2(part * inv, im);
+            } else {
+                *o = A.accumulate ? *o + part * inv : part * inv;
+            }
         }
     }
 }
@@ -711,9 +795,12 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
 // generated after the MFMA loop.  Four G planes (Gr, Gi; hi, lo; 128 KB) -- the -Gi products use
 // a sign-flipped Er fragment instead (8 v_xor per 16 antennas, shared by the 4 row tiles).
 // Adds to gpsky (A.accumulate): every pixel is owned by one lane, launches are stream-ordered.
+// Shapes: group I = A.rows_i antpos rows (TI = rows_i / 32 row tiles), group J = the remaining rows (TJ tiles);
+// tiles keep the 4 x 4 numbering of the full shape.
 constexpr int MX_PLANE = 16 * 2 * 2 * 32 * 16;        // 32768 B
 constexpr size_t MX_LDS = 4 * (size_t)MX_PLANE + 2 * MF_NA * 3 * sizeof(double);
 
+template <bool CPLX>
 __global__ void __launch_bounds__(512, 2)
 fringe_ant_bwd_cross_kernel(AntBwdArgs A)
 {
@@ -726,6 +813,7 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
     // vectors (L2 hits), and no grid dimension hits the 65535 cap
     const int f = blockIdx.x % A.Nf, ts = blockIdx.x / A.Nf;
     const int t = ts / A.S, split = ts % A.S;
+    const int TI = A.rows_i / 32, TJ = (A.Nant - A.rows_i) / 32, JB = A.rows_i;      // uniform
 
     const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
     for (int i = tid; i < 2 * MF_NA * 3; i += 512)
@@ -737,6 +825,7 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
     for (int e = tid; e < 16 * 2 * 2 * 32 * 4; e += 512) {
         const int jp = e & 3, row = (e >> 2) & 31, h = (e >> 7) & 1, ks = (e >> 8) & 1, tile = e >> 9;
         const int ti = tile >> 2, tj = tile & 3;
+        if (ti >= TI || tj >= TJ) continue;               // tiles outside the block's shape are never read
         const int i = 32 * ti + row;
         const int j0 = 32 * tj + ((2 * jp) & 3) + 8 * (2 * ks + (jp >> 1)) + 4 * h;
         float gr[2] = {0.f, 0.f}, gi[2] = {0.f, 0.f};
@@ -776,16 +865,16 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
             for (int e = 0; e < 16; ++e) { accR[q][e] = 0.f; accI[q][e] = 0.f; }
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
+            if (tj >= TJ) continue;                                     // uniform
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if (MF_NA + 32 * tj + 16 * ks >= A.Nant) continue;      // uniform: 16 padding antennas of group J (zero G columns)
                 uint4 Erh, Erl, Eih, Eil, Nrh, Nrl;
                 uint32_t* erh = reinterpret_cast<uint32_t*>(&Erh); uint32_t* erl = reinterpret_cast<uint32_t*>(&Erl);
                 uint32_t* eih = reinterpret_cast<uint32_t*>(&Eih); uint32_t* eil = reinterpret_cast<uint32_t*>(&Eil);
                 float ec[8], es[8];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
-                    const int an = MF_NA + 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
+                    const int an = JB + 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
                     const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
                     const float rr = (float)__builtin_amdgcn_fract(ph);
                     ec[jj] = __builtin_amdgcn_cosf(rr);
@@ -800,6 +889,7 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
                 Nrl = make_uint4(Erl.x ^ 0x80008000u, Erl.y ^ 0x80008000u, Erl.z ^ 0x80008000u, Erl.w ^ 0x80008000u);
 #pragma unroll
                 for (int ti = 0; ti < 4; ++ti) {
+                    if (ti >= TI) continue;                             // uniform
                     const int off = ((((ti * 4 + tj) * 2 + ks) * 2 + h) * 32 + (lane & 31)) * 16;
                     const uint4 Grh = *reinterpret_cast<const uint4*>(g_img + 0 * MX_PLANE + off);
                     const uint4 Gih = *reinterpret_cast<const uint4*>(g_img + 1 * MX_PLANE + off);
@@ -822,23 +912,36 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
             }
         }
         // contraction with E_i of group I: the D rows this lane holds
-        float part = 0.f;
+        float part = 0.f, parti = 0.f;
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
+            if (ti >= TI) continue;                                     // uniform
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int an = 32 * ti + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
                 const float rr = (float)__builtin_amdgcn_fract(ph);
-                part = fmaf(__builtin_amdgcn_cosf(rr), accR[ti][e], part);
-                part = fmaf(__builtin_amdgcn_sinf(rr), accI[ti][e], part);
+                const float ce = __builtin_amdgcn_cosf(rr), se = __builtin_amdgcn_sinf(rr);
+                part = fmaf(ce, accR[ti][e], part);
+                part = fmaf(se, accI[ti][e], part);
+                if constexpr (CPLX) {
+                    parti = fmaf(se, accR[ti][e], parti);
+                    parti = fmaf(-ce, accI[ti][e], parti);
+                }
                 if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         part += __shfl_xor(part, 32, 64);
+        if constexpr (CPLX) parti += __shfl_xor(parti, 32, 64);
         if (h == 0) {
             float* o = orow + (size_t)p * A.st_p;
-            *o = A.accumulate ? *o + part * inv : part * inv;
+            if constexpr (CPLX) {
+                const float im = parti * inv * A.imsign;
+                float2* o2 = reinterpret_cast<float2*>(o);
+                *o2 = A.accumulate ? make_float2(o2->x + part * inv, o2->y + im) : make_float2(part * inv, im);
+            } else {
+                *o = A.accumulate ? *o + part * inv : part * inv;
+            }
         }
     }
 }
@@ -931,45 +1034,71 @@ extern "C" size_t rime_fringe_ant_workspace(int Nbl, int Nt, int Nf, int Pstride
     return (size_t)S * Nbl * Nt * Nf * 2 * sizeof(float);
 }
 
-static bool ant_common_ok(int Nrows, int cross, int Nbl, int Nt, int Nf, int Pstride, long long st_p, int sign)
+static bool cross_shape_ok(int rows_i, int rows_j)
+{
+    return (rows_i == 32 && rows_j == 32) || (rows_i == 32 && rows_j == 64) || (rows_i == 64 && rows_j == 64) ||
+           (rows_i == 128 && rows_j == 128);
+}
+
+static bool ant_common_ok(int Nrows, int cross, int Nbl, int Nt, int Nf, int Pstride, long long st_p, int sign, int cplx)
 {
     if (st_p != 1 && st_p != 2) return false;
-    if (cross ? (Nrows != 2 * MF_NA) : (Nrows <= 0 || Nrows > MF_NA)) return false;
+    if (cplx != 0 && (cplx != 1 && cplx != -1)) return false;
+    if (cplx != 0 && st_p != 2) return false;                      // complex psky: interleaved (re, im)
+    if (cross ? !cross_shape_ok(cross, Nrows - cross) : (Nrows <= 0 || Nrows > MF_NA)) return false;
     if (Nbl <= 0 || Nt <= 0 || Nt > 65535 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0) return false;
     return sign == 1 || sign == -1;
+}
+
+template <int TI, int TJ>
+static void launch_fwd_cross(const AntArgs& A, dim3 grid, hipStream_t st, bool has_rowmin, int cplx)
+{
+    using SH = FwdShape<TI, TJ, true>;
+    if (cplx) {
+        hipLaunchKernelGGL((fringe_ant_fwd_cross_kernel<TI, TJ, false, true>), grid, dim3(SH::NW * 64), SH::LDS, st, A);
+        return;
+    }
+    hipLaunchKernelGGL((fringe_ant_fwd_cross_kernel<TI, TJ, true, false>), grid, dim3(SH::NW * 64), SH::LDS, st, A);
+    if (has_rowmin) hipLaunchKernelGGL((fringe_ant_fwd_cross_kernel<TI, TJ, false, false>), grid, dim3(SH::NW * 64), SH::LDS, st, A);
 }
 
 extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
                                          const double* freqs, const float* psky, const float* scale,
                                          const float* rowmin, const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf,
                                          int Pstride, long long st_t, long long st_f, long long st_p, int sign,
-                                         void* workspace, size_t workspace_bytes, void* stream)
+                                         int psky_complex, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!antpos || !sdir || !freqs || !psky || !scale || !pair_direct || !pair_conj) return RIME_EINVAL;
-    if (!ant_common_ok(Nrows, cross, Nbl, Nt, Nf, Pstride, st_p, sign)) return RIME_EINVAL;
+    if (!ant_common_ok(Nrows, cross, Nbl, Nt, Nf, Pstride, st_p, sign, psky_complex)) return RIME_EINVAL;
+    if (psky_complex && !cross) return RIME_EUNSUPPORTED;          // diagonal blocks: one real plane per call
     AntArgs A{};
-    A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.psky = psky; A.scale = scale; A.rowmin = rowmin;
+    A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.psky = psky; A.scale = scale; A.rowmin = psky_complex ? nullptr : rowmin;
     A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.vis = nullptr; A.ws = (float*)workspace;
     A.Nant = Nrows; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
-    A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign;
+    A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign; A.imsign = psky_complex < 0 ? -1.f : 1.f;
     ant_split_plan(Nt, Nf, Pstride, A.S, A.panels_per_split);
     if (!workspace || workspace_bytes < rime_fringe_ant_workspace(Nbl, Nt, Nf, Pstride)) return RIME_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
-#define RIME_FWD_PAIR(KERNEL_T, KERNEL_F, THREADS, LDSB)                                   \
-    do {                                                                                   \
-        hipLaunchKernelGGL(KERNEL_T, grid, dim3(THREADS), LDSB, st, A);                    \
-        if (rowmin) hipLaunchKernelGGL(KERNEL_F, grid, dim3(THREADS), LDSB, st, A);        \
-    } while (0)
     if (cross) {
-        RIME_FWD_PAIR((fringe_ant_fwd_cross_kernel<true>), (fringe_ant_fwd_cross_kernel<false>), 512, (FwdShape<4, true>::LDS));
+        const int ti = cross / 32, tj = (Nrows - cross) / 32;
+        if (ti == 1 && tj == 1) launch_fwd_cross<1, 1>(A, grid, st, rowmin != nullptr, psky_complex);
+        else if (ti == 1 && tj == 2) launch_fwd_cross<1, 2>(A, grid, st, rowmin != nullptr, psky_complex);
+        else if (ti == 2 && tj == 2) launch_fwd_cross<2, 2>(A, grid, st, rowmin != nullptr, psky_complex);
+        else launch_fwd_cross<4, 4>(A, grid, st, rowmin != nullptr, psky_complex);
         return check_launch();
     }
+#define RIME_FWD_PAIR(TA)                                                                                      \
+    do {                                                                                                       \
+        using SH = FwdShape<TA, TA, false>;                                                                    \
+        hipLaunchKernelGGL((fringe_ant_fwd_kernel<TA, true>), grid, dim3(SH::NW * 64), SH::LDS, st, A);        \
+        if (rowmin) hipLaunchKernelGGL((fringe_ant_fwd_kernel<TA, false>), grid, dim3(SH::NW * 64), SH::LDS, st, A); \
+    } while (0)
     switch ((Nrows + 31) / 32) {
-        case 1: RIME_FWD_PAIR((fringe_ant_fwd_kernel<1, true>), (fringe_ant_fwd_kernel<1, false>), (FwdShape<1, false>::NW * 64), (FwdShape<1, false>::LDS)); break;
-        case 2: RIME_FWD_PAIR((fringe_ant_fwd_kernel<2, true>), (fringe_ant_fwd_kernel<2, false>), (FwdShape<2, false>::NW * 64), (FwdShape<2, false>::LDS)); break;
-        case 3: RIME_FWD_PAIR((fringe_ant_fwd_kernel<3, true>), (fringe_ant_fwd_kernel<3, false>), (FwdShape<3, false>::NW * 64), (FwdShape<3, false>::LDS)); break;
-        default: RIME_FWD_PAIR((fringe_ant_fwd_kernel<4, true>), (fringe_ant_fwd_kernel<4, false>), (FwdShape<4, false>::NW * 64), (FwdShape<4, false>::LDS)); break;
+        case 1: RIME_FWD_PAIR(1); break;
+        case 2: RIME_FWD_PAIR(2); break;
+        case 3: RIME_FWD_PAIR(3); break;
+        default: RIME_FWD_PAIR(4); break;
     }
 #undef RIME_FWD_PAIR
     return check_launch();
@@ -996,7 +1125,7 @@ extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, con
 {
     if (!vis) return RIME_EINVAL;
     const int rc = rime_fringe_ant_fwd_block(antpos, Nant, 0, sdir, freqs, psky, scale, rowmin, pair_direct, pair_conj,
-                                             Nbl, Nt, Nf, Pstride, st_t, st_f, st_p, sign, workspace,
+                                             Nbl, Nt, Nf, Pstride, st_t, st_f, st_p, sign, 0, workspace,
                                              workspace_bytes, stream);
     if (rc != RIME_OK) return rc;
     return rime_fringe_ant_fwd_finish(workspace, workspace_bytes, vis, Nbl, Nt, Nf, Pstride, stream);
@@ -1021,17 +1150,18 @@ extern "C" int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cr
                                          const double* freqs, const float* gscale, const int* pair_direct,
                                          const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
                                          long long st_t, long long st_f, long long st_p, int sign,
-                                         int accumulate, float* gpsky, const void* workspace,
+                                         int psky_complex, int accumulate, float* gpsky, const void* workspace,
                                          size_t workspace_bytes, void* stream)
 {
     if (!antpos || !sdir || !freqs || !gscale || !pair_direct || !pair_conj || !gpsky) return RIME_EINVAL;
-    if (!ant_common_ok(Nrows, cross, Nbl, Nt, Nf, Pstride, st_p, sign)) return RIME_EINVAL;
+    if (!ant_common_ok(Nrows, cross, Nbl, Nt, Nf, Pstride, st_p, sign, psky_complex)) return RIME_EINVAL;
     if (!workspace || workspace_bytes < rime_fringe_ant_bwd_workspace(Nbl, Nt, Nf)) return RIME_EWORKSPACE;
     AntBwdArgs A{};
     A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.gvis = nullptr; A.gscale = gscale;
     A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.gpsky = gpsky; A.gvt = (const float*)workspace;
     A.Nant = Nrows; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
     A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign; A.accumulate = accumulate ? 1 : 0;
+    A.rows_i = cross; A.imsign = psky_complex < 0 ? -1.f : 1.f;
     // pixel ranges are independent outputs: split freely for parallelism (>= 256 pixel tiles/block
     // amortise the G staging; fewer when the grid would otherwise be small)
     const int ntile = Pstride / 32;
@@ -1041,8 +1171,13 @@ extern "C" int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cr
     A.S = (ntile + per - 1) / per;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
-    if (cross) hipLaunchKernelGGL(fringe_ant_bwd_cross_kernel, grid, dim3(512), MX_LDS, st, A);
-    else hipLaunchKernelGGL(fringe_ant_bwd_kernel, grid, dim3(512), MB_LDS, st, A);
+    if (cross) {
+        if (psky_complex) hipLaunchKernelGGL(fringe_ant_bwd_cross_kernel<true>, grid, dim3(512), MX_LDS, st, A);
+        else hipLaunchKernelGGL(fringe_ant_bwd_cross_kernel<false>, grid, dim3(512), MX_LDS, st, A);
+    } else {
+        if (psky_complex) hipLaunchKernelGGL(fringe_ant_bwd_kernel<true>, grid, dim3(512), MB_LDS, st, A);
+        else hipLaunchKernelGGL(fringe_ant_bwd_kernel<false>, grid, dim3(512), MB_LDS, st, A);
+    }
     return check_launch();
 }
 
@@ -1055,5 +1190,5 @@ extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, con
     const int rc = rime_fringe_ant_bwd_prepare(gvis, Nbl, Nt, Nf, workspace, workspace_bytes, stream);
     if (rc != RIME_OK) return rc;
     return rime_fringe_ant_bwd_block(antpos, Nant, 0, sdir, freqs, gscale, pair_direct, pair_conj, Nbl, Nt, Nf,
-                                     Pstride, st_t, st_f, st_p, sign, 0, gpsky, workspace, workspace_bytes, stream);
+                                     Pstride, st_t, st_f, st_p, sign, 0, 0, gpsky, workspace, workspace_bytes, stream);
 }

@@ -59,10 +59,13 @@ class FringeGeometry:
     minibatch and reused by forward and backward.
 
     blvecs (Nbl, 3) [m]; sdir (Nt, 3, Pstride) unit vectors, zero-padded past each time's
-    pixel count; freqs (Nf,) [Hz]; bl_models: optional list of model-pair index per baseline.
+    pixel count; freqs (Nf,) [Hz]; bl_mp: optional beam-model-pair index per baseline (Nmp pairs,
+    mp_pairs = their (model1, model2) tuples: needed for the matrix-core path with several models);
+    antpos (Nant, 3) + bl_ants (antenna-index pairs) enable the antenna-factored matrix-core kernels;
+    group: antennas per block group of that path (default 128; 32 / 64 for rank-local tile shards).
     """
     def __init__(self, blvecs, sdir, freqs, bl_mp=None, Nmp=1, conj=False, npix=None,
-                 antpos=None, bl_ants=None, mfma='auto', ant_like=None):
+                 antpos=None, bl_ants=None, mfma='auto', ant_like=None, mp_pairs=None, group=None):
         _require_cuda(blvecs, sdir)
         dev = blvecs.device
         self.blvecs = blvecs.detach().to(torch.float64).contiguous()
@@ -102,7 +105,8 @@ class FringeGeometry:
             if self.Nt > 65535:
                 self.ant = None
         elif antpos is not None and bl_ants is not None and mfma in ('auto', True):
-            self._setup_antenna_path(antpos, bl_ants, force=(mfma is True))
+            self._setup_antenna_path(antpos, bl_ants, force=(mfma is True), bl_mp=bl_mp if int(Nmp) > 1 else None,
+                                     mp_pairs=mp_pairs, group=group or MFMA_GROUP)
         # model-pair grouping
         self.Nmp = int(Nmp)
         if bl_mp is None or self.Nmp == 1:
@@ -120,15 +124,39 @@ class FringeGeometry:
 
 MFMA_MIN_ANTS = int(os.environ.get('RIME_MFMA_MIN_ANTS', '33'))   # 'auto' threshold (see _setup_antenna_path)
 MFMA_GROUP = 128          # antennas per group of the matrix-core path (4 x 4 tiles of 32)
+MFMA_MAX_ANTS = 2048      # table memory only: 136 blocks x 128 KB at 2048 antennas
 
 
-def _antenna_blocks(bl_ants, Nant):
+def _group_capacity(n, group):
+    """rows a group of n antennas occupies in a cross block: 32, 64 or 128 (the kernels' shapes)"""
+    if group <= 32 or n <= 32:
+        return 32
+    return 64 if (group <= 64 or n <= 64) else 128
+
+
+def _antenna_blocks(bl_ants, Nant, bl_mp=None, ant_model=None, group=MFMA_GROUP):
     """
-    Pair tables of the matrix-core path (see include/rime_hip.h).  Antennas are cut into groups of
-    MFMA_GROUP; returns {(I, J): (direct, conj)} with I <= J, int32 [128, 128] tables of baseline
-    slots indexed by the LOCAL antenna indices (row in group I, column in group J), or None when a
-    pair occurs twice (not representable).
+    Block decomposition of the pair matrix for the matrix-core path (see include/rime_hip.h).
+    Antennas are ordered by (beam model, index) and cut into groups of <= `group` antennas that share
+    a beam model; every (group pair, beam-model pair) that holds a baseline becomes one block with its
+    own psky plane `mp`:
+      diagonal block: one group against itself (upper-triangular 32 x 32 tiles),
+      cross block   : group I x group J, rows padded to a supported shape (32, 32), (32, 64), (64, 64)
+                      or (128, 128) antenna rows.
+    Returns a list of dicts {ants_i, ants_j | None, rows_i, rows_j, mp, direct, conj, cpass}, tables
+    int32 [128, 128] of baseline slots indexed by LOCAL antenna indices, or None when a pair occurs
+    twice (not representable).  cpass: +1 the block holds direct entries only, -1 conj entries only,
+    0 both (a complex psky then takes one pass per real plane).
     """
+    if ant_model is None:
+        ant_model = [0] * Nant
+    order = sorted(range(Nant), key=lambda a: (ant_model[a], a))
+    groups, gid, lid = [], {}, {}
+    for a in order:
+        if not groups or ant_model[groups[-1][0]] != ant_model[a] or len(groups[-1]) >= group:
+            groups.append([])
+        gid[a], lid[a] = len(groups) - 1, len(groups[-1])
+        groups[-1].append(a)
     tabs = {}
 
     def get(key):
@@ -138,22 +166,41 @@ def _antenna_blocks(bl_ants, Nant):
         return tabs[key]
 
     for b, (a1, a2) in enumerate(bl_ants):
-        g1, l1 = divmod(a1, MFMA_GROUP)
-        g2, l2 = divmod(a2, MFMA_GROUP)
+        mp = 0 if bl_mp is None else int(bl_mp[b])
+        g1, l1, g2, l2 = gid[a1], lid[a1], gid[a2], lid[a2]
         if g1 == g2:
-            direct, conj = get((g1, g1))
+            direct, conj = get((g1, g1, mp))
             if l1 // 32 <= l2 // 32:
                 tab, i, j = direct, l1, l2
             else:
                 tab, i, j = conj, l2, l1
         elif g1 < g2:
-            tab, i, j = get((g1, g2))[0], l1, l2           # baseline I_i -> J_j: V[i, j]
+            tab, i, j = get((g1, g2, mp))[0], l1, l2           # baseline I_i -> J_j: V[i, j]
         else:
-            tab, i, j = get((g2, g1))[1], l2, l1           # baseline J_j -> I_i: conj(V[i, j])
+            tab, i, j = get((g2, g1, mp))[1], l2, l1           # baseline J_j -> I_i: conj(V[i, j])
         if tab[i, j] >= 0:
             return None
         tab[i, j] = b
-    return tabs
+    blocks = []
+    for (gi, gj, mp) in sorted(tabs):
+        direct, conj = tabs[(gi, gj, mp)]
+        nd, nc = int((direct >= 0).sum()), int((conj >= 0).sum())
+        blk = dict(ants_i=groups[gi], ants_j=None, rows_i=len(groups[gi]), rows_j=0, mp=mp,
+                   cpass=(1 if nc == 0 else (-1 if nd == 0 else 0)))
+        if gi != gj:
+            ci, cj = _group_capacity(len(groups[gi]), group), _group_capacity(len(groups[gj]), group)
+            if (ci, cj) not in ((32, 32), (32, 64), (64, 32), (64, 64), (128, 128)):
+                ci = cj = 128                                # unequal groups: padded to the full shape
+            ai, aj = groups[gi], groups[gj]
+            if ci > cj:
+                # the kernels take the smaller group as I: swap the groups (V[j, i] = conj(V[i, j]))
+                ai, aj, ci, cj = aj, ai, cj, ci
+                direct, conj = conj.T.copy(), direct.T.copy()
+                blk['cpass'] = -blk['cpass']
+            blk.update(ants_i=ai, ants_j=aj, rows_i=ci, rows_j=cj)
+        blk['direct'], blk['conj'] = direct, conj
+        blocks.append(blk)
+    return blocks
 
 
 def _dense_strides(t):
@@ -170,9 +217,6 @@ def _dense_strides(t):
     return (ctypes.c_longlong * 4)(*[int(max(s, 1)) for s in st[:4]])
 
 
-MFMA_MAX_ANTS = 2048      # table memory only: 136 blocks x 128 KB at 2048 antennas
-
-
 def _pow2_scale(amax):
     """power of two s with amax * s in [2^13, 2^14]; 1 where amax == 0 (exact to apply and undo)"""
     safe = torch.where(amax > 0, amax, torch.ones_like(amax))
@@ -182,46 +226,62 @@ def _pow2_scale(amax):
 
 def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
     """
-    antenna-factored kernels, one pass per real plane of psky: the Npp polarisation products and,
-    for a complex psky, its real and imaginary planes (V is linear in psky:
-    V[ar + i ai] = V[ar] + i V[ai]; d/d(ai) = Re(conj(F) (-i g))).  A pass launches one kernel per
-    antenna-group block.  Returns the number of passes.
+    antenna-factored kernels: one launch per block of the pair matrix (ops._antenna_blocks), each on
+    the psky plane of its beam-model pair.  Real psky: one pass per polarisation product.  Complex
+    psky (V is linear in psky: V[ar + i ai] = V[ar] + i V[ai]; d/d(ai) = Re(conj(F) (-i g))): blocks
+    whose entries all have one orientation take ONE complex pass (forward: cross blocks; backward:
+    every block, the imaginary plane is a second lane-local contraction of the same products); the
+    others take one pass per real plane.  Returns the MFMA flops executed.
     """
     a = geom.ant
+    blocks = a['blocks']
     m = 2 if cplx else 1                                     # floats per psky element
-    st_t, st_pp, st_f = (int(strides[k]) * m for k in (0, 2, 3))
-    Nbl, Nt, Nf = geom.Nbl, geom.Nt, geom.Nf
+    st_t, st_mp, st_pp, st_f = (int(strides[k]) * m for k in range(4))
+    Nbl, Nt, Nf, Nmp = geom.Nbl, geom.Nt, geom.Nf, geom.Nmp
     dev = inp.device
     geo = (_ptr(geom.sdir), _ptr(geom.freqs))
     shape = (Nbl, Nt, Nf, geom.Pstride, st_t, st_f, m, geom.sign)
+    per16 = Nt * Nf * (geom.Pstride // 16) * 32768
+    flops = 0
     if not backward:
-        # inp: psky (Nt, 1, Npp, Nf, Ps[, 2]) float32 view; out: vis (Npp, Nbl, Nt, Nf, 2) float32
+        # inp: psky (Nt, Nmp, Npp, Nf, Ps[, 2]) float32 view; out: vis (Npp, Nbl, Nt, Nf, 2) float32
         if cplx:
-            amax = inp.abs().amax(dim=(-1, -2))                                    # (Nt, 1, Npp, Nf)
-            lo = inp.amin(dim=-2)                                                  # (Nt, 1, Npp, Nf, 2): per plane
-            rowmin = [lo[..., c].reshape(Nt, Npp, Nf).permute(1, 0, 2).contiguous() for c in range(2)]
+            amax = inp.abs().amax(dim=(-1, -2))                                    # (Nt, Nmp, Npp, Nf)
+            lo = inp.amin(dim=-2)                                                  # (Nt, Nmp, Npp, Nf, 2): per plane
+            rowmin = [lo[..., c].permute(1, 2, 0, 3).contiguous() for c in range(2)]
         else:
             lo, hi = torch.aminmax(inp, dim=-1)                                    # one pass, no |psky| temporary
             amax = torch.maximum(hi, -lo)
-            rowmin = [lo.reshape(Nt, Npp, Nf).permute(1, 0, 2).contiguous()]
-        scale = _pow2_scale(amax.reshape(Nt, Npp, Nf).permute(1, 0, 2)).contiguous()
+            rowmin = [lo.permute(1, 2, 0, 3).contiguous()]
+        scale = _pow2_scale(amax.permute(1, 2, 0, 3)).contiguous()                 # (Nmp, Npp, Nt, Nf)
         nbytes = lib.rime_fringe_ant_workspace(Nbl, Nt, Nf, geom.Pstride)
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
-        tmp = torch.empty((Nbl, Nt, Nf, 2), dtype=torch.float32, device=dev) if cplx else None
+        two_pass = [blk for blk in blocks if cplx and blk['fwd_cpass'] == 0]
+        tmp = torch.empty((Nbl, Nt, Nf, 2), dtype=torch.float32, device=dev) if two_pass else None
+
+        def launch(blk, pp, c, cflag):
+            mp = blk['mp']
+            src = ctypes.c_void_p(inp.data_ptr() + 4 * (mp * st_mp + pp * st_pp + c))
+            rc = lib.rime_fringe_ant_fwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], *geo, src,
+                                               _ptr(scale[mp, pp]), _ptr(rowmin[c][mp, pp]),
+                                               _ptr(blk['direct']), _ptr(blk['conj']),
+                                               *shape, cflag, _ptr(ws), ws.numel(), _stream())
+            check(rc, 'rime_fringe_ant_fwd_block')
+            return blk['mf_fwd']
+
         for pp in range(Npp):
-            for c in range(m):
-                dst = out[pp] if c == 0 else tmp
-                src = ctypes.c_void_p(inp.data_ptr() + 4 * (pp * st_pp + c))
-                for blk in a['blocks']:
-                    rc = lib.rime_fringe_ant_fwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], *geo, src,
-                                                       _ptr(scale[pp]), _ptr(rowmin[c][pp]),
-                                                       _ptr(blk['direct']), _ptr(blk['conj']),
-                                                       *shape, _ptr(ws), ws.numel(), _stream())
-                    check(rc, 'rime_fringe_ant_fwd_block')
-                rc = lib.rime_fringe_ant_fwd_finish(_ptr(ws), ws.numel(), _ptr(dst), Nbl, Nt, Nf, geom.Pstride,
-                                                    _stream())
-                check(rc, 'rime_fringe_ant_fwd_finish')
-            if cplx:                                         # V += i V[ai]
+            for blk in blocks:
+                single = cplx and blk['fwd_cpass'] != 0
+                flops += launch(blk, pp, 0, blk['fwd_cpass'] if single else 0)
+            check(lib.rime_fringe_ant_fwd_finish(_ptr(ws), ws.numel(), _ptr(out[pp]), Nbl, Nt, Nf, geom.Pstride,
+                                                 _stream()), 'rime_fringe_ant_fwd_finish')
+            if two_pass:                                     # V += i V[ai] on the baselines of those blocks
+                for blk in two_pass:
+                    flops += launch(blk, pp, 1, 0)
+                check(lib.rime_fringe_ant_fwd_finish(_ptr(ws), ws.numel(), _ptr(tmp), Nbl, Nt, Nf, geom.Pstride,
+                                                     _stream()), 'rime_fringe_ant_fwd_finish')
+                if len(two_pass) < len(blocks):
+                    tmp *= a['two_pass_mask']                # slots of single-pass blocks hold stale values
                 out[pp][..., 0] -= tmp[..., 1]
                 out[pp][..., 1] += tmp[..., 0]
     else:
@@ -229,26 +289,40 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
         nbytes = lib.rime_fringe_ant_bwd_workspace(Nbl, Nt, Nf)
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
         gvt = ws[:Nt * Nf * 2 * Nbl * 4].view(torch.float32).view(Nt * Nf, 2 * Nbl)    # what bwd_prepare writes
+        two_pass = [blk for blk in blocks if cplx and blk['cpass'] == 0]
         for pp in range(Npp):
-            for c in range(m):
+            written = set()
+            for c in range(2 if two_pass else 1):
                 g = inp[pp] if c == 0 else torch.stack([inp[pp][..., 1], -inp[pp][..., 0]], dim=-1).contiguous()
-                rc = lib.rime_fringe_ant_bwd_prepare(_ptr(g), Nbl, Nt, Nf, _ptr(ws), ws.numel(), _stream())
-                check(rc, 'rime_fringe_ant_bwd_prepare')
+                check(lib.rime_fringe_ant_bwd_prepare(_ptr(g), Nbl, Nt, Nf, _ptr(ws), ws.numel(), _stream()),
+                      'rime_fringe_ant_bwd_prepare')
                 if c == 0:
                     # max |gvis| per (t, f) from the transposed copy: a contiguous row reduction (the same
                     # reduction over the (Nbl, Nt, Nf, 2) layout is strided and 4x slower); -i g has the same maxima
                     lo, hi = torch.aminmax(gvt, dim=-1)
                     scale_pp = _pow2_scale(torch.maximum(hi, -lo)).contiguous()    # (Nt * Nf)
-                dst = ctypes.c_void_p(out.data_ptr() + 4 * (pp * st_pp + c))
-                for k, blk in enumerate(a['blocks']):
+                # single-pass blocks first: they initialise BOTH planes of their psky slice, the two-pass
+                # blocks then accumulate plane by plane
+                todo = sorted(blocks, key=lambda b: not (cplx and b['cpass'] != 0)) if c == 0 else two_pass
+                for blk in todo:
+                    single = cplx and blk['cpass'] != 0
+                    mp = blk['mp']
+                    planes = [(mp, 0), (mp, 1)] if single else [(mp, c)]
+                    acc = int(planes[0] in written)
+                    assert all((pl in written) == bool(acc) for pl in planes)
+                    written.update(planes)
+                    dst = ctypes.c_void_p(out.data_ptr() + 4 * (mp * st_mp + pp * st_pp + (0 if single else c)))
                     rc = lib.rime_fringe_ant_bwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], *geo,
                                                        _ptr(scale_pp), _ptr(blk['direct']), _ptr(blk['conj']),
-                                                       *shape, int(k > 0), dst, _ptr(ws), ws.numel(), _stream())
+                                                       *shape, blk['cpass'] if single else 0, acc, dst,
+                                                       _ptr(ws), ws.numel(), _stream())
                     check(rc, 'rime_fringe_ant_bwd_block')
-    return Npp * m
+                    flops += blk['mf_bwd']
+            assert len(written) == Nmp * m, 'every psky plane must be written by a block'
+    return flops * per16
 
 
-def _setup_antenna_path(self, antpos, bl_ants, force=False):
+def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs=None, group=MFMA_GROUP):
     """enable the antenna-factored matrix-core kernels when the baseline set suits them"""
     Nant = int(antpos.shape[0])
     bl_ants = [(int(a), int(b)) for a, b in bl_ants]
@@ -260,8 +334,21 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False):
     # 1.1x slower)
     if not force and (Nant < MFMA_MIN_ANTS or self.Nbl < Nant * Nant // 8):
         return
-    tabs = _antenna_blocks(bl_ants, Nant)
-    if tabs is None:
+    # several beam models: every antenna must carry ONE model (beam_model.py:303-327 pairs models per baseline)
+    ant_model = None
+    if bl_mp is not None and mp_pairs is not None and len(mp_pairs) > 1:
+        ant_model = [None] * Nant
+        for (a1, a2), mp in zip(bl_ants, bl_mp):
+            for ant, mdl in ((a1, mp_pairs[mp][0]), (a2, mp_pairs[mp][1])):
+                if ant_model[ant] is None:
+                    ant_model[ant] = mdl
+                elif ant_model[ant] != mdl:
+                    return
+        ant_model = [0 if mdl is None else mdl for mdl in ant_model]
+    elif bl_mp is not None and len(set(int(x) for x in bl_mp)) > 1:
+        return
+    raw = _antenna_blocks(bl_ants, Nant, bl_mp if ant_model is not None else None, ant_model, group)
+    if raw is None:
         return
     # the factorisation must reproduce the baseline vectors it replaces
     pos = antpos.detach().to(torch.float64).to(self.blvecs.device).contiguous()
@@ -270,46 +357,53 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False):
     if not torch.allclose(pos[i2] - pos[i1], self.blvecs, rtol=0, atol=1e-9):
         return
     dev = self.blvecs.device
-    blocks, tiles, mfma_fwd = [], 0, 0
-    for (gi, gj) in sorted(tabs):
-        direct, conj = tabs[(gi, gj)]
-        pi = pos[gi * MFMA_GROUP:min((gi + 1) * MFMA_GROUP, Nant)]
-        if gi == gj:
+    blocks, mfma_fwd, mfma_bwd = [], 0, 0
+    two_pass_mask = torch.zeros(self.Nbl, 1, 1, 1, dtype=torch.float32, device=dev)
+    for blk in raw:
+        pi = pos[torch.as_tensor(blk['ants_i'], device=dev)]
+        if blk['ants_j'] is None:
             rows, TA = pi.contiguous(), (pi.shape[0] + 31) // 32
-            tiles += TA * (TA + 1) // 2
-            mfma_fwd += 12 * (TA * (TA - 1) // 2) + 7 * TA      # diagonal tiles: symmetric products folded
+            mf_fwd = 12 * (TA * (TA - 1) // 2) + 7 * TA      # diagonal tiles: symmetric products folded
+            mf_bwd = 12 * (TA * (TA + 1) // 2)
+            cross, fwd_cpass = 0, 0                          # forward diagonal blocks: one real plane per call
         else:
-            pj = pos[gj * MFMA_GROUP:min((gj + 1) * MFMA_GROUP, Nant)]
-            rows = torch.zeros(2 * MFMA_GROUP, 3, dtype=torch.float64, device=pos.device)
+            pj = pos[torch.as_tensor(blk['ants_j'], device=dev)]
+            rows = torch.zeros(blk['rows_i'] + blk['rows_j'], 3, dtype=torch.float64, device=dev)
             rows[:pi.shape[0]] = pi
-            rows[MFMA_GROUP:MFMA_GROUP + pj.shape[0]] = pj
-            tiles += 16
-            mfma_fwd += 12 * 16
-        blocks.append(dict(pos=rows, nrows=int(rows.shape[0]), cross=int(gi != gj),
-                           direct=torch.as_tensor(direct.reshape(-1), device=dev),
-                           conj=torch.as_tensor(conj.reshape(-1), device=dev)))
+            rows[blk['rows_i']:blk['rows_i'] + pj.shape[0]] = pj
+            mf_fwd = mf_bwd = 12 * (blk['rows_i'] // 32) * (blk['rows_j'] // 32)
+            cross, fwd_cpass = blk['rows_i'], blk['cpass']
+        if fwd_cpass == 0:
+            slots = np.concatenate([blk['direct'][blk['direct'] >= 0], blk['conj'][blk['conj'] >= 0]])
+            two_pass_mask[torch.as_tensor(slots, dtype=torch.int64, device=dev)] = 1.0
+        blocks.append(dict(pos=rows, nrows=int(rows.shape[0]), cross=int(cross), mp=blk['mp'],
+                           cpass=blk['cpass'], fwd_cpass=fwd_cpass, mf_fwd=mf_fwd, mf_bwd=mf_bwd,
+                           direct=torch.as_tensor(blk['direct'].reshape(-1), device=dev),
+                           conj=torch.as_tensor(blk['conj'].reshape(-1), device=dev)))
+        mfma_fwd += mf_fwd
+        mfma_bwd += mf_bwd
     # executed matrix-core work per pass: per 16 pixels, 12 MFMAs of 2*32*32*16 flop on each 32x32
     # antenna tile of every block (3 hi/lo products x 4 real products); the forward runs 7 on the
     # diagonal tiles of a diagonal block
     per16 = self.Nt * self.Nf * (self.Pstride // 16) * 32768
-    self.ant = dict(blocks=blocks, Nant=Nant, tiles=tiles, mfma_fwd=mfma_fwd, mfma_bwd=12 * tiles,
-                    mfma_flops_fwd=per16 * mfma_fwd, mfma_flops_bwd=per16 * 12 * tiles)
+    self.ant = dict(blocks=blocks, Nant=Nant, mfma_fwd=mfma_fwd, mfma_bwd=mfma_bwd, two_pass_mask=two_pass_mask,
+                    mfma_flops_fwd=per16 * mfma_fwd, mfma_flops_bwd=per16 * mfma_bwd,
+                    multi_model=ant_model is not None)
 
 
 FringeGeometry._setup_antenna_path = _setup_antenna_path
 
 
 def _fringe_call(geom, backward, inp, out, Npp, cplx, strides=None):
-    if geom.ant is not None and geom.Nmp == 1 and inp.dtype == torch.float32 and strides is not None:
+    if geom.ant is not None and inp.dtype == torch.float32 and strides is not None:
         prof = PROFILE
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        nlaunch = _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx)
+        flops = _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx)
         if prof is not None:
             e1.record()
-            prof.append(('fringe_ant_bwd_kernel' if backward else 'fringe_ant_fwd_kernel', e0, e1, geom.elements,
-                         geom.ant['mfma_flops_bwd' if backward else 'mfma_flops_fwd'] * nlaunch))
+            prof.append(('fringe_ant_bwd_kernel' if backward else 'fringe_ant_fwd_kernel', e0, e1, geom.elements, flops))
         return
     code, rdt = _real_dtype(inp)
     fn = lib.rime_fringe_sum_bwd if backward else lib.rime_fringe_sum_fwd

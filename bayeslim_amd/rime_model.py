@@ -212,7 +212,8 @@ class RIME(utils.Module):
         like = self._ant_like.get(self.bl_group_id)
         geom = ops.FringeGeometry(self.sim_blvecs.to(dev), sdir, self.freqs, bl_mp=bl_mp,
                                   Nmp=len(pairs), npix=[c.numel() for c in cuts],
-                                  antpos=self.array.antvecs, bl_ants=bl_ants, ant_like=like)
+                                  antpos=self.array.antvecs, bl_ants=bl_ants, ant_like=like, mp_pairs=pairs,
+                                  group=getattr(self, 'mfma_group', None))
         if like is None:
             self._ant_like[self.bl_group_id] = geom
         # for the fused psky builder: int32 cut and its inverse per time step

@@ -134,22 +134,32 @@ int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* 
                         long long st_t, long long st_f, long long st_p, int sign, float* gpsky,
                         void* workspace, size_t workspace_bytes, void* stream);
 
-/* Arrays with more than 128 antennas: the antennas are cut into groups of <= 128 and the pair
- * matrix into blocks (I, J), I <= J.  rime_fringe_ant_fwd == one diagonal block + finish;
- * rime_fringe_ant_bwd == prepare + one diagonal block.
- *   diagonal block (cross = 0): antpos [Nrows <= 128, 3] of group I, tables as above (local indices)
- *   cross block    (cross = 1): antpos [256, 3] = group I then group J, each zero-padded to 128 rows;
- *       pair_direct[i*128 + j] = slot of baseline (I_i -> J_j), pair_conj[i*128 + j] = slot of
- *       baseline (J_j -> I_i), or -1
+/* Block decomposition of the pair matrix.  The antennas are cut into groups (<= 128 antennas: by
+ * position for arrays with more than 128 antennas, by beam model when antennas carry different beam
+ * models -- beam_model.py:303-327 pairs them per baseline --, by rank-local tile for baseline-tile
+ * sharding across GPUs) and the pair matrix into blocks; every block is one launch with its own psky
+ * plane.  rime_fringe_ant_fwd == one diagonal block + finish; rime_fringe_ant_bwd == prepare + one
+ * diagonal block.
+ *   diagonal block (cross = 0): antpos [Nrows <= 128, 3] of one group against itself, tables as above
+ *       (local indices)
+ *   cross block (cross = rows of group I): antpos [Nrows, 3] = group I (cross rows) then group J
+ *       (Nrows - cross rows), each zero-padded to a multiple of 32; supported (rows I, rows J): (32, 32),
+ *       (32, 64), (64, 64), (128, 128); pair_direct[i*128 + j] = slot of baseline (I_i -> J_j),
+ *       pair_conj[i*128 + j] = slot of baseline (J_j -> I_i), or -1
+ *   psky_complex: 0 = psky / gpsky is one real plane (st_p 1 or 2); +1 = interleaved complex (st_p == 2)
+ *       handled in ONE pass (forward: cross blocks only -- a diagonal block returns RIME_EUNSUPPORTED and
+ *       takes one call per real plane; the block must hold direct entries only); -1 = as +1 but the
+ *       block contracts conj(psky) (a block built with its groups swapped: conj entries only).  The
+ *       backward writes both gradient planes from one pass for either block kind.
  * Forward blocks fill disjoint baseline slots of the slab workspace (every baseline must belong
  * to exactly one block); _finish sums the pixel splits and writes vis [Nbl, Nt, Nf].  Backward:
- * _prepare transposes gvis into the workspace once, every block reads it; blocks after the first
- * pass accumulate = 1 (stream order makes the sum deterministic). */
+ * _prepare transposes gvis into the workspace once, every block reads it; blocks after the first that
+ * write the same gpsky plane pass accumulate = 1 (stream order makes the sum deterministic). */
 int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
                               const double* freqs, const float* psky, const float* scale,
                               const float* rowmin, const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf,
                               int Pstride, long long st_t, long long st_f, long long st_p, int sign,
-                              void* workspace, size_t workspace_bytes, void* stream);
+                              int psky_complex, void* workspace, size_t workspace_bytes, void* stream);
 int rime_fringe_ant_fwd_finish(const void* workspace, size_t workspace_bytes, float* vis,
                                int Nbl, int Nt, int Nf, int Pstride, void* stream);
 int rime_fringe_ant_bwd_prepare(const float* gvis, int Nbl, int Nt, int Nf,
@@ -158,7 +168,7 @@ int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cross, const 
                               const double* freqs, const float* gscale, const int* pair_direct,
                               const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
                               long long st_t, long long st_f, long long st_p, int sign,
-                              int accumulate, float* gpsky, const void* workspace,
+                              int psky_complex, int accumulate, float* gpsky, const void* workspace,
                               size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -260,36 +260,75 @@ def test_eq2top_basic_geometry():
     assert tel.hash(jd, torch.tensor([0.0])) in tel.conv_cache and angs.shape == (2, 1)   # tests/test_telescope.py:27-38
 
 
-def test_antenna_block_tables():
-    """pair tables of the matrix-core path: every baseline lands in exactly one slot of exactly one
-    (group I <= group J) block, with the orientation rules include/rime_hip.h documents"""
-    from bayeslim_amd import ops
-    rng = np.random.default_rng(0)
-    Nant = 300                                   # groups of 128, 128, 44
-    pairs = [(i, j) for i in range(Nant) for j in range(i, Nant) if rng.random() < 0.05]
-    pairs = [p if rng.random() < 0.5 else p[::-1] for p in pairs]
-    tabs = ops._antenna_blocks(pairs, Nant)
-    assert set(tabs) <= {(i, j) for i in range(3) for j in range(i, 3)}
+def _check_blocks(pairs, blocks, bl_mp=None, ant_model=None):
+    """every baseline lands in exactly one slot of exactly one block, with the orientation rules
+    include/rime_hip.h documents: V[row, col] = sum conj(E_row) E_col, direct = (row -> col)"""
     seen = np.zeros(len(pairs), dtype=int)
-    for (gi, gj), (direct, conj) in tabs.items():
-        for tab, is_conj in ((direct, False), (conj, True)):
+    for blk in blocks:
+        ai = blk['ants_i']
+        aj = blk['ants_j'] if blk['ants_j'] is not None else ai
+        nd = nc = 0
+        for tab, is_conj in ((blk['direct'], False), (blk['conj'], True)):
             ii, jj = np.nonzero(tab >= 0)
             for i, j in zip(ii, jj):
                 b = tab[i, j]
                 seen[b] += 1
                 a1, a2 = pairs[b]
-                row, col = gi * 128 + i, gj * 128 + j            # V[row, col] = sum conj(E_row) E_col
+                row, col = ai[i], aj[j]
                 assert (a1, a2) == ((col, row) if is_conj else (row, col))
-                if gi == gj:
+                if bl_mp is not None:
+                    assert bl_mp[b] == blk['mp']
+                if blk['ants_j'] is None:
                     assert i // 32 <= j // 32                     # upper-triangular tiles only
                     if is_conj:
                         assert i // 32 < j // 32
+                nd, nc = nd + (not is_conj), nc + is_conj
+        assert blk['cpass'] == (1 if nc == 0 else (-1 if nd == 0 else 0))
+        if blk['ants_j'] is not None:
+            assert (blk['rows_i'], blk['rows_j']) in ((32, 32), (32, 64), (64, 64), (128, 128))
+            assert len(ai) <= blk['rows_i'] and len(aj) <= blk['rows_j']
+        if ant_model is not None:
+            assert len({ant_model[a] for a in ai}) == 1 and len({ant_model[a] for a in aj}) == 1
     assert (seen == 1).all()
+
+
+def test_antenna_block_tables():
+    """pair tables of the matrix-core path: groups of <= 128 antennas, diagonal + cross blocks"""
+    from bayeslim_amd import ops
+    rng = np.random.default_rng(0)
+    Nant = 300                                   # groups of 128, 128, 44
+    pairs = [(i, j) for i in range(Nant) for j in range(i, Nant) if rng.random() < 0.05]
+    pairs = [p if rng.random() < 0.5 else p[::-1] for p in pairs]
+    blocks = ops._antenna_blocks(pairs, Nant)
+    assert len(blocks) == 6
+    _check_blocks(pairs, blocks)
     # a pair and its reverse are distinct slots; the same pair twice cannot be represented
     assert ops._antenna_blocks([(1, 2), (2, 1)], 4) is not None
     assert ops._antenna_blocks([(130, 2), (2, 130)], 140) is not None
     assert ops._antenna_blocks([(1, 2), (1, 2)], 4) is None
     assert ops._antenna_blocks([(2, 130), (2, 130)], 140) is None
+
+
+def test_antenna_blocks_per_beam_model_and_small_groups():
+    """several beam models: groups never mix models and every (group pair, model pair) is its own block
+    with its psky plane; groups of 32 (rank-local tile shards) give one-tile blocks"""
+    from bayeslim_amd import ops
+    rng = np.random.default_rng(1)
+    Nant = 90
+    ant_model = [int(a % 3 == 0) + 2 * int(a % 7 == 0 and a % 3 != 0) for a in range(Nant)]       # three models, unequal sizes
+    pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
+    pairs = [p if rng.random() < 0.8 else p[::-1] for p in pairs]
+    uniq = sorted({(ant_model[a], ant_model[b]) for a, b in pairs})
+    bl_mp = [uniq.index((ant_model[a], ant_model[b])) for a, b in pairs]
+    blocks = ops._antenna_blocks(pairs, Nant, bl_mp, ant_model)
+    _check_blocks(pairs, blocks, bl_mp, ant_model)
+    assert {blk['mp'] for blk in blocks} == set(range(len(uniq)))
+    # one model, groups of 32: 128 antennas -> 4 diagonal + 6 cross one-tile blocks
+    pairs = [(i, j) for i in range(128) for j in range(i + 1, 128)]
+    blocks = ops._antenna_blocks(pairs, 128, group=32)
+    _check_blocks(pairs, blocks)
+    assert sum(b['ants_j'] is None for b in blocks) == 4 and sum(b['ants_j'] is not None for b in blocks) == 6
+    assert all((b['rows_i'], b['rows_j']) == (32, 32) for b in blocks if b['ants_j'] is not None)
 
 
 def test_eq2top_device_matches_host():

@@ -278,6 +278,103 @@ def test_fringe_sum_matrix_core_antenna_groups(ops, Nant, frac, Npp):
     assert relmax(x.grad[..., :P], ref_in.grad) < 1e-4
 
 
+def _ant_setup(ops, Nant, Nt, Nf, P, frac, autos, seed=None, orient=None):
+    ant, pairs, blvecs, freqs, zenaz, _ = make_antenna_case(seed or Nant, Nant, Nt=Nt, Nf=Nf, P=P, frac=frac, autos=autos)
+    if orient is not None:                        # force one orientation: all i < j ('up') or all i > j ('down')
+        pairs = [(min(p), max(p)) if orient == 'up' else (max(p), min(p)) for p in pairs]
+        blvecs = torch.stack([ant[b] - ant[a] for a, b in pairs])
+    Ps = ops.pad_to_tile(P)
+    sdir = torch.zeros(Nt, 3, Ps, dtype=torch.float64)
+    for t in range(Nt):
+        sdir[t, :, :P] = orc.pointing_vectors(zenaz[t, 0], zenaz[t, 1])
+    return ant, pairs, blvecs, freqs, zenaz, sdir, Ps
+
+
+def _check_ant_path(ops, geom, psky, blvecs, zenaz, freqs, bl_mp, P, Ps, cplx, conj=False, tv=1e-5, tg=1e-4):
+    ref_in = psky.clone().requires_grad_(True)
+    ref = oracle_fringe_sum(ref_in, blvecs, zenaz, freqs, bl_mp, conj=conj)
+    gv = torch.as_tensor(np.random.default_rng(5).normal(size=tuple(ref.shape))
+                         + 1j * np.random.default_rng(6).normal(size=tuple(ref.shape)))
+    (ref * gv.conj()).real.sum().backward()
+    x = pad_psky(psky, Ps).to(torch.complex64 if cplx else torch.float32).cuda().requires_grad_(True)
+    prof = []
+    ops.PROFILE = prof
+    try:
+        vis = ops.fringe_sum(x, geom)
+        (vis * gv.to(torch.complex64).cuda().conj()).real.sum().backward()
+    finally:
+        ops.PROFILE = None
+    assert [k[0] for k in prof] == ['fringe_ant_fwd_kernel', 'fringe_ant_bwd_kernel']
+    assert relmax(vis, ref) < tv
+    assert relmax(x.grad[..., :P], ref_in.grad) < tg
+    return vis
+
+
+@pytest.mark.parametrize('Nant,group,frac', [(128, 32, 1.0), (100, 32, 0.7), (128, 64, 1.0), (90, 64, 0.8), (40, 32, 1.0)])
+def test_fringe_sum_matrix_core_small_groups(ops, Nant, group, frac):
+    """groups of 32 / 64 antennas (rank-local tile shards): one-tile diagonal blocks with the K-split
+    wave deal and the (32,32) / (32,64) / (64,64) cross shapes, both pair orientations, ragged last group"""
+    ant, pairs, blvecs, freqs, zenaz, sdir, Ps = _ant_setup(ops, Nant, 2, 5, 900, frac, 2)
+    rng = np.random.default_rng(4)
+    P = zenaz.shape[-1]
+    psky = torch.as_tensor(rng.normal(size=(2, 1, 1, 5, P)) * np.exp(-9.0 * rng.uniform(size=(2, 1, 1, 5, P))))
+    geom = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, antpos=ant.cuda(), bl_ants=pairs, mfma=True, group=group)
+    assert geom.ant is not None
+    ng = (Nant + group - 1) // group
+    assert len(geom.ant['blocks']) == ng * (ng + 1) // 2
+    shapes = {(b['cross'], b['nrows'] - b['cross']) for b in geom.ant['blocks'] if b['cross']}
+    assert shapes <= {(32, 32), (32, 64), (64, 64)} and shapes
+    vis = _check_ant_path(ops, geom, psky, blvecs, zenaz, freqs, [0] * len(pairs), P, Ps, False)
+    # identical to the 128-antenna grouping up to float32 summation order
+    geom0 = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, antpos=ant.cuda(), bl_ants=pairs, mfma=True)
+    v0 = ops.fringe_sum(pad_psky(psky, Ps).float().cuda(), geom0)
+    assert relmax(vis, v0) < 2e-6
+
+
+@pytest.mark.parametrize('Nant,nmodel,Npp,cplx', [(60, 2, 1, False), (90, 3, 1, False), (70, 2, 2, False), (64, 2, 1, True),
+                                                  (200, 2, 1, False)])
+def test_fringe_sum_matrix_core_beam_models(ops, Nant, nmodel, Npp, cplx):
+    """several beam models (beam_model.py:303-327): one block per (group pair, model pair), each on its own
+    psky plane -- forward and backward against the fp64 oracle, no vector-ALU fallback"""
+    ant, pairs, blvecs, freqs, zenaz, sdir, Ps = _ant_setup(ops, Nant, 2, 4, 600, 0.9, 2)
+    rng = np.random.default_rng(7)
+    P = zenaz.shape[-1]
+    ant_model = [int(rng.integers(0, nmodel)) if a % 5 else a % nmodel for a in range(Nant)]
+    uniq = sorted({(ant_model[a], ant_model[b]) for a, b in pairs})
+    bl_mp = [uniq.index((ant_model[a], ant_model[b])) for a, b in pairs]
+    shape = (2, len(uniq), Npp, 4, P)
+    psky = rng.normal(size=shape) * np.exp(-9.0 * rng.uniform(size=shape))
+    if cplx:
+        psky = psky + 1j * rng.normal(size=shape) * np.exp(-9.0 * rng.uniform(size=shape))
+    psky = torch.as_tensor(psky)
+    geom = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, bl_mp=bl_mp, Nmp=len(uniq), antpos=ant.cuda(),
+                              bl_ants=pairs, mfma=True, mp_pairs=uniq)
+    assert geom.ant is not None and geom.ant['multi_model']
+    assert {b['mp'] for b in geom.ant['blocks']} == set(range(len(uniq)))
+    _check_ant_path(ops, geom, psky, blvecs, zenaz, freqs, bl_mp, P, Ps, cplx)
+
+
+@pytest.mark.parametrize('Nant,orient,Npp', [(200, 'up', 1), (200, 'down', 2), (200, None, 1), (300, 'up', 4), (100, 'up', 1)])
+@pytest.mark.parametrize('conj', [False, True])
+def test_fringe_sum_matrix_core_complex_single_pass(ops, Nant, orient, Npp, conj):
+    """complex (Jones) psky: cross blocks with one pair orientation contract it in ONE pass (forward), every
+    one-orientation block writes both gradient planes from one backward pass; mixed blocks take two passes"""
+    ant, pairs, blvecs, freqs, zenaz, sdir, Ps = _ant_setup(ops, Nant, 2, 3, 500, 0.5, 0, orient=orient)
+    rng = np.random.default_rng(8)
+    P = zenaz.shape[-1]
+    shape = (2, 1, Npp, 3, P)
+    psky = torch.as_tensor(rng.normal(size=shape) * np.exp(-9.0 * rng.uniform(size=shape))
+                           + 1j * rng.normal(size=shape) * np.exp(-9.0 * rng.uniform(size=shape)))
+    geom = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, conj=conj, antpos=ant.cuda(), bl_ants=pairs, mfma=True)
+    assert geom.ant is not None
+    cp = [b['cpass'] for b in geom.ant['blocks']]
+    if orient == 'up':
+        assert all(c == 1 for c in cp)
+    elif orient == 'down':
+        assert all((c == -1) == bool(b['cross']) for c, b in zip(cp, geom.ant['blocks']))     # diagonal blocks: mixed tables
+    _check_ant_path(ops, geom, psky, blvecs, zenaz, freqs, [0] * len(pairs), P, Ps, True, conj=conj)
+
+
 def test_fringe_sum_full_size_properties(ops):
     """BASELINE config 4 at full size (128 antennas / 8128 baselines, 256 channels, 98 304 visible
     pixels): size-independent properties instead of an oracle -- linearity, the adjoint identity
