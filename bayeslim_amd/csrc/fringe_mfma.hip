@@ -154,7 +154,7 @@ struct FwdShape {
     // a single tile has two (re | im) units for four waves: the two K steps of a panel go to different
     // waves and the partial tiles are added in the epilogue
     static constexpr bool KSPLIT = NT == 1;
-    static constexpr int NW = NT >= 8 ? 8 : 4;                     // waves per block (2-wave blocks for <= 64
+    static constexpr int NW = (CROSS && NT >= 8) ? 8 : 4;                     // waves per block (2-wave blocks for <= 64
                                                                    // antennas: faster or slower with the grid size)
     static constexpr int ROWS = CROSS ? 32 * (TI + TJ) : 32 * TA;  // antenna rows of the LDS images (smaller
                                                                    // arrays: more blocks per CU, 5-7 % faster)
