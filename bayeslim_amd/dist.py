@@ -1,25 +1,32 @@
 """
-Multi-GPU execution of the RIME path: one process per GPU, baselines sharded across ranks,
+Multi-GPU execution of the RIME path: one process per GPU, visibilities sharded across ranks,
 `torch.distributed` collectives (backend 'nccl' == RCCL over xGMI on ROCm; 'gloo' in CPU tests).
 
 The reference has no collectives: its `DistributedLogProb` (optim.py:1391-1566) copies
 parameters to each device, runs the per-device closures one after another in a Python loop and
-sums gradients on device 0.  Here:
-  * visibilities are independent across baselines AND across channels.  Either axis can be
-    sharded in contiguous blocks (order preserved: the gathered tensor equals the single-GPU
-    layout) from replicated sky / beam parameters -- no data-path collective inside the kernels.
-    Baseline blocks suit the baseline-formulation kernels; CHANNEL blocks suit the antenna-factored
-    matrix-core kernels, whose cost does not depend on how many of the antenna pairs are requested
-    (and channel blocks also shard the per-channel sky / beam preparation and their gradients);
-  * forward: optional all-gather of the (Npol, Npol, Nbl/W, Nt, Nf) visibility blocks
-    (differentiable: its backward hands each rank the slice of the upstream gradient that
-    belongs to its baselines -- no communication);
-  * backward: one all-reduce (sum) of the parameter gradients, bucketed into a single flat
-    buffer per dtype so the ring runs over few, large messages.
+sums gradients on device 0 (optim.py:1539-1566).  Here:
+  * visibilities are independent across baselines AND across channels; sky / beam parameters are
+    replicated; no collective inside the kernels.  Partitions:
+      - contiguous baseline blocks (`shard_bounds`): right for the baseline-formulation kernels;
+      - baseline TILE shards (`plan_tile_shards`): the north-star's baseline partition for the
+        antenna-factored matrix-core kernels, whose cost is per 32 x 32 antenna-pair tile -- whole
+        blocks of the pair matrix (ops._antenna_blocks) are dealt to the ranks, so the MFMA work is
+        sharded; every rank regenerates the E operands of the antennas its tiles touch;
+      - contiguous channel blocks: shard MFMA work AND operand generation AND the per-channel
+        sky / beam preparation (the faster partition for those kernels);
+  * forward: all-gather of the visibility blocks, differentiable (its backward hands each rank the
+    slice of the upstream gradient that belongs to its block -- no communication), available as an
+    ASYNC pair (`all_gather_vis_start` / `.wait()`) so that the gather of one time chunk runs while
+    the kernels of the next chunk run (`pipelined_step`);
+  * backward: gradients of replicated parameters are summed in place, one collective per large
+    gradient (small ones share a flat bucket), started by `GradSync` from autograd's
+    post-accumulate hooks so that the exchange of a finished gradient overlaps the rest of the
+    backward; per-channel parameters under channel sharding exchange their disjoint blocks with an
+    in-place all-gather instead (half the bytes).
 """
-import numpy as np
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -47,70 +54,191 @@ def shard_baselines(bls, rank=None, world_size=None):
     return list(bls[s:e])
 
 
-class _AllGatherCat(torch.autograd.Function):
-    """all-gather of ragged per-rank blocks concatenated along `dim` (differentiable: the
-    backward hands every rank the slice of the upstream gradient that belongs to its block)"""
-    @staticmethod
-    def forward(ctx, x, counts, dim, group):
+# ---------------------------------------------------------------------------------------------
+# baseline-tile shards for the antenna-factored matrix-core kernels
+# ---------------------------------------------------------------------------------------------
+# cost model, in MFMA issue slots per 16 pixels (one v_mfma_f32_32x32x16_f16 = 1): forward + backward
+# matrix work of a block plus the operand generation of its antenna rows.  GEN_PER_ROW from the C4
+# profile (profiles/r01/pmc_v19.json): 128 rows cost 0.46 / 0.56 x the 100 forward MFMAs of the block.
+GEN_PER_ROW = 0.64
+
+
+def _block_cost(blk):
+    if blk['ants_j'] is None:
+        ta = (len(blk['ants_i']) + 31) // 32
+        mf = 7 * ta + 12 * (ta * (ta - 1) // 2) + 12 * (ta * (ta + 1) // 2)
+        rows = 32 * ta
+    else:
+        mf = 2 * 12 * (blk['rows_i'] // 32) * (blk['rows_j'] // 32)
+        rows = blk['rows_i'] + blk['rows_j']
+    return mf + 2 * GEN_PER_ROW * rows
+
+
+def plan_tile_shards(bl_ants, Nant, world_size, bl_mp=None, ant_model=None, groups=(128, 64, 32)):
+    """
+    Deal the blocks of the antenna pair matrix (ops._antenna_blocks: groups of <= g antennas,
+    diagonal + cross blocks, per beam-model pair) to `world_size` ranks, longest block first to the
+    least-loaded rank, for the group size g that gives the smallest maximum load.
+    bl_ants: antenna-INDEX pairs of all baselines.  Returns dict(group=g, rank_bls=[baseline indices
+    (ascending) per rank], load=[cost per rank], order=concatenation of rank_bls, inverse=its inverse
+    permutation (gathered[..., inverse] restores the original baseline order)), or None when the pair
+    set cannot be represented (a pair listed twice).
+    """
+    from . import ops
+    best = None
+    for g in groups:
+        blocks = ops._antenna_blocks(bl_ants, Nant, bl_mp, ant_model, group=g)
+        if blocks is None:
+            return None
+        cost = [_block_cost(b) for b in blocks]
+        load = [0.0] * world_size
+        owner = [[] for _ in range(world_size)]
+        ants = [set() for _ in range(world_size)]
+        for k in sorted(range(len(blocks)), key=lambda k: -cost[k]):
+            blk = blocks[k]
+            touched = set(blk['ants_i']) | set(blk['ants_j'] or ())
+            # least-loaded rank; ties go to the rank that already generates these antennas
+            r = min(range(world_size), key=lambda r: (round(load[r], 6), -len(ants[r] & touched), r))
+            load[r] += cost[k]
+            owner[r].append(k)
+            ants[r] |= touched
+        if best is None or max(load) < 0.98 * max(best['load']):
+            rank_bls = []
+            for r in range(world_size):
+                idx = [np.concatenate([blocks[k]['direct'][blocks[k]['direct'] >= 0],
+                                       blocks[k]['conj'][blocks[k]['conj'] >= 0]]) for k in owner[r]]
+                rank_bls.append(sorted(int(i) for i in np.concatenate(idx)) if idx else [])
+            best = dict(group=g, rank_bls=rank_bls, load=load, nblocks=[len(o) for o in owner])
+    order = np.asarray([i for bl in best['rank_bls'] for i in bl], dtype=np.int64)
+    assert len(order) == len(bl_ants) and len(set(order.tolist())) == len(order)
+    inverse = np.empty_like(order)
+    inverse[order] = np.arange(len(order))
+    best.update(order=order, inverse=inverse)
+    return best
+
+
+# ---------------------------------------------------------------------------------------------
+# differentiable all-gather of visibility blocks
+# ---------------------------------------------------------------------------------------------
+class _GatherHandle:
+    """an all-gather in flight: buffers + the backend's work object(s)"""
+    def __init__(self, x, counts, dim, group, async_op):
         world = len(counts)
-        rank = dist.get_rank(group)
+        self.counts, self.dim, self.group = tuple(counts), dim, group
+        self.rank = dist.get_rank(group)
+        self.shape_in = tuple(x.shape)
         nmax = max(counts)
-        ctx.counts, ctx.rank, ctx.dim = counts, rank, dim
-        if min(counts) == nmax and x.shape[dim] == nmax and not _SIMPLE:
+        self.complex = x.is_complex()
+        xd = x.detach()
+        self.equal = (min(counts) == nmax and x.shape[dim] == nmax and not _SIMPLE)
+        if self.equal:
             # equal blocks: one collective into a [world, ...] buffer, then a single re-layout (none at all
             # when every axis before `dim` has length 1, i.e. the baseline-sharded visibility tensor)
-            xin = x.contiguous()
-            buf = torch.view_as_real(xin) if xin.is_complex() else xin
-            out = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
-            dist.all_gather_into_tensor(out.view(-1), buf.reshape(-1), group=group)     # flat: backends differ on shapes
-            if xin.is_complex():
-                out = torch.view_as_complex(out)
-            shape = list(x.shape)
-            shape[dim] = world * nmax
-            return out.movedim(0, dim).reshape(shape)
-        pad = x
-        if x.shape[dim] < nmax:
-            padshape = list(x.shape)
-            padshape[dim] = nmax - x.shape[dim]
-            pad = torch.cat([x, x.new_zeros(padshape)], dim=dim)
-        pad = pad.contiguous()
-        if pad.is_complex():
-            buf = torch.view_as_real(pad)
-            parts = [torch.empty_like(buf) for _ in range(world)]
-            dist.all_gather(parts, buf, group=group)
-            parts = [torch.view_as_complex(p) for p in parts]
+            xin = xd.contiguous()
+            buf = torch.view_as_real(xin) if self.complex else xin
+            self.out = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
+            self.keep = buf
+            self.work = dist.all_gather_into_tensor(self.out.view(-1), buf.reshape(-1), group=group, async_op=async_op)
         else:
-            parts = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(parts, pad, group=group)
-        return torch.cat([p.narrow(dim, 0, c) for p, c in zip(parts, counts)], dim=dim)
+            pad = xd
+            if x.shape[dim] < nmax:
+                padshape = list(x.shape)
+                padshape[dim] = nmax - x.shape[dim]
+                pad = torch.cat([xd, xd.new_zeros(padshape)], dim=dim)
+            pad = pad.contiguous()
+            buf = torch.view_as_real(pad) if self.complex else pad
+            self.parts = [torch.empty_like(buf) for _ in range(world)]
+            self.keep = buf
+            self.work = dist.all_gather(self.parts, buf, group=group, async_op=async_op)
+
+    def result(self):
+        """wait for the collective (the current stream waits for the backend's) and lay the blocks out"""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.equal:
+            out = torch.view_as_complex(self.out) if self.complex else self.out
+            shape = list(self.shape_in)
+            shape[self.dim] = len(self.counts) * self.counts[0]
+            return out.movedim(0, self.dim).reshape(shape)
+        parts = [torch.view_as_complex(p) for p in self.parts] if self.complex else self.parts
+        return torch.cat([p.narrow(self.dim, 0, c) for p, c in zip(parts, self.counts)], dim=self.dim)
+
+
+class _GatherWait(torch.autograd.Function):
+    """autograd node of an all-gather: forward = wait + layout; backward = this rank's slice of the
+    upstream gradient (no communication)"""
+    @staticmethod
+    def forward(ctx, x, handle):
+        ctx.counts, ctx.rank, ctx.dim = handle.counts, handle.rank, handle.dim
+        return handle.result()
 
     @staticmethod
     def backward(ctx, g):
         s = sum(ctx.counts[:ctx.rank])
-        return g.narrow(ctx.dim, s, ctx.counts[ctx.rank]).contiguous(), None, None, None
+        return g.narrow(ctx.dim, s, ctx.counts[ctx.rank]).contiguous(), None
 
 
-def all_gather_vis(vis_local, counts=None, group=None, dim=2):
+class PendingGather:
+    def __init__(self, x, handle, inverse=None):
+        self.x, self.handle, self.inverse = x, handle, inverse
+
+    def wait(self):
+        """gathered tensor, connected to the autograd graph of the local block"""
+        full = _GatherWait.apply(self.x, self.handle)
+        if self.inverse is not None:
+            full = full.index_select(self.handle.dim, self.inverse)       # tile shards: back to the original order
+        return full
+
+
+def _counts(vis_local, counts, group, dim):
+    if counts is not None:
+        return tuple(int(c) for c in counts)
+    world = dist.get_world_size(group)
+    n = torch.tensor([vis_local.shape[dim]], device=vis_local.device)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    return tuple(int(x.item()) for x in ns)
+
+
+def all_gather_vis_start(vis_local, counts=None, group=None, dim=2, inverse=None):
+    """
+    Start the all-gather of per-rank visibility blocks (async on backends that support it: the
+    collective waits for the kernels already enqueued on the current stream, later kernels overlap
+    it).  `.wait()` returns the full tensor, rank blocks in rank order along `dim` (2 = baseline
+    shards, 4 = channel shards), re-ordered by `inverse` (int64 index tensor) when the shards are not
+    contiguous blocks of the original baseline order (tile shards).
+    """
+    counts = _counts(vis_local, counts, group, dim)
+    return PendingGather(vis_local, _GatherHandle(vis_local, counts, dim, group, async_op=True), inverse)
+
+
+def all_gather_vis(vis_local, counts=None, group=None, dim=2, inverse=None):
     """
     Gather per-rank visibility blocks into the full (Npol, Npol, Nbl, Nt, Nf) tensor on every
-    rank, rank blocks in rank order along `dim` (2 = baseline-sharded, 4 = frequency-sharded).
-    `counts`: block sizes per rank (default: exchanged with an all_gather of the local size).
+    rank (blocking form of all_gather_vis_start).  `counts`: block sizes per rank (default:
+    exchanged with an all_gather of the local size).
     """
-    world = dist.get_world_size(group)
-    if counts is None:
-        n = torch.tensor([vis_local.shape[dim]], device=vis_local.device)
-        ns = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(ns, n, group=group)
-        counts = [int(x.item()) for x in ns]
-    return _AllGatherCat.apply(vis_local, tuple(counts), dim, group)
+    counts = _counts(vis_local, counts, group, dim)
+    return PendingGather(vis_local, _GatherHandle(vis_local, counts, dim, group, async_op=False), inverse).wait()
 
 
-def all_gather_block_grads(param, dim, bounds, group=None):
+# ---------------------------------------------------------------------------------------------
+# gradient exchange
+# ---------------------------------------------------------------------------------------------
+def _block_gather_inplace_ok(g, dim, bounds):
+    nmax = max(b - a for a, b in bounds)
+    return (not _SIMPLE and min(b - a for a, b in bounds) == nmax and g.is_contiguous() and not g.is_complex()
+            and all(n == 1 for n in g.shape[:dim]) and bounds[0][0] == 0 and bounds[-1][1] == g.shape[dim])
+
+
+def all_gather_block_grads(param, dim, bounds, group=None, async_op=False):
     """
     Gradient exchange for a replicated parameter whose slices along `dim` are each used by exactly
-    one rank (frequency sharding of per-channel sky / beam parameters): the local .grad is non-zero
+    one rank (channel sharding of per-channel sky / beam parameters): the local .grad is non-zero
     only inside this rank's (start, stop) block, so an all-gather of the blocks rebuilds the full
-    gradient with half the bytes of an all-reduce.
+    gradient with half the bytes of an all-reduce.  Returns the work object when async_op (equal
+    blocks only; ragged blocks complete before returning).
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -119,13 +247,11 @@ def all_gather_block_grads(param, dim, bounds, group=None):
         param.grad = torch.zeros_like(param)
     nmax = max(b - a for a, b in bounds)
     g = param.grad
-    if (not _SIMPLE and min(b - a for a, b in bounds) == nmax and g.is_contiguous() and not g.is_complex()
-            and all(n == 1 for n in g.shape[:dim]) and bounds[0][0] == 0 and bounds[-1][1] == g.shape[dim]):
+    if _block_gather_inplace_ok(g, dim, bounds):
         # equal blocks that are contiguous runs of the gradient in rank order: in-place all-gather
         flat = g.view(-1)
         n = flat.numel() // world
-        dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n], group=group)
-        return
+        return dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n], group=group, async_op=async_op)
     blk = param.grad.narrow(dim, s, e - s)
     if e - s < nmax:
         padshape = list(blk.shape)
@@ -136,33 +262,119 @@ def all_gather_block_grads(param, dim, bounds, group=None):
     dist.all_gather(parts, blk, group=group)
     for (a, b), part in zip(bounds, parts):
         param.grad.narrow(dim, a, b - a).copy_(part.narrow(dim, 0, b - a))
+    return None
+
+
+BUCKET_BYTES = 1 << 20        # gradients smaller than this share one flat bucket per dtype; larger ones are reduced in place
+
+
+def _reduce_one(p, group, average, world, async_op):
+    """in-place all-reduce of one gradient (through a contiguous copy when .grad is not contiguous)"""
+    g = p.grad
+    if g.is_contiguous():
+        buf = torch.view_as_real(g) if g.is_complex() else g
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return work, ((lambda: buf.div_(world)) if average else None)
+    c = g.contiguous()
+    buf = torch.view_as_real(c) if c.is_complex() else c
+    work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+    def finish():
+        if average:
+            buf.div_(world)
+        g.copy_(c)                       # write back THROUGH the parameter's gradient, whatever its strides
+    return work, finish
 
 
 def all_reduce_grads(params, group=None, average=False):
     """
-    Sum .grad of the given parameters over ranks, in place.  Gradients are flattened into one
-    bucket per dtype (complex viewed as real), reduced with a single all_reduce each and
-    scattered back.  Parameters without a .grad on this rank contribute zeros.
+    Sum .grad of the given parameters over ranks, in place.  Large gradients are reduced where they
+    are (no staging copy); gradients below BUCKET_BYTES share one flat bucket per dtype so the ring
+    runs over few messages.  Non-contiguous gradients go through a contiguous copy and are written
+    back through `p.grad`.  Parameters without a .grad on this rank contribute zeros.
     """
     params = [p for p in params if p is not None]
-    by_dtype = {}
+    world = dist.get_world_size(group)
+    small = {}
     for p in params:
         if p.grad is None:
             p.grad = torch.zeros_like(p)
-        by_dtype.setdefault((p.grad.dtype, p.grad.device), []).append(p)
-    world = dist.get_world_size(group)
-    for (dt, dev), ps in by_dtype.items():
-        views = [torch.view_as_real(p.grad).reshape(-1) if p.grad.is_complex() else p.grad.reshape(-1)
-                 for p in ps]
-        flat = torch.cat(views)
+        if p.grad.numel() * p.grad.element_size() < BUCKET_BYTES:
+            small.setdefault((p.grad.dtype, p.grad.device), []).append(p)
+            continue
+        work, finish = _reduce_one(p, group, average, world, False)
+        if finish is not None:
+            finish()
+    for (dt, dev), ps in small.items():
+        real = [torch.view_as_real(p.grad.contiguous()) if p.grad.is_complex() else p.grad.contiguous() for p in ps]
+        flat = torch.cat([r.reshape(-1) for r in real])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:
             flat /= world
         o = 0
-        for p, v in zip(ps, views):
-            n = v.numel()
-            v.copy_(flat[o:o + n])
+        for p, r in zip(ps, real):
+            n = r.numel()
+            piece = flat[o:o + n].view(r.shape)
+            p.grad.copy_(torch.view_as_complex(piece) if p.grad.is_complex() else piece)
             o += n
+
+
+class GradSync:
+    """
+    Gradient exchange started from autograd: when `arm()`ed, the post-accumulate hook of every
+    registered parameter launches that parameter's collective asynchronously the moment its gradient
+    is final, so the exchange overlaps the rest of the backward pass; `finish()` waits for all of them.
+      shared parameters (used by every rank)            -> in-place all-reduce (sum)
+      block parameters  [(param, axis)] + `bounds`      -> in-place all-gather of the per-rank blocks
+    Un-armed backward passes (earlier time chunks of a pipelined step) only accumulate.
+    """
+    def __init__(self, shared=(), blocks=(), bounds=None, group=None):
+        self.group, self.bounds = group, bounds
+        self.shared = [p for p in shared if p is not None]
+        self.blocks = list(blocks)
+        self.armed = False
+        self.pending, self.done = [], set()
+        self.hooks = []
+        for p in self.shared:
+            self.hooks.append(p.register_post_accumulate_grad_hook(self._hook_shared))
+        for p, ax in self.blocks:
+            self.hooks.append(p.register_post_accumulate_grad_hook(lambda q, ax=ax: self._hook_block(q, ax)))
+
+    def _hook_shared(self, p):
+        if self.armed and id(p) not in self.done:
+            self.done.add(id(p))
+            self.pending.append(_reduce_one(p, self.group, False, 1, True))
+
+    def _hook_block(self, p, ax):
+        if self.armed and id(p) not in self.done:
+            self.done.add(id(p))
+            self.pending.append((all_gather_block_grads(p, ax, self.bounds, self.group, async_op=True), None))
+
+    def arm(self):
+        self.armed, self.pending, self.done = True, [], set()
+
+    def finish(self):
+        """wait for the collectives the hooks started; exchange whatever the backward never touched"""
+        self.armed = False
+        for p in self.shared:
+            if id(p) not in self.done:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                self.pending.append(_reduce_one(p, self.group, False, 1, True))
+        for p, ax in self.blocks:
+            if id(p) not in self.done:
+                self.pending.append((all_gather_block_grads(p, ax, self.bounds, self.group, async_op=True), None))
+        for work, fin in self.pending:
+            if work is not None:
+                work.wait()
+            if fin is not None:
+                fin()
+        self.pending, self.done = [], set()
+
+    def remove(self):
+        for h in self.hooks:
+            h.remove()
+        self.hooks = []
 
 
 def reduce_scalar(x, group=None):
@@ -172,27 +384,87 @@ def reduce_scalar(x, group=None):
     return y
 
 
+def pipelined_step(forward_chunk, nchunks, loss_fn, gather_start, grad_sync=None):
+    """
+    One forward + backward over `nchunks` time chunks with the collectives overlapped:
+        chunk k:  vis_k = forward_chunk(k)                 kernels enqueued
+                  gather_start(vis_k)                      async all-gather, behind those kernels
+                  loss + backward of chunk k-1             overlaps the gather of chunk k
+    and the gradient collectives of `grad_sync` (a GradSync) start inside the LAST chunk's backward.
+    loss_fn(full_vis_k, k) -> scalar.  Returns the summed loss (detached).  Gradients accumulate in
+    .grad over the chunks (the loss must be a sum over chunks, as chi^2 / sum |V|^2 are).
+    """
+    total = None
+
+    def finish(pending, k, last):
+        nonlocal total
+        full = pending.wait()
+        loss = loss_fn(full, k)
+        if last and grad_sync is not None:
+            grad_sync.arm()
+        loss.backward()
+        total = loss.detach() if total is None else total + loss.detach()
+
+    pending = None
+    for k in range(nchunks):
+        vis = forward_chunk(k)
+        nxt = gather_start(vis)
+        if pending is not None:
+            finish(pending, k - 1, False)
+        pending = nxt
+    finish(pending, nchunks - 1, True)
+    if grad_sync is not None:
+        grad_sync.finish()
+    return total
+
+
 class ShardedRIME:
     """
     Baseline-sharded driver around a RIME factory.  `make_rime(sim_bls)` must build a RIME for the
     given baseline list with this rank's replica of the sky / beam models.  forward() returns
     this rank's VisData block, or the gathered visibilities with gather=True.
+    tiles: deal whole blocks of the antenna pair matrix to the ranks (plan_tile_shards) instead of
+    contiguous baseline blocks -- shards the matrix-core work; `array` (ArrayModel) and optionally the
+    beam's `ant2beam` are needed to index the antennas.
     """
-    def __init__(self, make_rime, all_bls, group=None):
+    def __init__(self, make_rime, all_bls, group=None, tiles=False, array=None, ant2beam=None):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.all_bls = list(all_bls)
-        self.bounds = shard_bounds(len(self.all_bls), self.world)
-        self.counts = [e - s for s, e in self.bounds]
-        s, e = self.bounds[self.rank]
-        self.local_bls = self.all_bls[s:e]
+        self.inverse = None
+        self.plan = None
+        if tiles:
+            idx = array._ant_idx
+            bl_ants = [(idx[a], idx[b]) for a, b in self.all_bls]
+            ant_model = bl_mp = None
+            if ant2beam is not None and len(set(ant2beam.values())) > 1:
+                ant_model = [ant2beam[a] for a in array.ants]
+                uniq = sorted({(ant2beam[a], ant2beam[b]) for a, b in self.all_bls})
+                bl_mp = [uniq.index((ant2beam[a], ant2beam[b])) for a, b in self.all_bls]
+            self.plan = plan_tile_shards(bl_ants, len(array.ants), self.world, bl_mp, ant_model)
+        if self.plan is not None:
+            self.counts = [len(b) for b in self.plan['rank_bls']]
+            self.local_bls = [self.all_bls[i] for i in self.plan['rank_bls'][self.rank]]
+            self.inverse = torch.as_tensor(self.plan['inverse'])
+        else:
+            self.bounds = shard_bounds(len(self.all_bls), self.world)
+            self.counts = [e - s for s, e in self.bounds]
+            s, e = self.bounds[self.rank]
+            self.local_bls = self.all_bls[s:e]
         self.rime = make_rime(self.local_bls)
+        if self.plan is not None:
+            self.rime.mfma_group = self.plan['group']        # the geometry's blocks = the plan's blocks
+            self.rime.mfma_mode = True
+
+    def gather_start(self, vis):
+        inv = None if self.inverse is None else self.inverse.to(vis.device)
+        return all_gather_vis_start(vis, self.counts, self.group, dim=2, inverse=inv)
 
     def forward(self, gather=False, **kw):
         vd = self.rime(**kw)
         if gather:
-            vd.data = all_gather_vis(vd.data, self.counts, self.group, dim=2)
+            vd.data = self.gather_start(vd.data).wait()
             vd._set_bls(self.all_bls)
         return vd
 

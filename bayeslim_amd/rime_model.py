@@ -213,7 +213,7 @@ class RIME(utils.Module):
         geom = ops.FringeGeometry(self.sim_blvecs.to(dev), sdir, self.freqs, bl_mp=bl_mp,
                                   Nmp=len(pairs), npix=[c.numel() for c in cuts],
                                   antpos=self.array.antvecs, bl_ants=bl_ants, ant_like=like, mp_pairs=pairs,
-                                  group=getattr(self, 'mfma_group', None))
+                                  group=getattr(self, 'mfma_group', None), mfma=getattr(self, 'mfma_mode', 'auto'))
         if like is None:
             self._ant_like[self.bl_group_id] = geom
         # for the fused psky builder: int32 cut and its inverse per time step

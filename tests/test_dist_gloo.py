@@ -144,6 +144,140 @@ def test_frequency_sharded_forward_backward_equals_single_process(even):
         assert np.abs(gb - beam.grad.numpy()).max() < 1e-9 * np.abs(beam.grad.numpy()).max()
 
 
+def _worker_pipeline(rank, world, port, q, tiles):
+    """pipelined step: async gathers of time chunks + GradSync hooks, contiguous or tile shards"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ant, pairs, freqs, zen, az, sky, beam = _ant_problem()
+        sky = sky.clone().requires_grad_(True)
+        beam = beam.clone().requires_grad_(True)
+        blvecs = torch.stack([ant[b] - ant[a] for a, b in pairs])
+        if tiles:
+            plan = rdist.plan_tile_shards(pairs, len(ant), world)
+            mine = plan['rank_bls'][rank]
+            counts = [len(b) for b in plan['rank_bls']]
+            inverse = torch.as_tensor(plan['inverse'])
+        else:
+            s, e = rdist.shard_bounds(len(pairs), world)[rank]
+            mine, counts, inverse = list(range(s, e)), None, None
+        Nt = zen.shape[0]
+        w = torch.as_tensor(np.random.default_rng(9).normal(size=(1, 1, len(pairs), Nt, len(freqs))))
+        sync = rdist.GradSync(shared=[sky, beam])
+
+        def forward_chunk(k):
+            return _simulate(blvecs[mine], freqs, zen[k:k + 1], az[k:k + 1], sky, beam)
+
+        def gather_start(v):
+            return rdist.all_gather_vis_start(v, counts, dim=2, inverse=inverse)
+
+        def loss_fn(full, k):
+            return (w[:, :, :, k:k + 1] * (full.real ** 2 + full.imag ** 2)).sum()
+
+        tot = rdist.pipelined_step(forward_chunk, Nt, loss_fn, gather_start, sync)
+        sync.remove()
+        q.put((rank, float(tot), sky.grad.numpy(), beam.grad.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _ant_problem():
+    rng = np.random.default_rng(3)
+    Nant, Nf, P, Nt = 70, 3, 30, 3
+    T = lambda x: torch.as_tensor(x, dtype=torch.float64)
+    ant = T(rng.normal(0, 40, (Nant, 3)))
+    pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
+    freqs = T(np.linspace(120e6, 180e6, Nf))
+    zen = T(np.rad2deg(np.arccos(rng.uniform(0, 1, (Nt, P)))))
+    az = T(rng.uniform(0, 360, (Nt, P)))
+    sky = T(rng.normal(size=(1, 1, Nf, P)))
+    beam = T(np.abs(rng.normal(size=(1, 1, 1, Nf, P))))
+    return ant, pairs, freqs, zen, az, sky, beam
+
+
+@pytest.mark.parametrize('tiles', [False, True])
+def test_pipelined_step_overlapped_collectives_equal_single_process(tiles):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipeline, args=(r, world, port, q, tiles)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ant, pairs, freqs, zen, az, sky, beam = _ant_problem()
+    sky = sky.clone().requires_grad_(True)
+    beam = beam.clone().requires_grad_(True)
+    blvecs = torch.stack([ant[b] - ant[a] for a, b in pairs])
+    full = _simulate(blvecs, freqs, zen, az, sky, beam)
+    w = torch.as_tensor(np.random.default_rng(9).normal(size=tuple(full.shape)))
+    loss = (w * (full.real ** 2 + full.imag ** 2)).sum()
+    loss.backward()
+    for rank, tot, gs, gb in res:
+        assert abs(tot - float(loss.detach())) < 1e-9 * abs(float(loss.detach()))
+        assert np.abs(gs - sky.grad.numpy()).max() < 1e-9 * np.abs(sky.grad.numpy()).max()
+        assert np.abs(gb - beam.grad.numpy()).max() < 1e-9 * np.abs(beam.grad.numpy()).max()
+
+
+def _worker_noncontig(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        big = torch.zeros(600, 700, dtype=torch.float64, requires_grad=True)        # > BUCKET_BYTES: reduced in place
+        small = torch.zeros(5, 7, dtype=torch.complex128, requires_grad=True)        # shares the flat bucket
+        gb = torch.arange(600 * 700, dtype=torch.float64).reshape(700, 600).t() * (rank + 1)     # transposed strides
+        gs = (torch.arange(35, dtype=torch.float64).reshape(7, 5).t() * (1 + 2j)) * (rank + 1)
+        big.grad, small.grad = gb, gs
+        assert not big.grad.is_contiguous() and not small.grad.is_contiguous()
+        rdist.all_reduce_grads([big, small])
+        q.put((rank, big.grad.numpy().copy(), small.grad.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_reduce_grads_writes_back_through_noncontiguous_grads():
+    """a transposed .grad (custom backwards return such views) must receive the reduced values"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_noncontig, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    eb = np.arange(600 * 700, dtype=np.float64).reshape(700, 600).T * 3
+    es = np.arange(35, dtype=np.float64).reshape(7, 5).T * (1 + 2j) * 3
+    for rank, b, s_ in res:
+        assert np.array_equal(b, eb) and np.array_equal(s_, es)
+
+
+def test_tile_shard_plan():
+    """whole blocks of the antenna pair matrix per rank: a partition of the baselines, balanced cost,
+    and the inverse permutation restores the original order"""
+    for Nant, world in [(128, 8), (128, 4), (128, 2), (512, 8), (70, 4), (37, 2)]:
+        pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
+        plan = rdist.plan_tile_shards(pairs, Nant, world)
+        allb = sorted(i for bl in plan['rank_bls'] for i in bl)
+        assert allb == list(range(len(pairs)))
+        cat = np.concatenate([np.asarray(b, dtype=np.int64) for b in plan['rank_bls']])
+        assert np.array_equal(cat[plan['inverse']], np.arange(len(pairs)))
+        load = np.asarray(plan['load'])
+        assert load.min() > 0
+        if Nant >= 128:
+            assert load.max() / load.mean() < 1.25, (Nant, world, load)
+    # 128 antennas over 8 ranks: one-tile blocks (groups of 32), six cross tiles + two ranks with two diagonal tiles
+    plan = rdist.plan_tile_shards([(i, j) for i in range(128) for j in range(i + 1, 128)], 128, 8)
+    assert plan['group'] == 32 and sorted(plan['nblocks']) == [1] * 6 + [2] * 2
+    assert sorted(len(b) for b in plan['rank_bls']) == [992] * 2 + [1024] * 6
+    assert rdist.plan_tile_shards([(0, 1), (0, 1)], 4, 2) is None
+
+
 def test_shard_bounds():
     assert rdist.shard_bounds(8128, 8) == [(i * 1016, (i + 1) * 1016) for i in range(8)]
     b = rdist.shard_bounds(171, 4)
