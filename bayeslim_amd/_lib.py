@@ -40,6 +40,7 @@ SIGNATURES = {
     'rime_fringe_ant_bwd_block': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
                                        _i, _i, _vp, _vp, _sz, _vp]),
     'rime_gen_fringe': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rime_eq2top': (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _vp, _vp]),
     'rime_interp_gather_fwd': (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'rime_interp_scatter_bwd': (_i, [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'rime_beam_sky_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -499,6 +499,25 @@ def gen_fringe(blvecs, sdir, freqs, conj=False, dtype=torch.float32):
     return out
 
 
+def eq2top(ra, dec, M, vbary, vdiurnal):
+    """
+    ICRS (ra, dec) [deg, float64 on the GPU] -> (2, N) float64 tensor (zen, az) [deg]: annual
+    aberration, rotation by the host-built matrix M (3, 3) (ICRS -> East, North, Up), diurnal
+    aberration (astrometry.observation_frame gives M, vbary, vdiurnal per observation time).
+    """
+    _require_cuda(ra, dec)
+    r = ra.detach().to(torch.float64).contiguous()
+    d = dec.detach().to(torch.float64).contiguous()
+    assert r.dim() == 1 and r.shape == d.shape
+    out = torch.empty((2, r.numel()), dtype=torch.float64, device=r.device)
+    Mh = (ctypes.c_double * 9)(*[float(x) for x in np.asarray(M, dtype=np.float64).reshape(-1)])
+    vh = (ctypes.c_double * 3)(*[float(x) for x in np.asarray(vbary, dtype=np.float64).reshape(-1)])
+    rc = lib.rime_eq2top(_ptr(r), _ptr(d), r.numel(), ctypes.cast(Mh, ctypes.c_void_p), ctypes.cast(vh, ctypes.c_void_p),
+                         float(vdiurnal), _ptr(out[0]), _ptr(out[1]), _stream())
+    check(rc, 'rime_eq2top')
+    return out
+
+
 # ---------------------------------------------------------------------------------------
 class InterpStencil:
     """(inds, wgts) of PixInterp plus the CSR inverse index the deterministic adjoint uses."""

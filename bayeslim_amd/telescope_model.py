@@ -5,9 +5,16 @@ baseline vectors, redundancy bookkeeping, `gen_fringe`, :142-460).
 
 Differences that matter:
   * eq2top: the reference calls astropy's ICRS->AltAz on a cache miss (:498-502).  astropy is
-    not available here, so a miss is served by a plain LST rotation --
-    PARITY UNPINNED for that branch.  Pre-populating `conv_cache` with (zen, az) from any
-    source gives the reference's behaviour exactly (the cache-hit path is identical).
+    not available here; a miss is served by the built-in chain of `bayeslim_amd/astrometry.py`
+    (IAU 2006 precession + frame bias, truncated IAU 1980 nutation, GAST, annual + diurnal
+    aberration; float64; per-direction work in the HIP kernel `rime_eq2top` for sky angles on the
+    GPU) and announced ONCE with a warning that names what is not modelled (polar motion, UT1-UTC
+    unless `TelescopeModel.dut1` is set, light deflection).  Pinned to SOFA known answers, PARITY
+    UNPINNED against astropy itself.  Pre-populating `conv_cache` with (zen, az) from any source
+    gives the reference's behaviour exactly (the cache-hit path is identical).
+  * the module-level `eq2top` / `eq2top_device` / `JD2LST` are the PLAIN hour-angle rotation
+    (SURVEY.md App. B.1): generators of synthetic (zen, az) inputs for benchmarks and tests, where
+    the same arrays feed the CPU baseline and the GPU path.  The models never call them.
   * gen_fringe: the (Nbl, Nf, P) fringe tensor is produced by a HIP kernel, in float64 phase
     arithmetic; RIME itself never calls it (the fringe is fused into the sum).
 """
@@ -18,8 +25,13 @@ import math
 import numpy as np
 import torch
 
-from . import utils, ops
+import warnings
+
+from . import utils, ops, astrometry
 from .utils import _float, _cfloat, D2R
+
+
+_WARNED = False
 
 
 class TelescopeModel:
@@ -41,18 +53,26 @@ class TelescopeModel:
             del self.conv_cache[key]
 
     def eq2top(self, time, ra, dec, store=False, key=None):
-        """(zen, az) [deg] stacked as a (2, N) tensor; cached under `key` (:89-131)"""
+        """(zen, az) [deg] stacked as a (2, N) tensor; cached under `key` (:89-131).  A cache miss runs
+        the astrometry chain (see the module header) instead of astropy and says so once."""
         key = key if key is not None else self.hash(time, ra)
         if key in self.conv_cache:
             return self.conv_cache[key]
+        global _WARNED
+        if not _WARNED:
+            _WARNED = True
+            warnings.warn("TelescopeModel.eq2top: (zen, az) not in conv_cache; computed by bayeslim_amd.astrometry "
+                          "(IAU 2006 precession, truncated IAU 1980 nutation, annual + diurnal aberration) instead of "
+                          "astropy's ICRS->AltAz. Not modelled: polar motion, UT1-UTC (set TelescopeModel.dut1 [s]), "
+                          "light deflection; expected agreement a few 0.1 arcsec.", stacklevel=2)
+        M, vb, vd = astrometry.observation_frame(self.location, float(time), getattr(self, 'dut1', 0.0))
         if isinstance(ra, torch.Tensor) and ra.is_cuda:
-            # on-device rotation (float64 torch ops): 28 ms per time step on the host for an nside-128
-            # sky would bound a single pass over many time steps
-            angs = eq2top_device(self.location, time, ra, torch.as_tensor(dec, device=ra.device))
+            angs = ops.eq2top(ra, torch.as_tensor(dec, device=ra.device), M, vb, vd)
             if self.device is not None:
                 angs = angs.to(self.device)
         else:
-            zen, az = eq2top(self.location, time, utils.tensor2numpy(ra), utils.tensor2numpy(dec))
+            zen, az = astrometry.icrs_to_topo(self.location, float(time), utils.tensor2numpy(ra), utils.tensor2numpy(dec),
+                                              getattr(self, 'dut1', 0.0))
             angs = torch.as_tensor(np.stack([zen, az]), device=self.device, dtype=self.dtype)
         if store:
             self.conv_cache[key] = angs
@@ -76,8 +96,9 @@ def JD2LST(jd, longitude):
 def eq2top(location, time, ra, dec):
     """
     Equatorial (ra, dec) [deg] -> topocentric (zen, az) [deg], az East of North, by a pure
-    hour-angle rotation at the telescope latitude.  Ignores precession / nutation / aberration
-    / refraction, which astropy's ICRS->AltAz (telescope_model.py:469-502) includes.
+    hour-angle rotation at the telescope latitude: a generator of SYNTHETIC inputs (benchmarks,
+    tests).  Ignores precession / nutation / aberration, which astropy's ICRS->AltAz
+    (telescope_model.py:469-502) and TelescopeModel.eq2top include.
     """
     lon, lat = location[0], location[1]
     H = np.deg2rad(JD2LST(time, lon) - np.asarray(ra, dtype=np.float64))

@@ -172,6 +172,20 @@ int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cross, const 
                               size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * ICRS (ra, dec) -> topocentric (zenith angle, azimuth East of North), degrees, float64.
+ * Replaces the per-direction part of telescope_model.eq2top (telescope_model.py:469-502,
+ * astropy ICRS -> AltAz): annual aberration, rotation by the caller's 3 x 3 matrix
+ * M = L(lat) R3(GAST + lon) N P B (ICRS -> East, North, Up; bayeslim_amd/astrometry.py builds it
+ * per observation time: IAU 2006 precession + frame bias, truncated IAU 1980 nutation, GAST),
+ * diurnal aberration, conversion to angles.
+ *   ra_deg, dec_deg, zen_deg, az_deg: device f64 [N];  M_host f64 [9] row-major and
+ *   vbary_host f64 [3] (observer velocity / c, ICRS axes) are HOST pointers; vdiurnal = eastward
+ *   site velocity / c
+ * ------------------------------------------------------------------------------------- */
+int rime_eq2top(const double* ra_deg, const double* dec_deg, int N, const double* M_host,
+                const double* vbary_host, double vdiurnal, double* zen_deg, double* az_deg, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Materialised fringe, for callers that want the tensor itself (imaging.VisMapper.build_A,
  * tests):  out[b, f, p] = exp(sign * 2 pi i * freqs[f]/c * blvecs[b] . sdir[:, p])
  * Replaces ArrayModel.gen_fringe (telescope_model.py:350-356).  RIME never calls it.

@@ -292,6 +292,80 @@ def _check_blocks(pairs, blocks, bl_mp=None, ant_model=None):
     assert (seen == 1).all()
 
 
+def test_astrometry_against_sofa_known_answers():
+    """the eq2top chain (bayeslim_amd/astrometry.py, replacing astropy's ICRS->AltAz of
+    telescope_model.py:469-502) against SOFA's published known answers, component by component"""
+    import json
+    import os
+    from bayeslim_amd import astrometry as A
+    g = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'sofa_vectors.json')))
+    jd = lambda mjd: 2400000.5 + mjd
+    cen = lambda mjd: (jd(mjd) - 2451545.0) / 36525.0        # SOFA's test calls pass the same date as UT1 and TT
+    assert abs(A.era(jd(g['era00']['mjd'])) - g['era00']['value']) < g['era00']['tol']
+    assert abs(A.gmst(jd(g['gmst06']['mjd']), cen(g['gmst06']['mjd'])) - g['gmst06']['value']) < g['gmst06']['tol']
+    assert abs(A.mean_obliquity(cen(g['obl06']['mjd'])) - g['obl06']['value']) < g['obl06']['tol']
+    for k in ('nut80', 'nut00b'):                              # 31-term truncation: a few mas from either full series
+        dpsi, deps = A.nutation(cen(g[k]['mjd']))
+        assert abs(dpsi - g[k]['dpsi']) < g[k]['tol'] and abs(deps - g[k]['deps']) < g[k]['tol'], k
+    T = cen(g['gst06a']['mjd'])
+    dpsi, deps = A.nutation(T)
+    assert abs(A.gast(jd(g['gst06a']['mjd']), T, dpsi, A.mean_obliquity(T)) - g['gst06a']['value']) < g['gst06a']['tol']
+    assert np.abs(A.frame_bias() - np.array(g['bp00_rb']['value'])).max() < g['bp00_rb']['tol']
+    rbp = A.precession_matrix(cen(g['pmat06']['mjd'])) @ A.frame_bias()
+    assert np.abs(rbp - np.array(g['pmat06']['value'])).max() < g['pmat06']['tol']
+    T = cen(g['epv00']['mjd'])
+    v = (A.precession_matrix(T) @ A.frame_bias()).T @ A.earth_velocity(T) * A.C_AUDAY
+    vb = np.array(g['epv00']['vel_bary_au_per_day'])
+    assert np.linalg.norm(v - vb) / np.linalg.norm(vb) < g['epv00']['rel_tol']
+    # leap seconds / TT
+    assert A.tai_minus_utc(2459861.0) == 37.0 and A.tai_minus_utc(2451545.0) == 32.0 and A.tai_minus_utc(2441317.5) == 10.0
+    assert abs(A.tt_centuries(2451545.0 - (32.0 + 32.184) / 86400.0)) < 1e-15
+
+
+def test_eq2top_cache_miss_runs_the_astrometry_chain_and_says_so():
+    """a conv_cache miss is no longer a bare LST rotation: precession since J2000 (~0.3 deg in 2022), nutation and
+    aberration are applied, the first miss warns, and the chain is self-consistent (a source at the apparent
+    zenith place comes out at the zenith; rigid rotation + sub-arcminute aberration of separations)"""
+    import warnings
+    from bayeslim_amd import telescope_model, astrometry as A
+    telescope_model._WARNED = False
+    loc = (21.42827, -30.72148)
+    tel = telescope_model.TelescopeModel(loc)
+    jdv = 2459861.3
+    rng = np.random.default_rng(0)
+    ra, dec = rng.uniform(0, 360, 400), np.rad2deg(np.arcsin(rng.uniform(-1, 1, 400)))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        za = tel.eq2top(jdv, torch.as_tensor(ra), torch.as_tensor(dec), store=True)
+        tel.eq2top(jdv + 0.01, torch.as_tensor(ra), torch.as_tensor(dec))
+    assert len([x for x in w if 'astrometry' in str(x.message)]) == 1
+    assert tel.hash(jdv, torch.as_tensor(ra)) in tel.conv_cache and za.shape == (2, 400)
+    zen, az = za[0].numpy(), za[1].numpy()
+    z0, a0 = telescope_model.eq2top(loc, jdv, ra, dec)                   # plain rotation
+    s = lambda z, a: np.stack([np.sin(np.deg2rad(z)) * np.sin(np.deg2rad(a)), np.sin(np.deg2rad(z)) * np.cos(np.deg2rad(a)),
+                               np.cos(np.deg2rad(z))])
+    sep = np.rad2deg(np.arccos(np.clip((s(zen, az) * s(z0, a0)).sum(0), -1, 1)))
+    assert 0.15 < np.median(sep) < 0.45 and sep.max() < 0.5              # precession over 22.8 years + nutation + aberration
+    # pairwise separations are preserved up to differential aberration (< 41 arcsec)
+    p = np.stack([np.cos(np.deg2rad(dec)) * np.cos(np.deg2rad(ra)), np.cos(np.deg2rad(dec)) * np.sin(np.deg2rad(ra)),
+                  np.sin(np.deg2rad(dec))])
+    d_in = np.arccos(np.clip(p[:, :200].T @ p[:, 200:], -1, 1))
+    d_out = np.arccos(np.clip(s(zen, az)[:, :200].T @ s(zen, az)[:, 200:], -1, 1))
+    assert np.abs(d_in - d_out).max() < 2.1e-4
+    # the direction whose TRUE place is (GAST + lon, lat) is the zenith: build its ICRS place by inverting N P B
+    M, vb, vd = A.observation_frame(loc, jdv)
+    T = A.tt_centuries(jdv)
+    dpsi, deps = A.nutation(T)
+    eps0 = A.mean_obliquity(T)
+    NPB = A.nutation_matrix(eps0, dpsi, deps) @ A.precession_matrix(T) @ A.frame_bias()
+    lst = A.gast(jdv, T, dpsi, eps0) + np.deg2rad(loc[0])
+    ptrue = np.array([np.cos(np.deg2rad(loc[1])) * np.cos(lst), np.cos(np.deg2rad(loc[1])) * np.sin(lst), np.sin(np.deg2rad(loc[1]))])
+    picrs = NPB.T @ ptrue
+    assert np.allclose(M @ picrs, [0, 0, 1], atol=1e-14)
+    zz, _ = A.icrs_to_topo(loc, jdv, np.rad2deg(np.arctan2(picrs[1], picrs[0])), np.rad2deg(np.arcsin(picrs[2])))
+    assert float(np.max(zz)) < 21.0 / 3600.0                                             # only aberration moves it: <= 20.5 + 0.3 arcsec
+
+
 def test_antenna_block_tables():
     """pair tables of the matrix-core path: groups of <= 128 antennas, diagonal + cross blocks"""
     from bayeslim_amd import ops
