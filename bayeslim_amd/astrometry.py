@@ -211,7 +211,7 @@ def observation_frame(location, jd_utc, dut1=0.0):
 def icrs_to_topo(location, jd_utc, ra, dec, dut1=0.0):
     """numpy float64 restatement of the device path: (zen, az) [deg], az East of North"""
     M, vb, vd = observation_frame(location, jd_utc, dut1)
-    a, d = np.deg2rad(np.asarray(ra, dtype=np.float64)), np.deg2rad(np.asarray(dec, dtype=np.float64))
+    a, d = np.deg2rad(np.atleast_1d(np.asarray(ra, dtype=np.float64))), np.deg2rad(np.atleast_1d(np.asarray(dec, dtype=np.float64)))
     p = np.stack([np.cos(d) * np.cos(a), np.cos(d) * np.sin(a), np.sin(d)])
     p = aberrate(p, vb)
     s = M @ p
