@@ -366,6 +366,32 @@ def test_eq2top_cache_miss_runs_the_astrometry_chain_and_says_so():
     assert float(np.max(zz)) < 21.0 / 3600.0                                             # only aberration moves it: <= 20.5 + 0.3 arcsec
 
 
+def _healpix_vectors():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'healpix_vectors.json')))
+
+
+def test_healpix_pinned_to_docstring_and_hand_derived_vectors():
+    """RING pix2ang and get_interp_weights (utils.py:765-769 calls healpy's) against healpy's documented
+    examples and hand-derived values: pixel centres, phi wrap, ring boundaries, shifted rings, polar caps"""
+    from bayeslim_amd import healpix
+    g = _healpix_vectors()
+    for c in g['pix2ang']:
+        ip = c.get('pix', list(range(12 * c['nside'] ** 2)))
+        th, ph = healpix.pix2ang(c['nside'], ip)
+        assert np.abs(np.cos(th) - np.array(c['z'])).max() < 1e-15 and np.abs(ph - np.array(c['phi'])).max() < 1e-15
+    for c in g['interp']:
+        pix, w = healpix.get_interp_weights(c['nside'], c['theta'], c['phi'])
+        assert pix.shape == (4, 1) and abs(w.sum() - 1) < 1e-15
+        dense = np.zeros(12 * c['nside'] ** 2)
+        np.add.at(dense, pix[:, 0], w[:, 0])
+        want = np.zeros_like(dense)
+        for k, v in c['weights'].items():
+            want[int(k)] = v
+        assert np.abs(dense - want).max() < 1e-14, c['tag']
+
+
 def test_antenna_block_tables():
     """pair tables of the matrix-core path: groups of <= 128 antennas, diagonal + cross blocks"""
     from bayeslim_amd import ops
