@@ -137,6 +137,9 @@ __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_
 #ifndef RIME_MF_KP
 #define RIME_MF_KP 32
 #endif
+#ifndef RIME_V2_VALU
+#define RIME_V2_VALU 6
+#endif
 constexpr int MF_KP = RIME_MF_KP;               // pixels per panel (one barrier per panel); 16 per MFMA
 constexpr int MF_NH = MF_KP / 16;               // 16-pixel K steps per panel
 constexpr int MF_ROWB = 4 * MF_KP + 16;         // [re KP x f16][im KP x f16][pad]: odd number of 16-B granules
@@ -586,6 +589,339 @@ fringe_ant_fwd_cross_kernel(AntArgs A)
 }
 
 
+#if defined(RIME_BUILD_FWD_V2)
+// ---------------------------------------------------------------------------------------
+// forward kernel, second form (97..128 antennas, one diagonal block): generation hidden under the MFMAs
+// -- A MEASURED DEAD END, compiled only with -DRIME_BUILD_FWD_V2 (tools/fringe_mfma_lab.hip): at the C4 lab
+// shape 10.0 ms (non-negative sky) / 10.6 ms (signed) against 9.7 / 9.8 ms of the first form
+// (profiles/r02/lab_fwd_v2.txt).  Why: generation is ~33 issue cycles of VALU per MFMA at 128 antennas (f64
+// phase FMAs, fract, convert and sin / cos take 8 issue cycles each), an MFMA leaves 24 of its 32 cycles to
+// the wave's other instructions, so the issue port (8 + 33 per MFMA), not the matrix pipe, paces either
+// form; the first form's two co-resident 4-wave blocks de-phase by themselves and lose nothing to it.
+//
+// In the kernel above a wave alternates a generation phase (VALU only) with a contraction phase (MFMA +
+// LDS reads only); VALU and MFMA instructions of DIFFERENT waves do not overlap on a SIMD, so the kernel
+// costs (MFMA issue) + (VALU issue): 1600 + ~1400 cycles per 32-pixel panel and SIMD at 128 antennas.
+// Inside ONE wave, however, an MFMA holds the issue port for 8 of its 32 cycles: ~5-6 plain VALU
+// instructions issued behind it are (nearly) free.  This form makes every wave's instruction stream
+// "MFMA, a few VALU of the NEXT panel's generation, MFMA, ...":
+//   * 8 waves per block, one block per CU, TILE-PER-WAVE deal: waves 0-5 own one off-diagonal tile
+//     each (12 MFMAs per K step, 3 accumulators), waves 6 and 7 two diagonal tiles each (14 MFMAs,
+//     6 accumulators); SIMD partners (w, w + 4) carry 24 / 24 / 26 / 26 MFMAs.  48..96 accumulator
+//     registers instead of 160 leave room for the generation state of the interleaved stream (the
+//     4-wave deal spilled when interleaved);
+//   * one loop body per panel holds the fragment reads + MFMAs of panel k AND the generation (phase,
+//     sin / cos, weight, hi/lo split, LDS writes) of panel k + 1 into the other LDS buffer, plus the
+//     pixel fetch of panel k + 2; __builtin_amdgcn_sched_group_barrier pins the interleave
+//     (1 MFMA : 6 VALU : LDS / VMEM as available);
+//   * LDS images, fragment addressing, sign masks, diagonal-tile symmetry and the epilogue are those
+//     of the first form.
+// ---------------------------------------------------------------------------------------
+struct V2 {
+    static constexpr int ROWS = 128, NW = 8, GROWS = 64, GEN = 2;
+    static constexpr int IMG = ROWS * MF_ROWB, BUF = 2 * IMG + 64;
+    static constexpr size_t LDS = 2 * (size_t)BUF;
+};
+
+template <int W, bool SIGNED>
+__device__ __forceinline__ void ant_fwd_v2_body(const AntArgs& A, unsigned char* smem)
+{
+    constexpr bool DIAG = W >= 6;
+    // off-diagonal waves: tile (TI, TJ); diagonal waves: tiles (TI, TI) and (TI + 1, TI + 1)
+    constexpr int TI = W < 3 ? 0 : (W < 5 ? 1 : (W == 5 ? 2 : (W == 6 ? 0 : 2)));
+    constexpr int TJ = W < 3 ? W + 1 : (W < 5 ? W - 1 : (W == 5 ? 3 : TI));
+    constexpr int NTW = DIAG ? 2 : 1;                 // tiles of this wave
+    constexpr int MF_IMG = V2::IMG, MF_BUF = V2::BUF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int f = __builtin_amdgcn_readfirstlane(blockIdx.x % A.Nf), ts = blockIdx.x / A.Nf;
+    const int t = __builtin_amdgcn_readfirstlane(ts / A.S), split = __builtin_amdgcn_readfirstlane(ts % A.S);
+
+    const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
+    const float scl = A.scale[t * A.Nf + f];
+    const float* arow = A.psky + (size_t)t * A.st_t + (size_t)f * A.st_f;
+    const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
+    const int st_p = __builtin_amdgcn_readfirstlane((int)A.st_p);
+
+    const int pp = lane & 7, ag = lane >> 3;
+    const int grow = 2 * ag + 16 * (W & 3) + (W >> 2);
+    double ax[V2::GEN], ay[V2::GEN], az[V2::GEN];
+#pragma unroll
+    for (int u = 0; u < V2::GEN; ++u) {
+        const int an = V2::GROWS * u + grow;
+        const bool ok = an < A.Nant;
+        ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
+        ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
+        az[u] = ok ? nu_c * A.antpos[3 * an + 2] : 0.0;
+    }
+    const int goff = grow * MF_ROWB + pp * 4;
+
+    // per tile: real part, imaginary part (off-diagonal tiles: two products, subtracted in the epilogue;
+    // diagonal tiles: one accumulator fed with a negated Li fragment -- two tiles per wave must fit the registers)
+    constexpr int NACC = DIAG ? 2 : 3;
+    f32x16 acc[NTW][NACC];
+#pragma unroll
+    for (int q = 0; q < NTW; ++q)
+#pragma unroll
+        for (int r = 0; r < NACC; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][r][e] = 0.f;
+
+    const int npanel = A.Pstride / MF_KP;
+    const int pbeg = __builtin_amdgcn_readfirstlane(split * A.panels_per_split);
+    const int pend = __builtin_amdgcn_readfirstlane(min(npanel, pbeg + A.panels_per_split));
+    if (pbeg >= pend) return;
+
+    double2 sx[MF_NH], sy[MF_NH], sz[MF_NH]; float2 av[MF_NH];
+    const uint32_t lo_s = 16u * pp, lo_a0 = 8u * pp * (uint32_t)st_p, lo_a1 = lo_a0 + 4u * (uint32_t)st_p;
+    const double* sdy = sd + A.Pstride;
+    const double* sdz = sd + 2 * (size_t)A.Pstride;
+    auto fetch = [&](int panel, int hf) {
+        const int p0 = panel * MF_KP + 16 * hf;
+        sx[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sd + p0) + lo_s);
+        sy[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sdy + p0) + lo_s);
+        sz[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sdz + p0) + lo_s);
+        const char* ab = reinterpret_cast<const char*>(arow + (size_t)p0 * st_p);
+        av[hf] = make_float2(*reinterpret_cast<const float*>(ab + lo_a0), *reinterpret_cast<const float*>(ab + lo_a1));
+    };
+    auto generate = [&](unsigned char* buf, int next_panel) {          // prologue only (first panel of the block)
+#pragma unroll
+        for (int hf = 0; hf < MF_NH; ++hf) {
+            const float w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
+            if (SIGNED && tid < 8)
+                *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
+                    ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
+#pragma unroll
+            for (int u = 0; u < V2::GEN; ++u) {
+                const double ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
+                const double ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
+                const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
+                const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+                uint32_t rh, rl, ih, il;
+                split2(w0 * c0, w1 * c1, rh, rl);
+                split2(w0 * s0, w1 * s1, ih, il);
+                unsigned char* o = buf + goff + u * V2::GROWS * MF_ROWB + 32 * hf;
+                *reinterpret_cast<uint32_t*>(o) = rh;
+                *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+            }
+            fetch(next_panel, hf);
+        }
+    };
+
+    const int foff = (lane & 31) * MF_ROWB + (lane >> 5) * 16;
+    constexpr int NM = (DIAG ? 14 : 12) * MF_NH;      // MFMAs of one loop body
+
+    // ---- one loop body: contraction of the panel in `cb` with the generation of the next panel into
+    // `gb` (GEN) placed chunk by chunk behind the MFMAs; sched_barrier fences keep the hand-made order
+    // (the compiler still allocates registers and places the waits).  Generation = 4 (half panel, antenna)
+    // pairs of 2 pixels x 6 chunks: phase of pixel 0 | phase of pixel 1 | fract + convert | sin / cos |
+    // real part: weight, split, store | imaginary part.  The pixel data of the panel after next are
+    // fetched as soon as the last phase of a half panel has consumed the registers.
+    double ph0, ph1; float r0 = 0.f, r1 = 0.f, s0 = 0.f, c0 = 0.f, s1 = 0.f, c1 = 0.f, w0 = 0.f, w1 = 0.f;
+    auto gen_chunk = [&](auto idx, unsigned char* gb, int fetch_panel) {
+        constexpr int IDX = decltype(idx)::value;
+        if constexpr (IDX >= 0 && IDX < 24) {
+            constexpr int pair = IDX / 6, c = IDX % 6, hf = pair >> 1, u = pair & 1;
+            if constexpr (c == 0) {
+                if constexpr (u == 0) {
+                    w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl);
+                    w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
+                    if (SIGNED && tid < 8)
+                        *reinterpret_cast<uint32_t*>(gb + 2 * MF_IMG + 4 * (8 * hf + pp)) =
+                            ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
+                }
+                ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
+            } else if constexpr (c == 1) {
+                ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
+                if constexpr (u == 1) fetch(fetch_panel, hf);      // this half panel's pixel registers are free now
+            } else if constexpr (c == 2) {
+                r0 = (float)__builtin_amdgcn_fract(ph0);
+                r1 = (float)__builtin_amdgcn_fract(ph1);
+            } else if constexpr (c == 3) {
+                s0 = __builtin_amdgcn_sinf(r0); c0 = __builtin_amdgcn_cosf(r0);
+                s1 = __builtin_amdgcn_sinf(r1); c1 = __builtin_amdgcn_cosf(r1);
+            } else if constexpr (c == 4) {
+                uint32_t rh, rl;
+                split2(w0 * c0, w1 * c1, rh, rl);
+                unsigned char* o = gb + goff + u * V2::GROWS * MF_ROWB + 32 * hf;
+                *reinterpret_cast<uint32_t*>(o) = rh;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+            } else {
+                uint32_t ih, il;
+                split2(w0 * s0, w1 * s1, ih, il);
+                unsigned char* o = gb + goff + u * V2::GROWS * MF_ROWB + 32 * hf + 2 * MF_KP;
+                *reinterpret_cast<uint32_t*>(o) = ih;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG) = il;
+            }
+        }
+    };
+#define RIME_FENCE() __builtin_amdgcn_sched_barrier(0)
+    auto body = [&](const unsigned char* cb, unsigned char* gb, int fetch_panel, auto do_gen) {
+        constexpr bool GEN = decltype(do_gen)::value;
+        auto frag = [&](int tile, int img, int im, int ks) {
+            return *reinterpret_cast<const uint4*>(cb + img * MF_IMG + tile * 32 * MF_ROWB + foff + im * 2 * MF_KP + 32 * ks);
+        };
+        auto sgn = [&](uint4 v, const uint4& sg) {
+            if constexpr (SIGNED) { v.x ^= sg.x; v.y ^= sg.y; v.z ^= sg.z; v.w ^= sg.w; }
+            return v;
+        };
+        // fragments of (tile q, K step ks): loaded one (q, ks) group ahead of their MFMAs
+        constexpr int NG = NTW * MF_NH;                   // fragment groups of the body
+        uint4 F[2][8];                                    // two groups in flight
+        uint4 sgm[2];
+        auto load_group = [&](auto gi) {
+            constexpr int g = decltype(gi)::value;
+            if constexpr (g < NG) {
+                constexpr int q = g % NTW, ks = g / NTW, sl = g & 1;
+                const int ti = TI + q, tj = DIAG ? TI + q : TJ;
+                if constexpr (SIGNED) sgm[sl] = *reinterpret_cast<const uint4*>(cb + 2 * MF_IMG + (2 * ks + (lane >> 5)) * 16);
+                F[sl][0] = frag(ti, 0, 0, ks); F[sl][1] = frag(ti, 0, 1, ks);
+                F[sl][4] = frag(tj, 0, 0, ks); F[sl][5] = frag(tj, 0, 1, ks);
+                F[sl][6] = frag(tj, 1, 0, ks); F[sl][7] = frag(tj, 1, 1, ks);
+                if constexpr (!DIAG) { F[sl][2] = frag(ti, 1, 0, ks); F[sl][3] = frag(ti, 1, 1, ks); }
+            }
+        };
+        constexpr int MPG = DIAG ? 7 : 12;                // MFMAs per fragment group
+        int chunk_dummy = 0; (void)chunk_dummy;
+        load_group(std::integral_constant<int, 0>{});
+        if constexpr (GEN) {                              // the first chunks cover the LDS latency of the first fragments
+            gen_chunk(std::integral_constant<int, 0>{}, gb, fetch_panel);
+            gen_chunk(std::integral_constant<int, 1>{}, gb, fetch_panel);
+        }
+        RIME_FENCE();
+        static_for<0, NG>([&](auto gi) {
+            constexpr int g = decltype(gi)::value, q = g % NTW, sl = g & 1;
+            uint4 Lrh = sgn(F[sl][0], sgm[sl]), Lih = sgn(F[sl][1], sgm[sl]);
+            uint4 Lrl, Lil, Hr, Hi, Ni;
+            if constexpr (DIAG) {
+                Hr = half_frag(Lrh); Hi = half_frag(Lih);
+                Ni = make_uint4(Lih.x ^ 0x80008000u, Lih.y ^ 0x80008000u, Lih.z ^ 0x80008000u, Lih.w ^ 0x80008000u);
+            }
+            else { Lrl = sgn(F[sl][2], sgm[sl]); Lil = sgn(F[sl][3], sgm[sl]); }
+            const uint4 &Brh = F[sl][4], &Bih = F[sl][5], &Brl = F[sl][6], &Bil = F[sl][7];
+            static_for<0, MPG>([&](auto mi) {
+                constexpr int m = decltype(mi)::value;
+                if constexpr (DIAG) {
+                    // Vr = A + A^T, A = (Lrh/2).Brh + (Lih/2).Bih + Lrh.Brl + Lih.Bil;  Vi = A - A^T, A = Lrh.Bih + Lrh.Bil - Lih.Brl
+                    if constexpr (m == 0) acc[q][0] = RIME_MFMA(Hr, Brh, acc[q][0]);
+                    if constexpr (m == 1) acc[q][1] = RIME_MFMA(Lrh, Bih, acc[q][1]);
+                    if constexpr (m == 2) acc[q][0] = RIME_MFMA(Hi, Bih, acc[q][0]);
+                    if constexpr (m == 3) acc[q][1] = RIME_MFMA(Ni, Brl, acc[q][1]);
+                    if constexpr (m == 4) acc[q][0] = RIME_MFMA(Lrh, Brl, acc[q][0]);
+                    if constexpr (m == 5) acc[q][1] = RIME_MFMA(Lrh, Bil, acc[q][1]);
+                    if constexpr (m == 6) acc[q][0] = RIME_MFMA(Lih, Bil, acc[q][0]);
+                } else {
+                    if constexpr (m == 0) acc[q][0] = RIME_MFMA(Lrh, Brh, acc[q][0]);
+                    if constexpr (m == 1) acc[q][1] = RIME_MFMA(Lrh, Bih, acc[q][1]);
+                    if constexpr (m == 2) acc[q][2] = RIME_MFMA(Lih, Brh, acc[q][2]);
+                    if constexpr (m == 3) acc[q][0] = RIME_MFMA(Lih, Bih, acc[q][0]);
+                    if constexpr (m == 4) acc[q][1] = RIME_MFMA(Lrh, Bil, acc[q][1]);
+                    if constexpr (m == 5) acc[q][2] = RIME_MFMA(Lih, Brl, acc[q][2]);
+                    if constexpr (m == 6) acc[q][0] = RIME_MFMA(Lrh, Brl, acc[q][0]);
+                    if constexpr (m == 7) acc[q][1] = RIME_MFMA(Lrl, Bih, acc[q][1]);
+                    if constexpr (m == 8) acc[q][2] = RIME_MFMA(Lil, Brh, acc[q][2]);
+                    if constexpr (m == 9) acc[q][0] = RIME_MFMA(Lih, Bil, acc[q][0]);
+                    if constexpr (m == 10) acc[q][0] = RIME_MFMA(Lrl, Brh, acc[q][0]);
+                    if constexpr (m == 11) acc[q][0] = RIME_MFMA(Lil, Bih, acc[q][0]);
+                }
+                if constexpr (m == 1) load_group(std::integral_constant<int, g + 1>{});     // next group's fragments
+                if constexpr (GEN) {
+                    // chunk schedule: 22 chunks (2 .. 23) over the NM MFMAs of the body
+                    constexpr int k = g * MPG + m;                       // MFMA number in the body
+                    constexpr int c_lo = 2 + (k * 22) / NM, c_hi = 2 + ((k + 1) * 22) / NM;
+                    static_for<c_lo, c_hi>([&](auto ci) { gen_chunk(ci, gb, fetch_panel); });
+                }
+                RIME_FENCE();
+            });
+        });
+    };
+#undef RIME_FENCE
+    using yes = std::true_type; using no = std::false_type;
+
+    unsigned char* const buf0 = smem;
+    unsigned char* const buf1 = smem + MF_BUF;
+#pragma unroll
+    for (int hf = 0; hf < MF_NH; ++hf) fetch(pbeg, hf);
+    generate(buf0, min(pbeg + 1, pend - 1));
+    __syncthreads();
+    int panel = pbeg;
+    // bodies with generation: two per trip (compile-time buffer addresses)
+    for (; panel + 2 < pend; panel += 2) {
+        body(buf0, buf1, panel + 2, yes{});
+        __syncthreads();
+        body(buf1, buf0, min(panel + 3, pend - 1), yes{});
+        __syncthreads();
+    }
+    if (panel + 1 < pend) {                           // two panels left: buf0 holds `panel`
+        body(buf0, buf1, pend - 1, yes{});
+        __syncthreads();
+        body(buf1, buf0, pend - 1, no{});
+    } else {
+        body(buf0, buf1, pend - 1, no{});             // one panel left
+    }
+    __syncthreads();
+
+    // epilogue (as the first form): V[i,j] / scale -> baseline slots of this block's slab
+    float* dst = A.ws + (((size_t)split * A.Nt + t) * A.Nf + f) * 2 * A.Nbl;
+    const float inv = 1.0f / scl;
+    const int col = lane & 31;
+    float* tr = reinterpret_cast<float*>(smem) + W * (32 * 33);
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) {
+        const int ti = TI + q, tj = DIAG ? TI + q : TJ;
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            f32x16 val;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) val[e] = im ? (DIAG ? acc[q][1][e] : acc[q][1][e] - acc[q][NACC - 1][e]) : acc[q][0][e];
+            if constexpr (DIAG) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tr[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 33 + col] = val[e];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float tv = tr[col * 33 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)];
+                    val[e] = im ? val[e] - tv : val[e] + tv;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int i = ti * 32 + row, j = tj * 32 + col;
+                const float v = val[e] * inv;
+                const int bd = A.pair_direct[i * MF_NA + j];
+                if (bd >= 0) dst[(size_t)im * A.Nbl + bd] = v;
+                const int bc = A.pair_conj[i * MF_NA + j];
+                if (bc >= 0) dst[(size_t)im * A.Nbl + bc] = im ? -v : v;
+            }
+        }
+    }
+}
+
+template <bool SIGNED>
+__global__ void __launch_bounds__(512, 2)
+fringe_ant_fwd_v2_kernel(AntArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (row_is_signed(A) != SIGNED) return;
+    switch (threadIdx.x >> 6) {
+        case 0: ant_fwd_v2_body<0, SIGNED>(A, smem); break;
+        case 1: ant_fwd_v2_body<1, SIGNED>(A, smem); break;
+        case 2: ant_fwd_v2_body<2, SIGNED>(A, smem); break;
+        case 3: ant_fwd_v2_body<3, SIGNED>(A, smem); break;
+        case 4: ant_fwd_v2_body<4, SIGNED>(A, smem); break;
+        case 5: ant_fwd_v2_body<5, SIGNED>(A, smem); break;
+        case 6: ant_fwd_v2_body<6, SIGNED>(A, smem); break;
+        default: ant_fwd_v2_body<7, SIGNED>(A, smem); break;
+    }
+}
+
+
+#endif  // RIME_BUILD_FWD_V2
+
 // ---------------------------------------------------------------------------------------
 // backward:  gpsky[t,f,p] = Re sum_{i,j} E_i(p) conj(E_j(p)) G[i,j]
 //                        = sum_i ( Er_i Tr_i + Ei_i Ti_i ),   T_i(p) = sum_j conj(G[i,j]) E_j(p)
@@ -1034,6 +1370,15 @@ extern "C" size_t rime_fringe_ant_workspace(int Nbl, int Nt, int Nf, int Pstride
     return (size_t)S * Nbl * Nt * Nf * 2 * sizeof(float);
 }
 
+#if defined(RIME_BUILD_FWD_V2)
+// lab builds: RIME_MF_FWD_V2=1 selects the interleaved forward kernel for 97..128-antenna diagonal blocks
+static bool fwd_v2_enabled()
+{
+    static const int on = [] { const char* e = getenv("RIME_MF_FWD_V2"); return e ? atoi(e) : 0; }();
+    return on != 0;
+}
+#endif
+
 static bool cross_shape_ok(int rows_i, int rows_j)
 {
     return (rows_i == 32 && rows_j == 32) || (rows_i == 32 && rows_j == 64) || (rows_i == 64 && rows_j == 64) ||
@@ -1098,7 +1443,16 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
         case 1: RIME_FWD_PAIR(1); break;
         case 2: RIME_FWD_PAIR(2); break;
         case 3: RIME_FWD_PAIR(3); break;
-        default: RIME_FWD_PAIR(4); break;
+        default:
+#if defined(RIME_BUILD_FWD_V2)
+            if (fwd_v2_enabled()) {
+                hipLaunchKernelGGL((fringe_ant_fwd_v2_kernel<true>), grid, dim3(512), V2::LDS, st, A);
+                if (rowmin) hipLaunchKernelGGL((fringe_ant_fwd_v2_kernel<false>), grid, dim3(512), V2::LDS, st, A);
+                break;
+            }
+#endif
+            RIME_FWD_PAIR(4);
+            break;
     }
 #undef RIME_FWD_PAIR
     return check_launch();

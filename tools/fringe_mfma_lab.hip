@@ -1,5 +1,7 @@
 // fringe_mfma_lab.hip -- correctness + timing of the antenna-factored MFMA forward kernel against
 // the VALU baseline-formulation kernel on the same inputs (development tool).
+// RIME_MF_FWD_V2=1 in the environment selects the interleaved forward kernel (fringe_mfma.hip, second form)
+#define RIME_BUILD_FWD_V2 1
 #include "../bayeslim_amd/csrc/fringe.hip"
 #include "../bayeslim_amd/csrc/fringe_mfma.hip"
 #include <vector>
