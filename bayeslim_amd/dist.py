@@ -63,26 +63,31 @@ def shard_baselines(bls, rank=None, world_size=None):
 GEN_PER_ROW = 0.64
 
 
-def _block_cost(blk):
-    if blk['ants_j'] is None:
-        ta = (len(blk['ants_i']) + 31) // 32
-        mf = 7 * ta + 12 * (ta * (ta - 1) // 2) + 12 * (ta * (ta + 1) // 2)
-        rows = 32 * ta
-    else:
-        mf = 2 * 12 * (blk['rows_i'] // 32) * (blk['rows_j'] // 32)
-        rows = blk['rows_i'] + blk['rows_j']
-    return mf + 2 * GEN_PER_ROW * rows
+def _cap(n):
+    return 32 if n <= 32 else (64 if n <= 64 else 128)
+
+
+def _item_cost(ni, nj):
+    """cost of a block with ni row antennas against nj column antennas (nj None: diagonal block)"""
+    if nj is None:
+        ta = (ni + 31) // 32
+        return 7 * ta + 12 * (ta * (ta - 1) // 2) + 12 * (ta * (ta + 1) // 2) + 2 * GEN_PER_ROW * 32 * ta
+    ci, cj = _cap(ni), _cap(nj)
+    if (min(ci, cj), max(ci, cj)) not in ((32, 32), (32, 64), (64, 64), (128, 128)):
+        ci = cj = 128
+    return 2 * 12 * (ci // 32) * (cj // 32) + 2 * GEN_PER_ROW * (ci + cj)
 
 
 def plan_tile_shards(bl_ants, Nant, world_size, bl_mp=None, ant_model=None, groups=(128, 64, 32)):
     """
     Deal the blocks of the antenna pair matrix (ops._antenna_blocks: groups of <= g antennas,
-    diagonal + cross blocks, per beam-model pair) to `world_size` ranks, longest block first to the
-    least-loaded rank, for the group size g that gives the smallest maximum load.
-    bl_ants: antenna-INDEX pairs of all baselines.  Returns dict(group=g, rank_bls=[baseline indices
-    (ascending) per rank], load=[cost per rank], order=concatenation of rank_bls, inverse=its inverse
-    permutation (gathered[..., inverse] restores the original baseline order)), or None when the pair
-    set cannot be represented (a pair listed twice).
+    diagonal + cross blocks, per beam-model pair) to `world_size` ranks, longest item first to the
+    least-loaded rank, for the group size g -- with cross blocks whole or cut into slabs of 32 row
+    antennas (a rank's geometry drops the antennas its shard of a block does not touch) -- that gives the
+    smallest maximum load.  bl_ants: antenna-INDEX pairs of all baselines.  Returns dict(group=g,
+    rank_bls=[baseline indices (ascending) per rank], load=[cost per rank], order=concatenation of
+    rank_bls, inverse=its inverse permutation (gathered[..., inverse] restores the original baseline
+    order)), or None when the pair set cannot be represented (a pair listed twice).
     """
     from . import ops
     best = None
@@ -90,25 +95,37 @@ def plan_tile_shards(bl_ants, Nant, world_size, bl_mp=None, ant_model=None, grou
         blocks = ops._antenna_blocks(bl_ants, Nant, bl_mp, ant_model, group=g)
         if blocks is None:
             return None
-        cost = [_block_cost(b) for b in blocks]
-        load = [0.0] * world_size
-        owner = [[] for _ in range(world_size)]
-        ants = [set() for _ in range(world_size)]
-        for k in sorted(range(len(blocks)), key=lambda k: -cost[k]):
-            blk = blocks[k]
-            touched = set(blk['ants_i']) | set(blk['ants_j'] or ())
-            # least-loaded rank; ties go to the rank that already generates these antennas
-            r = min(range(world_size), key=lambda r: (round(load[r], 6), -len(ants[r] & touched), r))
-            load[r] += cost[k]
-            owner[r].append(k)
-            ants[r] |= touched
-        if best is None or max(load) < 0.98 * max(best['load']):
-            rank_bls = []
-            for r in range(world_size):
-                idx = [np.concatenate([blocks[k]['direct'][blocks[k]['direct'] >= 0],
-                                       blocks[k]['conj'][blocks[k]['conj'] >= 0]]) for k in owner[r]]
-                rank_bls.append(sorted(int(i) for i in np.concatenate(idx)) if idx else [])
-            best = dict(group=g, rank_bls=rank_bls, load=load, nblocks=[len(o) for o in owner])
+        for slabs in (False, True):
+            items = []                                 # (cost, baseline slots, antennas touched)
+            for blk in blocks:
+                d, c = blk['direct'], blk['conj']
+                ni = len(blk['ants_i'])
+                if blk['ants_j'] is None or not slabs or ni <= 32:
+                    slots = np.concatenate([d[d >= 0], c[c >= 0]])
+                    items.append((_item_cost(ni, None if blk['ants_j'] is None else len(blk['ants_j'])), slots,
+                                  set(blk['ants_i']) | set(blk['ants_j'] or ())))
+                else:
+                    for r0 in range(0, ni, 32):
+                        dd, cc = d[r0:r0 + 32], c[r0:r0 + 32]
+                        slots = np.concatenate([dd[dd >= 0], cc[cc >= 0]])
+                        if len(slots):
+                            cols = np.nonzero(((dd >= 0) | (cc >= 0)).any(0))[0]
+                            items.append((_item_cost(min(32, ni - r0), len(cols)), slots,
+                                          set(blk['ants_i'][r0:r0 + 32]) | {blk['ants_j'][k] for k in cols}))
+            if slabs and len(items) == len(blocks):
+                continue                               # nothing was cut: same as the whole-block variant
+            load = [0.0] * world_size
+            owner = [[] for _ in range(world_size)]
+            ants = [set() for _ in range(world_size)]
+            for k in sorted(range(len(items)), key=lambda k: -items[k][0]):
+                # least-loaded rank; ties go to the rank that already generates these antennas
+                r = min(range(world_size), key=lambda r: (round(load[r], 6), -len(ants[r] & items[k][2]), r))
+                load[r] += items[k][0]
+                owner[r].append(k)
+                ants[r] |= items[k][2]
+            if best is None or max(load) < 0.98 * max(best['load']):
+                rank_bls = [sorted(int(i) for k in owner[r] for i in items[k][1]) for r in range(world_size)]
+                best = dict(group=g, rank_bls=rank_bls, load=load, nblocks=[len(o) for o in owner], slabs=slabs)
     order = np.asarray([i for bl in best['rank_bls'] for i in bl], dtype=np.int64)
     assert len(order) == len(bl_ants) and len(set(order.tolist())) == len(order)
     inverse = np.empty_like(order)

@@ -182,16 +182,40 @@ def _antenna_blocks(bl_ants, Nant, bl_mp=None, ant_model=None, group=MFMA_GROUP)
             return None
         tab[i, j] = b
     blocks = []
+
+    def compact(tab, rows, cols):
+        out = np.full((MFMA_GROUP, MFMA_GROUP), -1, dtype=np.int32)
+        out[:len(rows), :len(cols)] = tab[np.ix_(rows, cols)]
+        return out
+
     for (gi, gj, mp) in sorted(tabs):
         direct, conj = tabs[(gi, gj, mp)]
         nd, nc = int((direct >= 0).sum()), int((conj >= 0).sum())
-        blk = dict(ants_i=groups[gi], ants_j=None, rows_i=len(groups[gi]), rows_j=0, mp=mp,
-                   cpass=(1 if nc == 0 else (-1 if nd == 0 else 0)))
+        # antennas of the groups that hold no baseline of this block are dropped (a rank-local shard of a
+        # block, a sparse pair set): fewer generated rows, possibly a smaller kernel shape
+        used = (direct >= 0) | (conj >= 0)
+        if gi == gj:
+            keep = np.nonzero(used.any(0) | used.any(1))[0]
+            # tile membership (index // 32) decides direct vs conj inside a diagonal block: only drop whole
+            # trailing / unused 32-antenna tiles' worth when the order of the rest is unchanged
+            if len(keep) < len(groups[gi]) and np.array_equal(keep // 32, np.arange(len(keep)) // 32):
+                direct, conj = compact(direct, keep, keep), compact(conj, keep, keep)
+                ants_i = [groups[gi][k] for k in keep]
+            else:
+                ants_i = groups[gi]
+            blk = dict(ants_i=ants_i, ants_j=None, rows_i=len(ants_i), rows_j=0, mp=mp,
+                       cpass=(1 if nc == 0 else (-1 if nd == 0 else 0)))
+        else:
+            ri, cj_ = np.nonzero(used.any(1))[0], np.nonzero(used.any(0))[0]
+            direct, conj = compact(direct, ri, cj_), compact(conj, ri, cj_)
+            blk = dict(ants_i=[groups[gi][k] for k in ri], ants_j=None, rows_i=len(ri), rows_j=0, mp=mp,
+                       cpass=(1 if nc == 0 else (-1 if nd == 0 else 0)))
+            gi_ants, gj_ants = blk['ants_i'], [groups[gj][k] for k in cj_]
         if gi != gj:
-            ci, cj = _group_capacity(len(groups[gi]), group), _group_capacity(len(groups[gj]), group)
+            ci, cj = _group_capacity(len(gi_ants), group), _group_capacity(len(gj_ants), group)
             if (ci, cj) not in ((32, 32), (32, 64), (64, 32), (64, 64), (128, 128)):
                 ci = cj = 128                                # unequal groups: padded to the full shape
-            ai, aj = groups[gi], groups[gj]
+            ai, aj = gi_ants, gj_ants
             if ci > cj:
                 # the kernels take the smaller group as I: swap the groups (V[j, i] = conj(V[i, j]))
                 ai, aj, ci, cj = aj, ai, cj, ci

@@ -1,8 +1,11 @@
-"""Per-rank compute time of the channel-sharded C4 step for world sizes 1, 2, 4, 8 on ONE GPU:
-rank 0's shard, no collectives (those are measured by the driver's multi-GPU runs).
+"""Per-rank COMPUTE time of the sharded C4 step for world sizes 1, 2, 4, 8 on ONE GPU, no collectives
+(those are measured by the driver's multi-GPU runs): the slowest rank's shard of
+  freq : contiguous channel blocks (rank 0's block; all blocks are equal)
+  bl   : baseline-tile shards (dist.plan_tile_shards): the rank with the largest planned load
 python tools/emulate_rank.py [workload] [nt]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 import bench
 from bayeslim_amd import dist as rdist
@@ -13,11 +16,11 @@ nt = int(sys.argv[2]) if len(sys.argv) > 2 else cfg['nt']
 dev = torch.device('cuda', 0)
 inp = bench.build_inputs(wl, nt)
 bls = bench.all_baselines(inp)
-base = None
-for world in (1, 2, 4, 8):
-    fblock = rdist.shard_bounds(cfg['Nf'], world)[0]
-    rime, params, attach, _ = bench.build_model(inp, dev, bls, fblock=fblock)
+idx = {a: i for i, a in enumerate(inp['ants'])}
+bl_ants = [(idx[a], idx[b]) for a, b in bls]
 
+
+def timed(rime, params, attach):
     def step():
         for p in params:
             p.grad = None
@@ -34,8 +37,26 @@ for world in (1, 2, 4, 8):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 4 * 1e3
     t0 = time.perf_counter(); step(); enq = (time.perf_counter() - t0) * 1e3; torch.cuda.synchronize()
-    base = base or ms
-    print('world %d: channels %3d per rank, %.2f ms/step (host enqueue %.2f ms), compute-only speedup %.2fx' % (
-        world, fblock[1] - fblock[0], ms, enq, base / ms))
-    del rime, params
-    torch.cuda.empty_cache()
+    return ms, enq
+
+
+base = {}
+for mode in ('freq', 'bl'):
+    for world in (1, 2, 4, 8):
+        if mode == 'freq':
+            fblock = rdist.shard_bounds(cfg['Nf'], world)[0]
+            rime, params, attach, _ = bench.build_model(inp, dev, bls, fblock=fblock)
+            what = 'channels %3d per rank' % (fblock[1] - fblock[0])
+        else:
+            plan = rdist.plan_tile_shards(bl_ants, len(inp['ants']), world)
+            r = int(np.argmax(plan['load']))
+            rime, params, attach, _ = bench.build_model(inp, dev, [bls[i] for i in plan['rank_bls'][r]])
+            rime.mfma_group, rime.mfma_mode = plan['group'], True
+            what = 'rank %d of the tile plan: groups of %d antennas, %d block(s), %d baselines, planned load %.0f of %.0f' % (
+                r, plan['group'], plan['nblocks'][r], len(plan['rank_bls'][r]), plan['load'][r], sum(plan['load']))
+        ms, enq = timed(rime, params, attach)
+        base.setdefault(mode, ms)
+        print('%-4s world %d: %s, %.2f ms/step (host enqueue %.2f ms), compute-only speedup %.2fx' % (
+            mode, world, what, ms, enq, base[mode] / ms))
+        del rime, params, attach
+        torch.cuda.empty_cache()
