@@ -448,6 +448,34 @@ def _fringe_call(geom, backward, inp, out, Npp, cplx, strides=None):
         prof.append(('fringe_bwd_kernel' if backward else 'fringe_fwd_kernel', e0, e1, geom.elements, 0))
 
 
+def _npp_chunks(Npp, cplx):
+    """polarisation-product planes in runs the baseline-formulation kernels take natively (real psky: 4, 2, 1
+    planes per launch; complex: 4 or 1): imaging puts any number of maps on this axis"""
+    sizes = (4, 1) if cplx else (4, 2, 1)
+    out, q = [], 0
+    while q < Npp:
+        n = next(k for k in sizes if k <= Npp - q)
+        out.append((q, n))
+        q += n
+    return out
+
+
+def _fringe_call_planes(geom, backward, psky_like, vis_like, cplx):
+    """_fringe_call over a psky-shaped tensor (Nt, Nmp, Npp, Nf, P) and a vis-shaped tensor (Npp, Nbl, Nt, Nf):
+    one launch when the kernels take the plane count as it is, else one per run of planes"""
+    Npp = psky_like.shape[2]
+    native = (geom.ant is not None and psky_like.dtype in (torch.float32, torch.complex64)) or \
+        (Npp in (1, 4)) or (Npp == 2 and not cplx)
+    for q0, n in ([(0, Npp)] if native else _npp_chunks(Npp, cplx)):
+        p = psky_like.narrow(2, q0, n)
+        v = vis_like.narrow(0, q0, n)
+        pr, vr = (torch.view_as_real(p) if cplx else p), torch.view_as_real(v)
+        if backward:
+            _fringe_call(geom, True, vr, pr, n, cplx, _dense_strides(p))
+        else:
+            _fringe_call(geom, False, pr, vr, n, cplx, _dense_strides(p))
+
+
 class _FringeSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, psky, geom):
@@ -466,8 +494,7 @@ class _FringeSum(torch.autograd.Function):
         _, rdt = _real_dtype(p)
         cdt = torch.complex64 if rdt == torch.float32 else torch.complex128
         vis = torch.empty((Npp, geom.Nbl, Nt, Nf), dtype=cdt, device=p.device)
-        _fringe_call(geom, False, torch.view_as_real(p) if cplx else p, torch.view_as_real(vis),
-                     Npp, cplx, strides)
+        _fringe_call_planes(geom, False, p, vis, cplx)
         ctx.geom, ctx.cplx, ctx.dtype = geom, cplx, psky.dtype
         ctx.pshape, ctx.pstride = tuple(p.shape), tuple(p.stride())   # gradient buffer template only
         return vis
@@ -477,9 +504,7 @@ class _FringeSum(torch.autograd.Function):
         geom = ctx.geom
         g = gvis.contiguous()
         gp = torch.empty_strided(ctx.pshape, ctx.pstride, dtype=ctx.dtype, device=g.device)
-        _fringe_call(geom, True, torch.view_as_real(g),
-                     torch.view_as_real(gp) if ctx.cplx else gp, ctx.pshape[2], ctx.cplx,
-                     _dense_strides(gp))
+        _fringe_call_planes(geom, True, gp, g, ctx.cplx)
         return gp, None
 
 
@@ -504,7 +529,7 @@ def fringe_adjoint(gvis, geom, Npp=None, dtype=None):
     assert tuple(g.shape) == (Npp, geom.Nbl, geom.Nt, geom.Nf)
     rdt = torch.float32 if g.dtype == torch.complex64 else torch.float64
     out = torch.empty((geom.Nt, 1, Npp, geom.Nf, geom.Pstride), dtype=rdt, device=g.device)
-    _fringe_call(geom, True, torch.view_as_real(g), out, Npp, False, _dense_strides(out))
+    _fringe_call_planes(geom, True, out, g, False)
     return out
 
 

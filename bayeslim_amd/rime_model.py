@@ -161,14 +161,17 @@ class RIME(utils.Module):
         return dev
 
     def _zenaz(self, key, time, ra, dec, dev):
-        za = self._zenaz_cache.get(key)
-        if za is None:
-            angs = self.telescope.eq2top(time, ra, dec, store=self.cache_eq2top, key=key)
-            zen = torch.as_tensor(angs[0]).to(device=dev, dtype=torch.float64)
-            az = torch.as_tensor(angs[1]).to(device=dev, dtype=torch.float64)
-            za = (zen, az)
-            self._zenaz_cache[key] = za
-        return za
+        src = self.telescope.conv_cache.get(key)
+        hit = self._zenaz_cache.get(key)
+        if hit is not None and hit[0] == id(src) and src is not None:
+            return hit[1]
+        angs = self.telescope.eq2top(time, ra, dec, store=self.cache_eq2top, key=key)
+        zen = torch.as_tensor(angs[0]).to(device=dev, dtype=torch.float64)
+        az = torch.as_tensor(angs[1]).to(device=dev, dtype=torch.float64)
+        # remembered together with the identity of the conv_cache entry it came from: replacing that
+        # entry (new coordinates for the same key) is seen on the next forward
+        self._zenaz_cache[key] = (id(self.telescope.conv_cache.get(key)), (zen, az))
+        return zen, az
 
     def _batch_geometry(self, name, ra, dec, Npix, dev, pairs, bl_mp):
         """
@@ -177,10 +180,29 @@ class RIME(utils.Module):
         the float64 pointing vectors (telescope_model.py:337-343), padded to a common stride Ps
         (multiple of 64) and concatenated over the Nt time steps of the minibatch.
         """
-        gkey = (self.bl_group_id, self.time_group_id, name, Npix)
+        # everything the cached entry bakes in is part of its key: the FoV cut, the antenna positions (tensor
+        # identity + in-place version), the channel grid and the matrix-core grouping
+        av = self.array.antvecs
+        fq = self.freqs
+        cc = self.telescope.conv_cache
+        gkey = (self.bl_group_id, self.time_group_id, name, Npix, float(self.beam.fov), av.data_ptr(), av._version,
+                (fq.data_ptr(), fq._version) if isinstance(fq, torch.Tensor) else id(fq),
+                getattr(self, 'mfma_group', None), getattr(self, 'mfma_mode', 'auto'),
+                tuple(id(cc.get((name, Npix, float(t)))) for t in self.sim_times))      # replaced (zen, az) entries
         bg = self._geom_cache.get(gkey)
         if bg is not None:
             return bg
+        for k in [k for k in self._geom_cache if k[:4] == gkey[:4]]:        # superseded entries of this minibatch
+            del self._geom_cache[k]
+        # the reference's fringe uses array.freqs[array._freq_idx] (telescope_model.py:350); here RIME.freqs
+        # feeds the kernels, so the two must describe the same channels
+        af = self.array._freqs_active() if getattr(self.array, 'freqs', None) is not None else None
+        if af is not None:
+            a64 = torch.as_tensor(af).detach().to('cpu', torch.float64)
+            r64 = torch.as_tensor(self.freqs).detach().to('cpu', torch.float64)
+            if a64.shape != r64.shape or not torch.allclose(a64, r64, rtol=1e-6, atol=0.0):
+                raise ValueError('RIME.freqs and the ArrayModel\'s active frequencies (array.freqs[_freq_idx]) differ: '
+                                 'the fringe is evaluated at RIME.freqs')
         keys = [(name, Npix, float(t)) for t in self.sim_times]
         za = [self._zenaz(k, t, ra, dec, dev) for k, t in zip(keys, self.sim_times)]
         cuts = []

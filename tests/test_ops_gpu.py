@@ -765,3 +765,27 @@ def test_eq2top_kernel_matches_float64_host_chain(ops):
     a = tel.eq2top(2459861.2, torch.as_tensor(ra).cuda(), torch.as_tensor(dec).cuda())
     b = tel.eq2top(2459861.2, torch.as_tensor(ra), torch.as_tensor(dec))
     assert a.is_cuda and np.abs(a.cpu().numpy()[0] - b.numpy()[0]).max() < 1e-10
+
+
+@pytest.mark.parametrize('Npp,cplx,dtype', [(3, False, torch.float64), (5, False, torch.float32), (2, True, torch.float64),
+                                            (3, True, torch.float32), (7, False, torch.float64)])
+def test_fringe_sum_any_number_of_planes(ops, Npp, cplx, dtype):
+    """plane counts the baseline-formulation kernels do not take natively (imaging puts Nmaps on this axis,
+    imaging.py:717-815) run as several launches -- same values and gradients as the oracle"""
+    blvecs, freqs, zenaz, psky, bl_mp = make_case(21, Nbl=9, Nt=2, Nf=5, P=130, Nmp=1, Npp=Npp, cplx=cplx)
+    geom, Ps = to_gpu_geometry(ops, blvecs, freqs, zenaz, bl_mp, 1)
+    ref_in = psky.clone().requires_grad_(True)
+    ref = oracle_fringe_sum(ref_in, blvecs, zenaz, freqs, bl_mp)
+    gv = torch.as_tensor(np.random.default_rng(5).normal(size=tuple(ref.shape))
+                         + 1j * np.random.default_rng(6).normal(size=tuple(ref.shape)))
+    (ref * gv.conj()).real.sum().backward()
+    cdt = {torch.float64: torch.complex128, torch.float32: torch.complex64}[dtype]
+    x = pad_psky(psky, Ps).to(cdt if cplx else dtype).cuda().requires_grad_(True)
+    vis = ops.fringe_sum(x, geom)
+    tv, tg = (1e-11, 1e-11) if dtype == torch.float64 else (1e-5, 1e-4)
+    assert vis.shape == (Npp, 9, 2, 5) and relmax(vis, ref) < tv
+    (vis * gv.to(cdt).cuda().conj()).real.sum().backward()
+    assert relmax(x.grad[..., :130], ref_in.grad) < tg
+    if not cplx:
+        adj = ops.fringe_adjoint(gv.to(cdt).cuda(), geom)
+        assert relmax(adj[..., :130], ref_in.grad) < tg
