@@ -438,7 +438,7 @@ alm2pix_fwd_f16_kernel(const uint4* __restrict__ a_hi, const uint4* __restrict__
 // loaded latency); per-lane row streaming without LDS staging and contiguous split ranges are
 // within 5 % of this.
 template <int MT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)       // two blocks per CU: the kernel is bound by the Ylm bytes in flight
 alm2pix_bwd_f16_kernel(const uint4* __restrict__ g_hi, const uint4* __restrict__ g_lo,
                        const float* __restrict__ inv_scale, const float* __restrict__ Ylm, float y_scale,
                        int R, int Rpad, int Ncoeff, int Npix, int S, float* __restrict__ part)
@@ -582,6 +582,29 @@ struct SplitPlan {
     int S, steps_per_split;          // backward only: pixel splits
 };
 
+template <int MT> __global__ void alm2pix_bwd_f16_kernel(const uint4*, const uint4*, const float*, const float*, float,
+                                                         int, int, int, int, int, float*);
+
+// blocks of the f16-split backward kernel the chip holds at once (occupancy query, cached per shape)
+static long bwd_resident_blocks(int MT)
+{
+    static long cache[5] = {0, 0, 0, 0, 0};
+    if (cache[MT] == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+        if (e == hipSuccess) {
+            if (MT == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, alm2pix_bwd_f16_kernel<4>, 256, 0);
+            else if (MT == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, alm2pix_bwd_f16_kernel<2>, 256, 0);
+            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, alm2pix_bwd_f16_kernel<1>, 256, 0);
+        }
+        cache[MT] = (e == hipSuccess && per_cu > 0) ? (long)per_cu * prop.multiProcessorCount : 512;
+        (void)hipGetLastError();
+    }
+    return cache[MT];
+}
+
 static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward)
 {
     SplitPlan p{};
@@ -591,11 +614,20 @@ static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward)
     p.img_bytes = (size_t)p.nsteps * 2 * p.Rpad * 16;
     p.S = 1; p.steps_per_split = p.nsteps;
     if (backward) {
-        // ~2048 blocks of 128 coefficients x MT row tiles
+        // ~2048 blocks of 128 coefficients x MT row tiles, as WHOLE rounds of the resident grid: every block
+        // streams the same number of chunks, so 4.1 rounds cost 5 (C3: 66 tiles x 32 splits = 2112 blocks over
+        // 512 resident ones; 31 splits = 2046 blocks = 4.0 rounds)
         const long blocks = (long)((Ncoeff + 127) / 128) * (p.Rpad / (p.MT * 32));
+        const long resident = bwd_resident_blocks(p.MT);
         long S = (2048 + blocks - 1) / blocks;                   // measured flat between 1024 and 4096 blocks
         const long maxS = std::max(1, p.nsteps / 32);          // >= 16 chunks of 2 K steps per block
-        p.S = (int)std::max<long>(1, std::min(S, maxS));
+        S = std::max<long>(1, std::min(S, maxS));
+        if (blocks * S > resident) {
+            const long rounds = std::max<long>(1, (blocks * S + resident / 2) / resident);    // nearest whole number of rounds
+            const long S2 = (rounds * resident) / blocks;                                      // largest split count that fits them
+            if (S2 >= 1 && S2 <= maxS) S = S2;
+        }
+        p.S = (int)S;
         p.steps_per_split = 0;                                   // chunks are dealt cyclically
     }
     return p;
