@@ -42,7 +42,7 @@ def gen_fringe(blvecs, zen, az, freqs, conj=False):
     s = pointing_vectors(zen, az).to(blvecs.dtype)
     sign = -2j if conj else 2j
     const = freqs[:, None] * (sign * math.pi / C_LIGHT)
-    return ((blvecs @ s)[:, None, :] * const).exp()
+    return ((blvecs @ s)[:, None, :] * const).exp_()          # in place on the temporary, as the reference (:356)
 
 
 # ---------------------------------------------------------------------------
