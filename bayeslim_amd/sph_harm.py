@@ -146,13 +146,42 @@ class AlmModel:
                 self._inflated = inflate_Ylm(Ylm).contiguous()
                 self._inflated_key = key
             Ylm = self._inflated
-        if torch.is_complex(Ylm) and torch.is_complex(params) and self.real_output:
-            if not params.is_cuda:
-                raise RuntimeError('AlmModel.forward_alm needs GPU tensors (no CPU path)')
-            return ops.alm2pix(params, self._cast_Ylm(Ylm, params.dtype))
-        # real Ylm (built with real=True) or complex output requested: plain GEMM (hipBLASLt)
+        if not params.is_cuda:
+            raise RuntimeError('AlmModel.forward_alm needs GPU tensors (no CPU path)')
+        if torch.is_complex(Ylm) and torch.is_complex(params):
+            Yk = self._cast_Ylm(Ylm, params.dtype)
+            if self.real_output:
+                return ops.alm2pix(params, Yk)
+            # complex output: Im(a Y) = Re((-i a) Y), so the rows [a ; -i a] go through the kernels in ONE
+            # pass over Ylm (2 R rows) and the two halves are the real and imaginary parts
+            both = ops.alm2pix(torch.stack([params, params * (-1j)]), Yk)
+            return torch.complex(both[0], both[1])
+        if not torch.is_complex(Ylm) and not torch.is_complex(params):
+            # real Ylm (gen_sph2pix(real=True)): sum_c a_c Y_c = Re sum_k (a_2k - i a_2k+1)(Y_2k + i Y_2k+1) -- the
+            # same kernels on a pair-packed copy of Ylm (built once per Ylm object, same bytes)
+            Yp = self._packed_real_Ylm(Ylm, params.dtype)
+            a = params
+            if a.shape[-1] % 2:
+                a = torch.cat([a, a.new_zeros(a.shape[:-1] + (1,))], dim=-1)
+            a = a.reshape(a.shape[:-1] + (a.shape[-1] // 2, 2))
+            return ops.alm2pix(torch.complex(a[..., 0], -a[..., 1]), Yp)
+        # mixed real / complex operands (not produced by the reference's own constructors): plain GEMM
         out = torch.einsum('...i,ij->...j', params, Ylm.to(params.dtype))
         return out.real if (self.real_output and torch.is_complex(out)) else out
+
+    def _packed_real_Ylm(self, Ylm, dtype):
+        """real (Ncoeff, Npix) Ylm as complex (ceil(Ncoeff / 2), Npix): rows 2k + i rows 2k+1, cached per Ylm object"""
+        cache = self.__dict__.setdefault('_Ylm_pack_cache', {})
+        ent = cache.get(id(Ylm))
+        if ent is None or ent[0] is not Ylm or ent[1] != Ylm._version or ent[2].real.dtype != dtype:
+            if len(cache) > 8:
+                cache.clear()
+            Y = Ylm.to(dtype)
+            if Y.shape[0] % 2:
+                Y = torch.cat([Y, Y.new_zeros((1, Y.shape[1]))], dim=0)
+            ent = (Ylm, Ylm._version, torch.complex(Y[0::2], Y[1::2]).contiguous())
+            cache[id(Ylm)] = ent
+        return ent[2]
 
     def _cast_Ylm(self, Ylm, dtype):
         """Ylm in the parameters' dtype, converted once per Ylm object (a complex128 matrix used with
