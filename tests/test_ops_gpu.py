@@ -516,6 +516,8 @@ def test_interp_gather(ops, mode, dtype):
     g = load_golden('interp_rect')
     key = mode.replace(',', '_')
     Npb = len(g['theta_grid']) * len(g['phi_grid'])
+    # the fixture does not store the beam map: it is re-drawn from the generator's stream, which drew the 120
+    # (zen, az) samples first (tests/golden/make_golden.py, gen_interp_cases) -- the two draws below replay them
     rng = np.random.default_rng(3)
     rng.uniform(0.02, 89.9, 120)
     rng.uniform(0.0, 359.999, 120)
