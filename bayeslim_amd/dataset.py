@@ -80,6 +80,55 @@ class VisData(TensorData):
         if return_obj:
             return self
 
+    def _inflate_by_redundancy(self, new_bls, red_bl_inds, try_view=False):
+        """
+        new VisData whose baseline axis is self's indexed by red_bl_inds (one redundant-group index per
+        baseline of new_bls): data, flags, cov and icov alike (dataset.py:1568-1602).  The gather is a
+        differentiable index_select on the tensors' own device.
+        """
+        idx = torch.as_tensor(red_bl_inds, dtype=torch.int64)
+
+        def take(x):
+            if x is None:
+                return None
+            return x.index_select(2, idx.to(x.device))
+
+        cov = self.cov if (self.cov is None or self.cov_axis not in (None, 'bl')) else take(self.cov)
+        icov = self.icov if (self.icov is None or self.cov_axis not in (None, 'bl')) else take(self.icov)
+        out = VisData()
+        out.setup_meta(telescope=self.telescope, antpos=self.antpos)
+        out.setup_data(new_bls, self.times, self.freqs, pol=self.pol, data=take(self.data), flags=take(self.flags),
+                       cov=cov, cov_axis=self.cov_axis, icov=icov, history=self.history)
+        return out
+
+    def inflate_by_redundancy(self, bls, bl2red):
+        """copy every redundant type held here over to the physical baselines `bls` of the same type
+        (bl2red: baseline -> redundant-group index, e.g. ArrayModel.bl2red; dataset.py:1604-1640)"""
+        mine = {bl2red[b]: i for i, b in enumerate(self.bls)}
+        keep = [b for b in bls if bl2red[b] in mine]
+        return self._inflate_by_redundancy(keep, [mine[bl2red[b]] for b in keep])
+
+
+class RedVisInflate(utils.Module):
+    """VisData redundant-inflation block of a forward-model chain (dataset.py:3699-3735): the step that
+    follows RIME when only one baseline per redundant group was simulated"""
+    def __init__(self, new_bls, red_bl_inds):
+        super().__init__()
+        self.new_bls = new_bls
+        self.red_bl_inds = torch.as_tensor(red_bl_inds, dtype=torch.int64)
+        self.device = None
+
+    def __call__(self, vd, **kwargs):
+        return vd._inflate_by_redundancy(new_bls=self.new_bls, red_bl_inds=self.red_bl_inds)
+
+    def forward(self, vd, **kwargs):
+        return self(vd, **kwargs)
+
+    def push(self, device):
+        if not isinstance(device, torch.dtype):
+            self.red_bl_inds = utils.push(self.red_bl_inds, device)
+            self.device = device
+
 
 class MapData(TensorData):
     """sky map of shape (Npol, 1, Nfreqs, Npix) with pixel angles (dataset.py:1867)"""

@@ -828,6 +828,26 @@ def gen_apply_cal(ba):
         (vout * cot.conj()).real.sum().backward()
         out.update({'vis_' + tag: vis, 'gains_' + tag: gains, 'vout_' + tag: vout, 'cot_' + tag: cot,
                     'gvis_' + tag: vis.grad, 'ggains_' + tag: gains.grad})
+    # remaining branches of the function: undo (gain inversion), covariance propagation, delay-type visibilities
+    for tag, npol, two in [('1pol', 1, False), ('2pol', 2, True)]:
+        vis = rc(npol, npol, Nbl, Nt, Nf).requires_grad_(True)
+        gains = rc(npol, npol, Nant, Nt, Nf)
+        if two:
+            gains[0, 1] = 0
+            gains[1, 0] = 0
+        gains.requires_grad_(True)
+        cov = torch.as_tensor(np.abs(rng.normal(size=(npol, npol, Nbl, Nt, Nf))) + 0.1)
+        vout, cout = apply_cal(vis, gains, g1_idx, g2_idx, cal_2pol=two, cov=cov, undo=True)
+        cot = rc(*vout.shape)
+        (vout * cot.conj()).real.sum().backward()
+        out.update({'u_vis_' + tag: vis, 'u_gains_' + tag: gains, 'u_cov_' + tag: cov, 'u_vout_' + tag: vout,
+                    'u_cout_' + tag: cout, 'u_cot_' + tag: cot, 'u_gvis_' + tag: vis.grad, 'u_ggains_' + tag: gains.grad})
+    dvis = torch.as_tensor(rng.normal(size=(1, 1, Nbl, Nt, Nf))).requires_grad_(True)
+    dg = torch.as_tensor(rng.normal(size=(1, 1, Nant, Nt, Nf))).requires_grad_(True)
+    for undo in (False, True):
+        dout, _ = apply_cal(dvis, dg, g1_idx, g2_idx, vis_type='dly', undo=undo)
+        out['dly_vout_undo%d' % undo] = dout
+    out.update(dly_vis=dvis, dly_gains=dg)
     save('apply_cal', **out)
 
 

@@ -740,8 +740,28 @@ def test_apply_cal(ops, dtype):
         (out * cot.to(cdt).cuda().conj()).real.sum().backward()
         assert relmax(v.grad, vr.grad) < tol
         assert relmax(gn.grad, gr.grad) < 10 * tol
-    with pytest.raises(NotImplementedError):
-        calibration._apply_cal(v, gn, [0], [0], undo=True)
+    # the remaining branches of the reference function: undo + covariance (1-pol, 2-pol), delay-type visibilities
+    rdt = torch.float64 if dtype == 'f64' else torch.float32
+    for tag, two in (('1pol', False), ('2pol', True)):
+        vis = torch.as_tensor(g['u_vis_' + tag]).to(cdt).cuda().requires_grad_(True)
+        gains = torch.as_tensor(g['u_gains_' + tag]).to(cdt).cuda().requires_grad_(True)
+        cov = torch.as_tensor(g['u_cov_' + tag]).to(rdt).cuda()
+        out, cout = calibration._apply_cal(vis, gains, g['g1_idx'], g['g2_idx'], cal_2pol=two, cov=cov, undo=True)
+        assert relmax(out.detach(), g['u_vout_' + tag]) < 10 * tol, tag
+        assert relmax(cout, g['u_cout_' + tag]) < 10 * tol, tag
+        (out * torch.as_tensor(g['u_cot_' + tag]).to(cdt).cuda().conj()).real.sum().backward()
+        assert relmax(vis.grad, g['u_gvis_' + tag]) < 10 * tol, tag
+        assert relmax(gains.grad, g['u_ggains_' + tag]) < 100 * tol, tag
+    dv, dgn = torch.as_tensor(g['dly_vis']).to(rdt).cuda(), torch.as_tensor(g['dly_gains']).to(rdt).cuda()
+    for undo in (False, True):
+        out, _ = calibration._apply_cal(dv, dgn, g['g1_idx'], g['g2_idx'], vis_type='dly', undo=undo)
+        assert relmax(out, g['dly_vout_undo%d' % undo]) < tol
+    # 4-pol undo: the proper 2 x 2 inverse (the reference's torch.pinv branch cannot run): undo(apply(V)) == V
+    v4 = cplx(2, 2, len(bls), Nt, Nf).to(cdt).cuda()
+    g4 = (cplx(2, 2, Nant, Nt, Nf) + 2 * torch.eye(2)[:, :, None, None, None]).to(cdt).cuda()
+    fwd, _ = calibration.apply_cal(v4, blnames, g4, ants)
+    back, _ = calibration.apply_cal(fwd, blnames, g4, ants, undo=True)
+    assert relmax(back, v4) < (1e-10 if dtype == 'f64' else 1e-3)
 
 
 def test_eq2top_kernel_matches_float64_host_chain(ops):
