@@ -694,9 +694,14 @@ extern "C" size_t rime_fringe_sum_workspace(int dtype, int Nbl, int Nt, int Nf, 
         Plan pl = plan_fwd(Nbl, Nt, Nf, Pstride, CH);
         return pl.S <= 1 ? 0 : (size_t)pl.S * Npp * Nbl * Nt * Nf * 2 * tsz;
     }
+    // every beam-model-pair group plans its own baseline splits (plan_bwd(bl_cnt)): the split count is not
+    // monotone in the group size (it is rounded to whole tiles per split), but never exceeds the un-rounded
+    // pick for the largest possible group -- that bound sizes the workspace
     const int PIX = 1;
-    int S = 1;
-    for (int n : {1, Nbl}) { Plan pl = plan_bwd(n, Nt, Nf, Pstride, CH, PIX); if (pl.S > S) S = pl.S; }
+    const int block = Pstride >= 256 * PIX ? 256 : (((Pstride + PIX - 1) / PIX + 63) / 64) * 64;
+    const long nblk = (Pstride + block * PIX - 1) / (block * PIX);
+    const long waves = nblk * (block / 64) * (long)((Nf + CH - 1) / CH) * Nt;
+    const int S = pick_splits(waves, (Nbl + TB - 1) / TB);
     return S <= 1 ? 0 : (size_t)S * Nt * Npp * Nf * Pstride * (psky_complex ? 2 : 1) * tsz;
 }
 

@@ -811,3 +811,21 @@ def test_fringe_sum_any_number_of_planes(ops, Npp, cplx, dtype):
     if not cplx:
         adj = ops.fringe_adjoint(gv.to(cdt).cuda(), geom)
         assert relmax(adj[..., :130], ref_in.grad) < tg
+
+
+@pytest.mark.parametrize('Nbl,Nmp,P', [(339, 4, 1), (730, 4, 64), (500, 3, 200), (97, 5, 30)])
+def test_fringe_sum_baseline_formulation_model_pair_groups_workspace(ops, Nbl, Nmp, P):
+    """every beam-model-pair group of the vector-ALU backward plans its own baseline splits; the workspace bound
+    must cover the group with the most splits (a random cross-check found RIME_EWORKSPACE here)"""
+    blvecs, freqs, zenaz, psky, bl_mp = make_case(Nbl, Nbl=Nbl, Nt=1, Nf=28, P=P, Nmp=Nmp, Npp=4, cplx=False)
+    geom, Ps = to_gpu_geometry(ops, blvecs, freqs, zenaz, bl_mp, Nmp)
+    ref_in = psky.clone().requires_grad_(True)
+    ref = oracle_fringe_sum(ref_in, blvecs, zenaz, freqs, bl_mp)
+    gv = torch.as_tensor(np.random.default_rng(5).normal(size=tuple(ref.shape))
+                         + 1j * np.random.default_rng(6).normal(size=tuple(ref.shape)))
+    (ref * gv.conj()).real.sum().backward()
+    x = pad_psky(psky, Ps).float().cuda().requires_grad_(True)
+    vis = ops.fringe_sum(x, geom)
+    assert relmax(vis, ref) < 1e-5
+    (vis * gv.to(torch.complex64).cuda().conj()).real.sum().backward()
+    assert relmax(x.grad[..., :P], ref_in.grad) < 1e-4

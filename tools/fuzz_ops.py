@@ -1,6 +1,7 @@
 """Randomised cross-checks of the GPU ops against each other (development tool): the antenna-factored
 (matrix-core) fringe kernels vs the baseline-formulation kernels, forward and backward, over random
-antenna counts, pair subsets, polarisation layouts, channel / time / pixel counts."""
+antenna counts, pair subsets and orientations, polarisation layouts, channel / time / pixel counts, numbers of
+beam models (blocks per model pair) and block group sizes (128 / 64 / 32: every kernel shape)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -32,10 +33,21 @@ for trial in range(ntrial):
     uniform = rng.random() < 0.7
     freqs = torch.as_tensor(np.linspace(110e6, 190e6, Nf) if uniform else np.sort(rng.uniform(100e6, 200e6, Nf)))
     conj = bool(rng.random() < 0.5)
-    gm = ops.FringeGeometry(blv, sdir.cuda(), freqs, conj=conj, antpos=torch.as_tensor(ant).cuda(), bl_ants=pairs, mfma=True)
-    gv = ops.FringeGeometry(blv, sdir.cuda(), freqs, conj=conj, mfma=False)
+    orient = rng.choice(['mixed', 'up', 'down'])
+    if orient != 'mixed':
+        pairs = [(min(p), max(p)) if orient == 'up' else (max(p), min(p)) for p in pairs]
+        blv = torch.as_tensor(np.stack([ant[b] - ant[a] for a, b in pairs])).cuda()
+    Nmod = int(rng.choice([1, 1, 2, 3]))
+    model = [int(rng.integers(0, Nmod)) for _ in range(Nant)]
+    uniq = sorted({(model[a], model[b]) for a, b in pairs})
+    bl_mp = [uniq.index((model[a], model[b])) for a, b in pairs]
+    Nmp = len(uniq)
+    group = int(rng.choice([128, 128, 64, 32]))
+    gm = ops.FringeGeometry(blv, sdir.cuda(), freqs, conj=conj, antpos=torch.as_tensor(ant).cuda(), bl_ants=pairs, mfma=True,
+                            bl_mp=bl_mp, Nmp=Nmp, mp_pairs=uniq, group=group)
+    gv = ops.FringeGeometry(blv, sdir.cuda(), freqs, conj=conj, mfma=False, bl_mp=bl_mp, Nmp=Nmp)
     assert gm.ant is not None, 'antenna path refused: Nant %d' % Nant
-    x = rng.normal(size=(Nt, 1, Npp, Nf, Ps)) * np.exp(-8 * rng.uniform(size=(Nt, 1, Npp, Nf, Ps)))
+    x = rng.normal(size=(Nt, Nmp, Npp, Nf, Ps)) * np.exp(-8 * rng.uniform(size=(Nt, Nmp, Npp, Nf, Ps)))
     if cplx:
         x = x + 1j * rng.normal(size=x.shape) * np.exp(-8 * rng.uniform(size=x.shape))
     x[..., P:] = 0
@@ -51,6 +63,6 @@ for trial in range(ntrial):
     eg = float((res[0][1] - res[1][1]).abs().max() / res[1][1].abs().max().clamp_min(1e-30))
     worst = [max(worst[0], ev), max(worst[1], eg)]
     flag = '' if (ev < 1e-5 and eg < 1e-4) else '   <-- FAIL'
-    print('trial %2d: Nant %3d Nbl %5d Nt %d Nf %2d P %4d Npp %d cplx %d conj %d uniform %d  vis %.1e grad %.1e%s' % (
-        trial, Nant, len(pairs), Nt, Nf, P, Npp, cplx, conj, uniform, ev, eg, flag))
+    print('trial %3d: Nant %3d Nbl %5d Nt %d Nf %2d P %4d Npp %d cplx %d conj %d uniform %d orient %-5s models %d (%d pairs) group %3d blocks %3d  vis %.1e grad %.1e%s' % (
+        trial, Nant, len(pairs), Nt, Nf, P, Npp, cplx, conj, uniform, orient, Nmod, Nmp, group, len(gm.ant['blocks']), ev, eg, flag), flush=True)
 print('worst: vis %.2e grad %.2e' % tuple(worst))
