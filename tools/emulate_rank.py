@@ -2,7 +2,7 @@
 (those are measured by the driver's multi-GPU runs): the slowest rank's shard of
   freq : contiguous channel blocks (rank 0's block; all blocks are equal)
   bl   : baseline-tile shards (dist.plan_tile_shards): the rank with the largest planned load
-python tools/emulate_rank.py [workload] [nt]"""
+python tools/emulate_rank.py [workload] [nt] [nf]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +12,9 @@ from bayeslim_amd import dist as rdist
 
 wl = sys.argv[1] if len(sys.argv) > 1 else 'c4'
 cfg = bench.WORKLOADS[wl]
+if len(sys.argv) > 3:                                   # third argument: number of channels (e.g. c5 with 32 of its 512)
+    cfg = dict(cfg, Nf=int(sys.argv[3]))
+    bench.WORKLOADS[wl] = cfg
 nt = int(sys.argv[2]) if len(sys.argv) > 2 else cfg['nt']
 dev = torch.device('cuda', 0)
 inp = bench.build_inputs(wl, nt)

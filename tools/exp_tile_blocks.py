@@ -1,5 +1,9 @@
+"""Experiment (development tool): per-step time of small block sets of the C4 pair matrix on one GPU -- two one-tile
+diagonal blocks vs one 64-antenna diagonal block vs one cross tile -- the numbers behind the remark in DESIGN.md section 6
+that a launch costs mostly the generation of its antenna rows (two diagonal tiles 34.6 ms, the 64-antenna diagonal block
+WITH its cross tile 34.3 ms, one cross tile 26.9 ms at 8 times x 256 channels).  python tools/exp_tile_blocks.py"""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from bayeslim_amd import dist as rdist
