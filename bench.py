@@ -126,7 +126,7 @@ def build_inputs(wl, nt, seed=0):
     return inp
 
 
-def build_model(inp, dev, bls, seed=0, fblock=None, nchunks=1):
+def build_model(inp, dev, bls, seed=0, fblock=None, nchunks=1, redundant=False):
     """
     The drop-in modules on the GPU for this rank's shard: the baseline list `bls` and, when
     `fblock = (f0, f1)` is given, the channel block [f0, f1).  Parameters are created FULL-SIZE
@@ -142,7 +142,7 @@ def build_model(inp, dev, bls, seed=0, fblock=None, nchunks=1):
     freqs_full = torch.as_tensor(inp['freqs'], dtype=f32, device=dev)
     freqs = freqs_full[f0:f1]
     arr = telescope_model.ArrayModel(utils.AntposDict(inp['ants'], torch.as_tensor(inp['antvecs'])),
-                                     freqs=freqs, device=dev, skip_reds=True)
+                                     freqs=freqs, device=dev, skip_reds=not redundant)
     tel = telescope_model.TelescopeModel((LON, LAT))
     gen = torch.Generator(device='cpu').manual_seed(seed)
     Npix = len(inp['ra'])
@@ -219,8 +219,15 @@ def build_model(inp, dev, bls, seed=0, fblock=None, nchunks=1):
     # geometry frequencies stay float64: an exactly uniform grid lets the fringe kernel use its
     # rotation recurrence (float32-rounded channel centres are not uniform to better than ~8 Hz)
     times = inp['times'] if nchunks == 1 else [np.asarray(t) for t in np.array_split(inp['times'], nchunks)]
+    data_bls = None
+    if redundant:
+        # --redundant: simulate ONE baseline per redundant group and inflate to all requested baselines
+        # (RIME's data_bls, rime_model.py:148-226, 436-437): the same visibilities, listed by redundant group
+        want = set(bls)
+        data_bls = [b for b in arr.get_bls(uniq_bls=False, keep_autos=False) if b in want]
+        bls = [b for b in arr.get_bls(uniq_bls=True, keep_autos=False) if arr.bl2red[b] in {arr.bl2red[d] for d in data_bls}]
     rime = rime_model.RIME(sky, tel, beam, arr, bls, times,
-                           torch.as_tensor(inp['freqs'][f0:f1], dtype=torch.float64, device=dev))
+                           torch.as_tensor(inp['freqs'][f0:f1], dtype=torch.float64, device=dev), data_bls=data_bls)
 
     def attach():
         """(re-)attach this rank's views of the replicated leaf parameters (new graph each step)"""
@@ -331,6 +338,9 @@ def main():
     ap.add_argument('--nt', type=int, default=None, help='time steps per step (minibatch)')
     ap.add_argument('--nf', type=int, default=None, help='override the number of channels (e.g. one rank\'s share of c5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--redundant', action='store_true',
+                    help='NOT the headline configuration: simulate one baseline per redundant group and inflate to all '
+                         'baselines (the reference\'s data_bls mechanism); N = 1 only')
     ap.add_argument('--shard', default='auto', choices=['auto', 'freq', 'bl'],
                     help='multi-GPU partition: channel blocks or baseline (tile) blocks; auto measures both and '
                          'reports the faster one as `value`, the other under `alt`')
@@ -407,7 +417,11 @@ def main():
                 bb = rdist.shard_bounds(len(bls), world)
                 my_bls, counts, inverse = bls[bb[rank][0]:bb[rank][1]], [e - s for s, e in bb], None
                 label = 'baseline-sharded x%d' % world
-        rime, params, attach, per_channel = build_model(inp, dev, my_bls, fblock=fblock, nchunks=nchunks)
+        rime, params, attach, per_channel = build_model(inp, dev, my_bls, fblock=fblock, nchunks=nchunks,
+                                                        redundant=args.redundant and not distributed)
+        if args.redundant and not distributed:
+            label += '; %d of %d baselines simulated (one per redundant group), inflated through data_bls' % (
+                rime.Nsim_bls, len(my_bls))
         if plan is not None:
             rime.mfma_group, rime.mfma_mode = plan['group'], True
         gsync = None
