@@ -266,9 +266,11 @@ def all_gather_block_grads(param, dim, bounds, group=None, async_op=False):
     g = param.grad
     if _block_gather_inplace_ok(g, dim, bounds):
         # equal blocks that are contiguous runs of the gradient in rank order: in-place all-gather
+        # (the send block is a copy: an input that aliases the output is legal for RCCL but made a 4-rank gloo
+        # rehearsal on a shared GPU crawl; 1/world of the gradient is cheap to copy)
         flat = g.view(-1)
         n = flat.numel() // world
-        return dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n], group=group, async_op=async_op)
+        return dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n].clone(), group=group, async_op=async_op)
     blk = param.grad.narrow(dim, s, e - s)
     if e - s < nmax:
         padshape = list(blk.shape)
@@ -401,7 +403,7 @@ def reduce_scalar(x, group=None):
     return y
 
 
-def pipelined_step(forward_chunk, nchunks, loss_fn, gather_start, grad_sync=None):
+def pipelined_step(forward_chunk, nchunks, loss_fn, gather_start, grad_sync=None, trace=None):
     """
     One forward + backward over `nchunks` time chunks with the collectives overlapped:
         chunk k:  vis_k = forward_chunk(k)                 kernels enqueued
@@ -410,21 +412,28 @@ def pipelined_step(forward_chunk, nchunks, loss_fn, gather_start, grad_sync=None
     and the gradient collectives of `grad_sync` (a GradSync) start inside the LAST chunk's backward.
     loss_fn(full_vis_k, k) -> scalar.  Returns the summed loss (detached).  Gradients accumulate in
     .grad over the chunks (the loss must be a sum over chunks, as chi^2 / sum |V|^2 are).
+    trace: optional callable(str) called at the stage boundaries (debugging aid; it may synchronise).
     """
     total = None
 
     def finish(pending, k, last):
         nonlocal total
         full = pending.wait()
+        if trace:
+            trace('chunk %d: gathered' % k)
         loss = loss_fn(full, k)
         if last and grad_sync is not None:
             grad_sync.arm()
         loss.backward()
+        if trace:
+            trace('chunk %d: backward done' % k)
         total = loss.detach() if total is None else total + loss.detach()
 
     pending = None
     for k in range(nchunks):
         vis = forward_chunk(k)
+        if trace:
+            trace('chunk %d: forward done' % k)
         nxt = gather_start(vis)
         if pending is not None:
             finish(pending, k - 1, False)
@@ -432,6 +441,8 @@ def pipelined_step(forward_chunk, nchunks, loss_fn, gather_start, grad_sync=None
     finish(pending, nchunks - 1, True)
     if grad_sync is not None:
         grad_sync.finish()
+        if trace:
+            trace('gradient collectives finished')
     return total
 
 

@@ -350,6 +350,7 @@ def main():
 
     # stdout carries exactly ONE JSON line: libraries that chat on fd 1 (RCCL's version banner, gloo's
     # connection notes) are sent to stderr for the whole run, the result goes to the saved descriptor
+    t_start = time.perf_counter()
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
@@ -373,6 +374,12 @@ def main():
     assert world == args.gpus or world == 1, 'launch N ranks with torch.distributed.run for --gpus N'
 
     from bayeslim_amd import ops, dist as rdist
+
+    def dbg(msg):
+        if os.environ.get('BENCH_DEBUG'):
+            sys.stderr.write('[bench rank %d %.1fs] %s\n' % (rank, time.perf_counter() - t_start, msg))
+            sys.stderr.flush()
+
     cfg = WORKLOADS[args.workload]
     if args.nf:
         cfg = dict(cfg, Nf=args.nf, desc=cfg['desc'] + ' [%d channels]' % args.nf)
@@ -457,11 +464,19 @@ def main():
             def gather_start(v):
                 return rdist.all_gather_vis_start(v, counts, dim=gdim, inverse=inverse)     # RCCL, async, differentiable
 
-            return rdist.pipelined_step(forward_chunk, nchunks, loss_fn, gather_start, gsync)
+            trace = None
+            if os.environ.get('BENCH_DEBUG') == '2':
+                def trace(msg):
+                    torch.cuda.synchronize()
+                    dbg(msg)
+            return rdist.pipelined_step(forward_chunk, nchunks, loss_fn, gather_start, gsync, trace=trace)
 
-        for _ in range(args.warmup):
+        dbg('mode %s: model built (%d baselines, %s), %d chunk(s)' % (shard, len(my_bls), label, nchunks))
+        for k in range(args.warmup):
             step()
+            dbg('mode %s: warm-up step %d enqueued' % (shard, k))
         sync()
+        dbg('mode %s: warm-up done' % shard)
         prof.clear()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -473,6 +488,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         ops.PROFILE = None
+        dbg('mode %s: timed steps done, %.1f ms/step' % (shard, dt / args.steps * 1e3))
         if gsync is not None:
             gsync.remove()
         grad_bytes = sum(p.numel() * p.element_size() for p in params)
