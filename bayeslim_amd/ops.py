@@ -476,9 +476,29 @@ def _fringe_call_planes(geom, backward, psky_like, vis_like, cplx):
             _fringe_call(geom, False, pr, vr, n, cplx, _dense_strides(p))
 
 
+def _blvec_grad(geom, p, g, cplx):
+    """
+    d loss / d blvecs [Nbl, 3] of the fringe sum: d vis / d b_k = sum_p psky (sign 2 pi i nu / c) s_k F, i.e. the
+    FORWARD kernels on the three direction-cosine-weighted copies of psky (telescope_model.py:350-356 is
+    differentiable w.r.t. blvecs through torch autograd; here it costs three more forward passes and is only
+    computed when the baseline vectors require a gradient).  p: psky (Nt, Nmp, Npp, Nf, Ps); g: gvis (Npp, Nbl, Nt, Nf).
+    """
+    Nt, Nmp, Npp, Nf, Ps = p.shape
+    rdt = torch.float32 if p.dtype in (torch.float32, torch.complex64) else torch.float64
+    s3 = geom.sdir.to(rdt)                                                   # (Nt, 3, Ps)
+    pw = (p[:, :, :, None] * s3[:, None, None, :, None, :]).reshape(Nt, Nmp, Npp * 3, Nf, Ps).contiguous()
+    w = torch.empty((Npp * 3, geom.Nbl, Nt, Nf), dtype=g.dtype, device=g.device)
+    _fringe_call_planes(geom, False, pw, w, cplx)
+    w = w.reshape(Npp, 3, geom.Nbl, Nt, Nf)
+    fac = (geom.sign * 2.0 * np.pi / 2.99792458e8) * geom.freqs                # (Nf,) float64
+    # Re( conj(g) * i fac * w ) = -fac * Im( conj(g) w )
+    t = (g.conj()[:, None] * w).imag.to(torch.float64) * (-fac)
+    return t.sum(dim=(0, 3, 4)).t().contiguous()                             # (Nbl, 3)
+
+
 class _FringeSum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, psky, geom):
+    def forward(ctx, psky, geom, blvecs=None):
         _require_cuda(psky)
         assert psky.dim() == 5, 'psky must be (Nt, Nmp, Npp, Nf, Pstride)'
         Nt, Nmp, Npp, Nf, Ps = psky.shape
@@ -497,22 +517,33 @@ class _FringeSum(torch.autograd.Function):
         _fringe_call_planes(geom, False, p, vis, cplx)
         ctx.geom, ctx.cplx, ctx.dtype = geom, cplx, psky.dtype
         ctx.pshape, ctx.pstride = tuple(p.shape), tuple(p.stride())   # gradient buffer template only
+        ctx.psky = p if (blvecs is not None and blvecs.requires_grad) else None     # kept only for the blvecs gradient
         return vis
 
     @staticmethod
     def backward(ctx, gvis):
         geom = ctx.geom
         g = gvis.contiguous()
-        gp = torch.empty_strided(ctx.pshape, ctx.pstride, dtype=ctx.dtype, device=g.device)
-        _fringe_call_planes(geom, True, gp, g, ctx.cplx)
-        return gp, None
+        gp = None
+        if ctx.needs_input_grad[0]:
+            gp = torch.empty_strided(ctx.pshape, ctx.pstride, dtype=ctx.dtype, device=g.device)
+            _fringe_call_planes(geom, True, gp, g, ctx.cplx)
+        gb = None
+        if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] and ctx.psky is not None:
+            gb = _blvec_grad(geom, ctx.psky, g, ctx.cplx)
+        return gp, None, gb
 
 
-def fringe_sum(psky, geom):
+def fringe_sum(psky, geom, blvecs=None):
     """
     psky (Nt, Nmp, Npp, Nf, Pstride) real or complex on the GPU; geom a FringeGeometry.
-    Returns vis (Npp, Nbl, Nt, Nf) complex.  Differentiable w.r.t. psky.
+    Returns vis (Npp, Nbl, Nt, Nf) complex.  Differentiable w.r.t. psky and, when `blvecs` -- the (Nbl, 3)
+    tensor the geometry was built from, still attached to its graph -- requires a gradient, w.r.t. the baseline
+    vectors (hence antenna positions): three extra forward passes in the backward.
     """
+    if blvecs is not None and blvecs.requires_grad:
+        assert tuple(blvecs.shape) == (geom.Nbl, 3)
+        return _FringeSum.apply(psky, geom, blvecs)
     return _FringeSum.apply(psky, geom)
 
 

@@ -153,6 +153,14 @@ class RIME(utils.Module):
             self.Ntimes = len(self.sim_times)
 
     # -- forward ---------------------------------------------------------------------------
+    def _current_blvecs(self):
+        """baseline vectors of the current group; re-derived from the antenna positions when those carry a
+        gradient (the reference derives them once at setup, rime_model.py:193, so its graph to antvecs survives a
+        single backward only), else the tensor cached at setup"""
+        if getattr(self.array.antvecs, 'requires_grad', False):
+            return self.array.get_blvecs(self.sim_bls)
+        return self.sim_blvecs
+
     def _compute_device(self, sky):
         dev = sky.device
         if dev.type != 'cuda':
@@ -231,13 +239,17 @@ class RIME(utils.Module):
         bl_ants = [(idx[b[0]], idx[b[1]]) for b in self.sim_bls]
         # pair tables of the matrix-core path depend on the baseline group only: built once, shared by
         # the geometries of all time minibatches
-        like = self._ant_like.get(self.bl_group_id)
-        geom = ops.FringeGeometry(self.sim_blvecs.to(dev), sdir, self.freqs, bl_mp=bl_mp,
+        # (keyed on the antenna positions too: the blocks hold them)
+        lkey = (self.bl_group_id, av.data_ptr(), av._version)
+        like = self._ant_like.get(lkey)
+        geom = ops.FringeGeometry(self._current_blvecs().detach().to(dev), sdir, self.freqs, bl_mp=bl_mp,
                                   Nmp=len(pairs), npix=[c.numel() for c in cuts],
                                   antpos=self.array.antvecs, bl_ants=bl_ants, ant_like=like, mp_pairs=pairs,
                                   group=getattr(self, 'mfma_group', None), mfma=getattr(self, 'mfma_mode', 'auto'))
         if like is None:
-            self._ant_like[self.bl_group_id] = geom
+            for k in [k for k in self._ant_like if k[0] == self.bl_group_id]:      # tables of superseded positions
+                del self._ant_like[k]
+            self._ant_like[lkey] = geom
         # for the fused psky builder: int32 cut and its inverse per time step
         pos = torch.full((Nt, Npix), -1, dtype=torch.int32, device=dev)
         for j, cut in enumerate(cuts):
@@ -294,7 +306,8 @@ class RIME(utils.Module):
             n1, n2, Nmp, Nf = ps.shape[:4]
             # -> (Nt, Nmp, Npp, Nf, Ps) as a strided VIEW: the fringe kernels take the strides
             ps = ps.reshape(n1 * n2, Nmp, Nf, Nt, Ps).permute(3, 1, 0, 2, 4)
-            v = ops.fringe_sum(ps, bg['geom'])                       # (Npp, Nbl, Nt, Nf)
+            blv = self._current_blvecs()
+            v = ops.fringe_sum(ps, bg['geom'], blv.to(dev) if blv.requires_grad else None)   # (Npp, Nbl, Nt, Nf)
             v = v.reshape(n1, n2, v.shape[1], Nt, Nf)
             vis = v if vis is None else vis + v
 

@@ -829,3 +829,39 @@ def test_fringe_sum_baseline_formulation_model_pair_groups_workspace(ops, Nbl, N
     assert relmax(vis, ref) < 1e-5
     (vis * gv.to(torch.complex64).cuda().conj()).real.sum().backward()
     assert relmax(x.grad[..., :P], ref_in.grad) < 1e-4
+
+
+@pytest.mark.parametrize('mfma,dtype,cplx', [(False, torch.float64, False), (False, torch.float64, True), (True, torch.float32, False)])
+def test_fringe_sum_gradient_wrt_baseline_vectors(ops, mfma, dtype, cplx):
+    """d loss / d blvecs (the reference's gen_fringe is differentiable w.r.t. blvecs through autograd,
+    telescope_model.py:350-356): three direction-cosine-weighted forward passes, against the fp64 oracle --
+    through antenna positions on the matrix-core path"""
+    ant, pairs, blvecs, freqs, zenaz, _ = make_antenna_case(9, 40, Nt=2, Nf=5, P=300, frac=1.0, autos=0)
+    rng = np.random.default_rng(12)
+    Nt, _, P = zenaz.shape
+    psky = rng.normal(size=(Nt, 1, 2, 5, P))
+    if cplx:
+        psky = psky + 1j * rng.normal(size=psky.shape)
+    psky = torch.as_tensor(psky)
+    Ps = ops.pad_to_tile(P)
+    sdir = torch.zeros(Nt, 3, Ps, dtype=torch.float64)
+    for t in range(Nt):
+        sdir[t, :, :P] = orc.pointing_vectors(zenaz[t, 0], zenaz[t, 1])
+    # oracle: gradient w.r.t. antenna positions through blvecs = ant[j] - ant[i]
+    a64 = ant.clone().requires_grad_(True)
+    i1, i2 = torch.as_tensor([a for a, _ in pairs]), torch.as_tensor([b for _, b in pairs])
+    ref = oracle_fringe_sum(psky, a64[i2] - a64[i1], zenaz, freqs, [0] * len(pairs))
+    gv = torch.as_tensor(np.random.default_rng(5).normal(size=tuple(ref.shape))
+                         + 1j * np.random.default_rng(6).normal(size=tuple(ref.shape)))
+    (ref * gv.conj()).real.sum().backward()
+    cdt = torch.complex128 if dtype == torch.float64 else torch.complex64
+    ag = ant.cuda().requires_grad_(True)
+    blv = ag[i2.cuda()] - ag[i1.cuda()]
+    geom = ops.FringeGeometry(blv.detach(), sdir.cuda(), freqs, antpos=ant.cuda() if mfma else None,
+                              bl_ants=pairs if mfma else None, mfma=True if mfma else 'auto')
+    assert (geom.ant is not None) == mfma
+    x = pad_psky(psky, Ps).to(cdt if cplx else dtype).cuda()
+    vis = ops.fringe_sum(x, geom, blv)
+    (vis * gv.to(cdt).cuda().conj()).real.sum().backward()
+    tol = 1e-10 if dtype == torch.float64 else 2e-4
+    assert relmax(ag.grad, a64.grad) < tol
