@@ -40,6 +40,11 @@ SIGNATURES = {
     'rime_fringe_ant_bwd_block': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
                                        _i, _i, _vp, _vp, _sz, _vp]),
     'rime_gen_fringe': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rime_comm_unique_id': (_i, [_vp]),
+    'rime_comm_init': (_i, [ctypes.POINTER(ctypes.c_void_p), _i, _i, _vp]),
+    'rime_comm_destroy': (_i, [_vp]),
+    'rime_comm_allgather_vis': (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
+    'rime_comm_reduce_grads': (_i, [_vp, _i, _vp, _sz, _vp]),
     'rime_eq2top': (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _vp, _vp]),
     'rime_interp_gather_fwd': (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'rime_interp_scatter_bwd': (_i, [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -502,3 +502,69 @@ class ShardedRIME:
         if params is None:
             params = [p for p in self.rime.parameters()]
         all_reduce_grads(params, self.group)
+
+
+# ---------------------------------------------------------------------------------------------
+# the same two collectives behind the library's C ABI (include/rime_hip.h: rime_comm_*)
+# ---------------------------------------------------------------------------------------------
+class RcclComm:
+    """
+    An RCCL communicator owned through the C ABI (rime_comm_init), for hosts that do not want
+    torch.distributed on the data path: `allgather_vis` / `reduce_grads` enqueue ncclAllGather /
+    ncclAllReduce on the CURRENT torch stream with raw device pointers.  One rank creates the 128-byte
+    unique id (`RcclComm.unique_id()`), every rank passes it to the constructor; `from_group` does that
+    exchange over an existing torch.distributed group (any backend, e.g. gloo: control plane only).
+    """
+    def __init__(self, nranks, rank, unique_id):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        assert len(unique_id) == 128
+        self.nranks, self.rank = int(nranks), int(rank)
+        self._comm = ctypes.c_void_p()
+        buf = (ctypes.c_char * 128).from_buffer_copy(bytes(unique_id))
+        _lib.check(_lib.lib.rime_comm_init(ctypes.byref(self._comm), self.nranks, self.rank,
+                                           ctypes.cast(buf, ctypes.c_void_p)), 'rime_comm_init')
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+        from . import _lib
+        buf = (ctypes.c_char * 128)()
+        _lib.check(_lib.lib.rime_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), 'rime_comm_unique_id')
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_group(cls, group=None):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(world, rank, box[0])
+
+    def _stream(self):
+        return self._ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def allgather_vis(self, vis_local):
+        """equal blocks: returns a (nranks,) + vis_local.shape complex tensor, blocks in rank order"""
+        v = vis_local.detach().contiguous()
+        assert v.is_cuda and v.is_complex()
+        out = torch.empty((self.nranks,) + tuple(v.shape), dtype=v.dtype, device=v.device)
+        code = 0 if v.dtype == torch.complex64 else 1
+        self._lib.check(self._lib.lib.rime_comm_allgather_vis(self._comm, code, self._ct.c_void_p(v.data_ptr()),
+                                                             self._ct.c_void_p(out.data_ptr()), v.numel(), self._stream()),
+                        'rime_comm_allgather_vis')
+        return out
+
+    def reduce_grads(self, tensors):
+        """in-place sum over ranks of contiguous real or complex float32 / float64 tensors"""
+        for t in tensors:
+            assert t.is_cuda and t.is_contiguous()
+            r = torch.view_as_real(t) if t.is_complex() else t
+            code = 0 if r.dtype == torch.float32 else 1
+            self._lib.check(self._lib.lib.rime_comm_reduce_grads(self._comm, code, self._ct.c_void_p(r.data_ptr()), r.numel(),
+                                                                self._stream()), 'rime_comm_reduce_grads')
+
+    def close(self):
+        if self._comm:
+            self._lib.check(self._lib.lib.rime_comm_destroy(self._comm), 'rime_comm_destroy')
+            self._comm = self._ct.c_void_p()

@@ -290,6 +290,25 @@ int rime_apply_cal_bwd(int dtype, int NP, int diag, const void* vis, const void*
                        long long gst_a, long long gst_t, long long gst_f, void* gvis, void* d1, void* d2,
                        void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Collectives of the sharded RIME step over RCCL (the replacement of DistributedLogProb.closure's per-device
+ * Python loop, optim.py:1539-1566).  Thin wrappers: raw device pointers, the caller's stream, no allocation.
+ * RCCL is resolved at first use (the copy already loaded into the process wins); without it every call
+ * returns RIME_EUNSUPPORTED.  The shipped Python path drives the same RCCL operations through
+ * torch.distributed; these give a host without torch.distributed the same two operations.
+ *   rime_comm_unique_id : fills 128 bytes (ncclUniqueId) on ONE rank; the caller distributes them
+ *   rime_comm_init      : ncclCommInitRank on the current device -> opaque communicator
+ *   rime_comm_allgather_vis : every rank contributes `complex_per_rank` complex values (its block of the
+ *       visibility tensor, blocks of equal size); vis_all receives nranks blocks in rank order
+ *   rime_comm_reduce_grads  : in-place sum over ranks of `count` real values (gradients of replicated parameters)
+ * ------------------------------------------------------------------------------------- */
+int rime_comm_unique_id(void* id128);
+int rime_comm_init(void** comm_out, int nranks, int rank, const void* id128);
+int rime_comm_destroy(void* comm);
+int rime_comm_allgather_vis(void* comm, int dtype, const void* vis_local, void* vis_all,
+                            size_t complex_per_rank, void* stream);
+int rime_comm_reduce_grads(void* comm, int dtype, void* grads, size_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -865,3 +865,21 @@ def test_fringe_sum_gradient_wrt_baseline_vectors(ops, mfma, dtype, cplx):
     (vis * gv.to(cdt).cuda().conj()).real.sum().backward()
     tol = 1e-10 if dtype == torch.float64 else 2e-4
     assert relmax(ag.grad, a64.grad) < tol
+
+
+def test_rccl_wrappers_one_rank(ops):
+    """rime_comm_* (thin RCCL wrappers of the C ABI): a one-rank communicator on the test GPU -- the all-gather
+    returns the block, the all-reduce leaves the gradients, both stream-ordered with the surrounding torch work"""
+    from bayeslim_amd import dist as rdist
+    comm = rdist.RcclComm(1, 0, rdist.RcclComm.unique_id())
+    try:
+        v = torch.randn(3, 1000, 7, dtype=torch.complex64, device='cuda')
+        out = comm.allgather_vis(v * 2)
+        assert out.shape == (1, 3, 1000, 7) and torch.equal(out[0], v * 2)
+        g32, g64 = torch.randn(100000, device='cuda'), torch.randn(33, 5, dtype=torch.complex128, device='cuda')
+        a, b = g32.clone(), g64.clone()
+        comm.reduce_grads([g32, g64])
+        torch.cuda.synchronize()
+        assert torch.equal(g32, a) and torch.equal(g64, b)
+    finally:
+        comm.close()
