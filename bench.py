@@ -543,8 +543,21 @@ def main():
                     traffic = None
                 if traffic is not None:
                     break
+        # the chip holds ~1.75 GHz of its 2.4 GHz under this load (GRBM_GUI_ACTIVE / kernel time in the committed PMC
+        # summary): the same executed rate against the peak AT THAT CLOCK, as information only
+        clock = None
+        cpath = os.path.join(ROOT, 'profiles', 'r02', 'pmc_summary.json')
+        if mflops > 0 and args.workload == 'c4' and os.path.exists(cpath):
+            try:
+                pm = json.load(open(cpath))
+                clock = next((v.get('clock_GHz') for k, v in pm.items() if k.startswith(dom) and v.get('clock_GHz')), None)
+            except Exception:
+                clock = None
         roof = dict(bound=bound, kernel=dom, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
                     frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source, pipe=pipe,
+                    sustained_clock_GHz=None if clock is None else round(clock, 3),
+                    frac_of_peak_at_sustained_clock=None if clock is None else round(achieved / (peak * clock / 2.4), 4),
+                    sustained_clock_source=None if clock is None else 'profiles/r02/pmc_summary.json (separate PMC pass, not this run)',
                     useful_tflops=round(useful, 2),
                     useful_note='8 flop (one complex MAC) per antenna pair x pixel x channel x time; the fp32 vector / matrix '
                                 'peak that bounds an exact-f32 contraction is %.1f TFLOP/s' % FP32_PEAK_TFLOPS,
