@@ -4,8 +4,9 @@ Telescope / array models with the reference's API (telescope_model.py), for the 
 baseline vectors, redundancy bookkeeping, `gen_fringe`, :142-460).
 
 Differences that matter:
-  * eq2top: the reference calls astropy's ICRS->AltAz on a cache miss (:498-502).  astropy is
-    not available here; a miss is served by the built-in chain of `bayeslim_amd/astrometry.py`
+  * eq2top: the reference calls astropy's ICRS->AltAz on a cache miss (:498-502).  When astropy is
+    importable that is what runs here too (`_astropy_eq2top`); it is not available in the build image, where
+    a miss is served by the built-in chain of `bayeslim_amd/astrometry.py`
     (IAU 2006 precession + frame bias, truncated IAU 1980 nutation, GAST, annual + diurnal
     aberration; float64; per-direction work in the HIP kernel `rime_eq2top` for sky angles on the
     GPU) and announced ONCE with a warning that names what is not modelled (polar motion, UT1-UTC
@@ -58,6 +59,13 @@ class TelescopeModel:
         key = key if key is not None else self.hash(time, ra)
         if key in self.conv_cache:
             return self.conv_cache[key]
+        if getattr(self, 'use_astropy', True):
+            angs = _astropy_eq2top(self.location, float(time), ra, dec)
+            if angs is not None:                             # astropy present: exactly what the reference computes
+                angs = torch.as_tensor(np.stack(angs), device=self.device, dtype=self.dtype)
+                if store:
+                    self.conv_cache[key] = angs
+                return angs
         global _WARNED
         if not _WARNED:
             _WARNED = True
@@ -83,6 +91,25 @@ class TelescopeModel:
             self.device = device
             for k, v in self.conv_cache.items():
                 self.conv_cache[k] = v.to(device)
+
+
+def _astropy_eq2top(location, time, ra, dec):
+    """the reference's own transformation (telescope_model.py:469-502: ICRS -> AltAz of astropy, IERS tables and
+    all) when astropy is importable in the user's environment, else None.  Host-side setup work, cached by the caller;
+    the image this was built in has no astropy, so this branch is untested here and the astrometry chain serves a miss."""
+    try:
+        from astropy import units
+        from astropy.time import Time
+        from astropy.coordinates import EarthLocation, AltAz, ICRS
+    except Exception:
+        return None
+    loc = location
+    if not isinstance(loc, EarthLocation):
+        loc = EarthLocation(lon=location[0] * units.deg, lat=location[1] * units.deg,
+                            height=(location[2] if len(location) > 2 else 0.0) * units.m)
+    out = ICRS(ra=utils.tensor2numpy(ra) * units.deg, dec=utils.tensor2numpy(dec) * units.deg).transform_to(
+        AltAz(location=loc, obstime=Time(time, format='jd')))
+    return out.zen.deg, out.az.deg
 
 
 def JD2LST(jd, longitude):
