@@ -370,7 +370,10 @@ def main():
         backend = os.environ.get('BENCH_BACKEND', 'nccl')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group(backend, rank=rank, world_size=world)      # 'nccl' == RCCL on ROCm; device chosen above
+        import datetime
+        # 'nccl' == RCCL on ROCm; device chosen above.  A collective that does not complete within 10 minutes aborts the
+        # job instead of hanging it (the steps of every workload here take seconds)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
     assert world == args.gpus or world == 1, 'launch N ranks with torch.distributed.run for --gpus N'
 
     from bayeslim_amd import ops, dist as rdist
