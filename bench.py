@@ -373,7 +373,8 @@ def main():
         import datetime
         # 'nccl' == RCCL on ROCm; device chosen above.  A collective that does not complete within 10 minutes aborts the
         # job instead of hanging it (the steps of every workload here take seconds)
-        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
+        kw = dict(device_id=dev) if backend == 'nccl' else {}        # bind the communicator to this rank's GPU up front
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10), **kw)
     assert world == args.gpus or world == 1, 'launch N ranks with torch.distributed.run for --gpus N'
 
     from bayeslim_amd import ops, dist as rdist
