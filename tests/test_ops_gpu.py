@@ -377,9 +377,10 @@ def test_fringe_sum_matrix_core_complex_single_pass(ops, Nant, orient, Npp, conj
 
 def test_fringe_sum_full_size_properties(ops):
     """BASELINE config 4 at full size (128 antennas / 8128 baselines, 256 channels, 98 304 visible
-    pixels): size-independent properties instead of an oracle -- linearity, the adjoint identity
-    Re<V(x), G> == <x, V^T(G)> between the forward and backward kernels, and agreement of the
-    antenna-factored (matrix-core) and baseline-formulation (vector-ALU) kernels"""
+    pixels): size-independent properties -- linearity, the adjoint identity Re<V(x), G> == <x, V^T(G)>
+    between the forward and backward kernels, agreement of the antenna-factored (matrix-core) and
+    baseline-formulation (vector-ALU) kernels -- plus a sampled float64 oracle comparison of visibilities
+    and gradient entries at this size"""
     rng = np.random.default_rng(0)
     Nant, Nf, P = 128, 256, 98304
     ant = rng.normal(0, 80.0, (Nant, 3)); ant[:, 2] *= 0.02
@@ -412,6 +413,24 @@ def test_fringe_sum_full_size_properties(ops):
         (v * G.conj()).real.sum().backward()
         rhs = (x.grad.double() * x1.double()).sum()
         assert abs(float(lhs - rhs)) < 1e-4 * abs(float(lhs)) + 1e-6
+        gx = x.grad.detach()
+        # SAMPLED oracle comparison at full size: float64 sums evaluated for a few (baseline, channel) visibilities over
+        # all 98 304 pixels and a few (channel, pixel) gradient entries over all 8 128 baselines (torch float64 on the GPU:
+        # the defining formula telescope_model.py:350-356 + rime_model.py:429, not the kernels)
+        srng = np.random.default_rng(3)
+        bsel = torch.as_tensor(srng.choice(len(pairs), 24, replace=False), device='cuda')
+        fsel = torch.as_tensor(srng.choice(Nf, 5, replace=False), device='cuda')
+        tau = blvecs[bsel] @ sdir[0]                                                        # (24, P) metres
+        ph = 2j * np.pi / 2.99792458e8 * freqs.cuda()[fsel][None, :, None] * tau[:, None, :]
+        ref = (torch.exp(ph) * x1[0, 0, 0][fsel].double()[None]).sum(-1)                    # (24, 5)
+        got = v.detach()[0][bsel][:, 0][:, fsel]
+        assert float((got - ref).abs().max()) < 1e-5 * scale
+        psel = torch.as_tensor(srng.choice(P, 48, replace=False), device='cuda')
+        tau = blvecs @ sdir[0][:, psel]                                                     # (Nbl, 48)
+        ph = 2j * np.pi / 2.99792458e8 * freqs.cuda()[fsel][None, :, None] * tau[:, None, :]
+        gref = (torch.exp(ph).conj() * G[0][:, 0][:, fsel].to(torch.complex128)[:, :, None]).real.sum(0)    # (5, 48)
+        ggot = gx[0, 0, 0][fsel][:, psel]
+        assert float((ggot - gref).abs().max()) < 1e-4 * float(gx.abs().max())
 
 
 def test_fringe_sum_matrix_core_splits_and_degenerate_rows(ops):
