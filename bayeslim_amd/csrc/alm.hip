@@ -555,6 +555,178 @@ alm2pix_bwd_f16_kernel(const uint4* __restrict__ g_hi, const uint4* __restrict__
     }
 }
 
+// backward, LDS-DMA form (even Npix): the kernel above is bound by the Ylm bytes it keeps in flight (one 32-KB tile
+// per block in registers, two blocks per CU: 64 KB -> 2.8 TB/s).  Here the Ylm tile and the pre-split gout granules of a
+// chunk (KS K steps of 16 pixels) go from global memory straight into LDS (global_load_lds_dwordx4: no registers hold
+// bytes in flight) through a ring of NSLOT slots, ONE raw barrier per chunk and a counted s_waitcnt vmcnt that leaves
+// the NSLOT - 2 younger chunks in flight across it (MI355X guide, "Pipelining across barriers"), one 4-wave block per CU.
+// An LDS-DMA wave instruction deposits 64 x 16 B contiguously in lane order, so rows cannot be padded; the fragment
+// reads stay conflict-free through an XOR swizzle applied to the SOURCE address: the chunk's tile is 128 rows of
+// GR = 8 KS granules (two pixels each), granule s of row c lands at position s ^ (c & 15) (KS 2) or s ^ ((c >> 1) & 7)
+// (KS 1: two rows per 256 B of banks).  Rows / pixels beyond the
+// matrix read a 16-byte block of zeros.  Every wave issues the same number of DMA instructions per chunk (the counted
+// wait depends on it): a remainder is padded with loads of the zero block into a scratch KB.
+// The load is issued from inline asm: hipcc counts a builtin LDS-DMA as a pending LDS write and drains it (vmcnt(0))
+// before the next ds_read, which would serialise the ring; the kernel counts its own DMA queue.
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_wave_base) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wait until all but the `younger` most recent chunks (NPW instructions each) of this wave have landed
+template <int NPW, int MAXY> __device__ __forceinline__ void wait_chunks(int younger)
+{
+    if constexpr (MAXY == 0) wait_vmcnt<0>();
+    else {
+        if (younger >= MAXY) wait_vmcnt<NPW * MAXY>();
+        else wait_chunks<NPW, MAXY - 1>(younger);
+    }
+}
+
+template <int MT, int KS, int NSLOT> struct BwdDma {
+    static constexpr int ROWS = MT * 32;
+    static constexpr int GR = 8 * KS;                  // 16-byte granules (two pixels) per row of the chunk's Ylm tile
+    static constexpr int RP = 64 / GR;                 // tile rows per wave instruction (1 KB)
+    static constexpr int YB = 128 * GR * 16;           // the chunk's Ylm tile: 128 coefficients x KS x 16 px x (re, im) f32
+    static constexpr int GB = 2 * ROWS * 16;           // one K step of one gout image (hi or lo)
+    static constexpr int SLOT = YB + KS * 2 * GB;
+    static constexpr int NGW = GB / 1024;              // wave instructions per gout image and K step
+    static constexpr int TI = KS * (16 + 2 * NGW);     // wave instructions per chunk
+    static constexpr int NPW = (TI + 3) / 4;           // per wave
+    static constexpr int LDS = NSLOT * SLOT + 1024;    // + the scratch KB of the padding loads
+    static_assert(LDS <= 160 * 1024, "LDS ring too large");
+    static_assert(NPW * (NSLOT - 2) < 64, "vmcnt range");
+};
+
+template <int MT, int KS, int NSLOT>
+__global__ void __launch_bounds__(256, 1)
+alm2pix_bwd_f16_dma_kernel(const uint4* __restrict__ g_hi, const uint4* __restrict__ g_lo,
+                           const float* __restrict__ inv_scale, const float* __restrict__ Ylm,
+                           const float* __restrict__ zero16, float y_scale,
+                           int R, int Rpad, int Ncoeff, int Npix, int S, int CT, int RT, float* __restrict__ part)
+{
+    using C = BwdDma<MT, KS, NSLOT>;
+    constexpr int ROWS = C::ROWS, AHEAD = NSLOT - 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // Workgroups go to the 8 XCDs round-robin by linear id.  The blocks of one pixel split read the SAME gout chunks
+    // (and, over row tiles, the same Ylm tile): each XCD takes a contiguous range of the (split, coefficient tile,
+    // row tile) order, so the ~32 blocks an XCD holds at a time share a split and the gout stream is served by that
+    // XCD's L2 instead of crossing the fabric once per coefficient tile (it was half as many bytes as Ylm itself).
+    const int NB = S * CT * RT, per_xcd = (NB + 7) / 8;
+    const int q = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    if ((int)(blockIdx.x / 8) >= per_xcd || q >= NB) return;      // whole block, before any barrier
+    const int split = q / (CT * RT);
+    const int r0 = (q % RT) * ROWS;
+    const int cblk = ((q / RT) % CT) * 128;
+    const int cl = wave * 32 + (lane & 31);            // this lane's coefficient row of the tile
+    const int c = cblk + cl;
+    const int h = lane >> 5;
+    const int send = (Npix + 15) / 16;                 // K steps of 16 pixels
+    const int nchunk = (send + KS - 1) / KS;
+    const int niter = split < nchunk ? (nchunk - split + S - 1) / S : 0;      // chunks split, split + S, ...
+    f32x16 accr[MT], acci[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { accr[m][e] = 0.f; acci[m][e] = 0.f; }
+
+    auto issue = [&](int it, int slot) {
+        const int s0 = KS * (split + it * S);
+        const unsigned base = smem_addr + (unsigned)(slot * C::SLOT);
+#pragma unroll
+        for (int u = 0; u < C::NPW; ++u) {
+            const int t = wave + 4 * u;                // wave-uniform
+            if (t < 16 * KS) {                         // RP whole rows of the chunk's tile
+                const int cr = C::RP * t + lane / C::GR;
+                const int sg = (lane % C::GR) ^ ((cr >> (KS == 1 ? 1 : 0)) & (C::GR - 1));
+                const int cc = cblk + cr, j = 16 * s0 + 2 * sg;
+                const float* src = (cc < Ncoeff && j < Npix) ? Ylm + ((size_t)cc * Npix + j) * 2 : zero16;
+                glds16(src, base + t * 1024);
+            } else if (t < C::TI) {
+                const int tg = t - 16 * KS;
+                const int ks = tg / (2 * C::NGW), r = tg % (2 * C::NGW), img = r / C::NGW, k = r % C::NGW;
+                const int i = k * 64 + lane;
+                const int row = i % ROWS, hh = i / ROWS;
+                const int qq = (s0 + ks) * 2 + hh;
+                const uint4* g = img ? g_lo : g_hi;
+                const void* src = s0 + ks < send ? (const void*)&g[(size_t)qq * Rpad + r0 + row] : (const void*)zero16;
+                glds16(src, base + C::YB + (ks * 2 + img) * C::GB + k * 1024);
+            } else {
+                glds16(zero16, smem_addr + NSLOT * C::SLOT);
+            }
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        if (a < niter) issue(a, a);
+    const uint32_t ybase = (uint32_t)cl * (C::GR * 16u);
+    const uint32_t sw = (uint32_t)((cl >> (KS == 1 ? 1 : 0)) & (C::GR - 1));
+    int slot = 0, nslot = AHEAD;                       // slot being read; slot the next issue fills
+    for (int it = 0; it < niter; ++it) {
+        wait_chunks<C::NPW, AHEAD - 1>(niter - 1 - it);          // chunk `it` of this wave has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave's part has landed; everyone is done with chunk it - 1
+        if (it + AHEAD < niter) issue(it + AHEAD, nslot);        // into the slot chunk it - 1 occupied
+        const unsigned char* sl = smem + slot * C::SLOT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint4* lds_hi = reinterpret_cast<const uint4*>(sl + C::YB + ks * 2 * C::GB);
+            const uint4* lds_lo = reinterpret_cast<const uint4*>(sl + C::YB + (ks * 2 + 1) * C::GB);
+            float4 y[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                y[qd] = *reinterpret_cast<const float4*>(sl + ybase + ((((uint32_t)(8 * ks + 4 * h + qd)) ^ sw) * 16u));
+            uint4 rh, rl, ih, il;
+            split2h(y[0].x * y_scale, y[0].z * y_scale, rh.x, rl.x);
+            split2h(y[1].x * y_scale, y[1].z * y_scale, rh.y, rl.y);
+            split2h(y[2].x * y_scale, y[2].z * y_scale, rh.z, rl.z);
+            split2h(y[3].x * y_scale, y[3].z * y_scale, rh.w, rl.w);
+            split2h(y[0].y * y_scale, y[0].w * y_scale, ih.x, il.x);
+            split2h(y[1].y * y_scale, y[1].w * y_scale, ih.y, il.y);
+            split2h(y[2].y * y_scale, y[2].w * y_scale, ih.z, il.z);
+            split2h(y[3].y * y_scale, y[3].w * y_scale, ih.w, il.w);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int gi = h * ROWS + m * 32 + (lane & 31);
+                const uint4 ah = lds_hi[gi], al = lds_lo[gi];
+                accr[m] = ALM_MFMA(ah, rh, accr[m]);
+                acci[m] = ALM_MFMA(ah, ih, acci[m]);
+                accr[m] = ALM_MFMA(ah, rl, accr[m]);
+                acci[m] = ALM_MFMA(ah, il, acci[m]);
+                accr[m] = ALM_MFMA(al, rh, accr[m]);
+                acci[m] = ALM_MFMA(al, ih, acci[m]);
+            }
+        }
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        nslot = nslot + 1 == NSLOT ? 0 : nslot + 1;
+    }
+    if (c < Ncoeff) {
+        float* dst = part + (size_t)split * R * Ncoeff * 2;
+        const float iy = 1.0f / y_scale;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = r0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < R) {
+                    const float sc = inv_scale[row] * iy;
+                    *reinterpret_cast<float2*>(dst + ((size_t)row * Ncoeff + c) * 2) =
+                        make_float2(accr[m][e] * sc, -acci[m][e] * sc);
+                }
+            }
+    }
+}
+
 __global__ void alm_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t len, int S)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
@@ -605,6 +777,27 @@ static long bwd_resident_blocks(int MT)
     return cache[MT];
 }
 
+// LDS-DMA backward kernel: even pixel counts (16-byte aligned Ylm granules); RIME_ALM_BWD_DMA=0 selects the
+// register-staged kernel
+static bool bwd_use_dma(int Npix)
+{
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("RIME_ALM_BWD_DMA"); env = (e && e[0] == '0') ? 0 : 1; }
+    return env == 1 && Npix % 2 == 0;
+}
+
+// the LDS-DMA kernel's ring (3 slots of 32 KB Ylm + the gout granules) leaves room for one block per CU
+static long bwd_dma_resident_blocks()
+{
+    static long cache = 0;
+    if (cache == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        cache = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        (void)hipGetLastError();
+    }
+    return cache;
+}
+
 static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward)
 {
     SplitPlan p{};
@@ -618,15 +811,31 @@ static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward)
         // streams the same number of chunks, so 4.1 rounds cost 5 (C3: 66 tiles x 32 splits = 2112 blocks over
         // 512 resident ones; 31 splits = 2046 blocks = 4.0 rounds)
         const long blocks = (long)((Ncoeff + 127) / 128) * (p.Rpad / (p.MT * 32));
-        const long resident = bwd_resident_blocks(p.MT);
+        const long resident = bwd_use_dma(K) ? bwd_dma_resident_blocks() : bwd_resident_blocks(p.MT);
         long S = (2048 + blocks - 1) / blocks;                   // measured flat between 1024 and 4096 blocks
         const long maxS = std::max(1, p.nsteps / 32);          // >= 16 chunks of 2 K steps per block
         S = std::max<long>(1, std::min(S, maxS));
-        if (blocks * S > resident) {
+        if (bwd_use_dma(K)) {
+            // LDS-DMA kernel, one block per CU.  Cost of S splits in units of one chunk (2 K steps) of one block:
+            // rounds of the chip x (chunks per block + ~3 for the ring's ramp and the epilogue) + the partial plane
+            // each split writes and the reduce kernel reads back (R Ncoeff 16 B at ~4 TB/s against ~2.2 us per
+            // chunk).  Measured (C3 shape, 66 tiles): S 11 / 15 / 19 / 23 / 31 -> 1.09 / 1.08 / 1.10 / 1.17 / 1.21 ms,
+            // S 8 (2.06 rounds) 1.31 ms; 17 tiles x 196608 px: S 15 / 30 / 45 / 60 -> 1.12 / 1.16 / 1.17 / 1.25 ms.
+            const long nchunk = (p.nsteps + 1) / 2;
+            const double c1 = (double)R * Ncoeff * 1.8e-6;
+            double best = 1e300;
+            const long top = std::min<long>(maxS, 8 * resident / blocks + 1);
+            for (long s = 1; s <= std::max<long>(1, top); ++s) {
+                const long rounds = (blocks * s + resident - 1) / resident;
+                const double cost = (double)rounds * ((nchunk + s - 1) / s + 3) + c1 * s;
+                if (cost < best) { best = cost; S = s; }
+            }
+        } else if (blocks * S > resident) {
             const long rounds = std::max<long>(1, (blocks * S + resident / 2) / resident);    // nearest whole number of rounds
             const long S2 = (rounds * resident) / blocks;                                      // largest split count that fits them
             if (S2 >= 1 && S2 <= maxS) S = S2;
         }
+        if (const char* e = getenv("RIME_ALM_BWD_SPLITS")) { const long v = atol(e); if (v >= 1 && v <= maxS) S = v; }   // lab
         p.S = (int)S;
         p.steps_per_split = 0;                                   // chunks are dealt cyclically
     }
@@ -641,15 +850,35 @@ static void launch_split_rows(const float* X, int R, int L, const SplitPlan& p, 
     inv = (float*)((char*)workspace + 2 * p.img_bytes);
     unsigned int* rowmax = (unsigned int*)(inv + p.Rpad);
     const int nseg = (2 * p.nsteps * 8 + SPLIT_SEG - 1) / SPLIT_SEG;
-    (void)hipMemsetAsync(rowmax, 0, (size_t)p.Rpad * sizeof(unsigned int), st);
+    (void)hipMemsetAsync(rowmax, 0, (size_t)p.Rpad * sizeof(unsigned int) + 64, st);     // + the zero granule behind it
     hipLaunchKernelGGL(row_absmax_kernel, dim3(R, (L + SPLIT_SEG - 1) / SPLIT_SEG), dim3(256), 0, st, X, R, L, rowmax);
     hipLaunchKernelGGL(split_rows_kernel, dim3(p.Rpad, std::max(1, nseg)), dim3(256), 0, st, X, R, L, p.Rpad,
                        neg_odd, rowmax, hi, lo, inv);
 }
 
+template <int MT, int KS, int NSLOT>
+static hipError_t launch_bwd_dma(dim3 grid, hipStream_t st, const uint4* hi, const uint4* lo, const float* inv, const float* Y,
+                                 const float* zero16, float ys, int R, int Rpad, int Ncoeff, int Npix, int S, float* part)
+{
+    const int CT = (int)grid.y, RT = (int)grid.z;
+    const int NB = S * CT * RT;
+    grid = dim3(8 * ((NB + 7) / 8));
+    constexpr int LDS = BwdDma<MT, KS, NSLOT>::LDS;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&alm2pix_bwd_f16_dma_kernel<MT, KS, NSLOT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((alm2pix_bwd_f16_dma_kernel<MT, KS, NSLOT>), grid, dim3(256), LDS, st, hi, lo, inv, Y, zero16, ys, R, Rpad,
+                       Ncoeff, Npix, S, CT, RT, part);
+    return hipSuccess;
+}
+
 static size_t split_ws_bytes(const SplitPlan& p)
 {
-    return 2 * p.img_bytes + (size_t)p.Rpad * (sizeof(float) + sizeof(unsigned int));
+    return 2 * p.img_bytes + (size_t)p.Rpad * (sizeof(float) + sizeof(unsigned int)) + 64;    // 64: a zero granule
 }
 
 } // namespace rime
@@ -723,7 +952,16 @@ extern "C" int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, do
         dim3 grid(p.S, (Ncoeff + 127) / 128, p.Rpad / (p.MT * 32));
         const float ys = (float)y_scale;
         const float* Y = (const float*)Ylm;
-        if (p.MT == 4) hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<4>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.S, part);
+        if (bwd_use_dma(Npix)) {
+            const float* zero16 = (const float*)((char*)workspace + split_ws_bytes(p) - 64);
+            hipError_t e = hipSuccess;
+            // chunks of 2 K steps in a ring of 3 slots; 1 K step in 6 slots (more, smaller loads in flight) measured the same
+            if (p.MT == 4) e = launch_bwd_dma<4, 2, 3>(grid, st, hi, lo, inv, Y, zero16, ys, R, p.Rpad, Ncoeff, Npix, p.S, part);
+            else if (p.MT == 2) e = launch_bwd_dma<2, 2, 3>(grid, st, hi, lo, inv, Y, zero16, ys, R, p.Rpad, Ncoeff, Npix, p.S, part);
+            else e = launch_bwd_dma<1, 2, 3>(grid, st, hi, lo, inv, Y, zero16, ys, R, p.Rpad, Ncoeff, Npix, p.S, part);
+            if (e != hipSuccess) return RIME_ELAUNCH;
+        }
+        else if (p.MT == 4) hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<4>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.S, part);
         else if (p.MT == 2) hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<2>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.S, part);
         else hipLaunchKernelGGL((alm2pix_bwd_f16_kernel<1>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, p.S, part);
         if (p.S > 1) {

@@ -12,7 +12,7 @@ for trial in range(ntrial):
     rng = np.random.default_rng(trial)
     R = int(rng.choice([1, 3, 4, 31, 32, 33, 64, 65, 100, 128, 129, 200]))
     Nc = int(rng.choice([1, 5, 8, 31, 32, 33, 127, 128, 129, 500, 1000]))
-    Npix = int(rng.choice([1, 7, 31, 32, 33, 100, 1111, 4096, 5001]))
+    Npix = int(rng.choice([1, 2, 7, 30, 31, 32, 33, 34, 100, 1110, 1111, 4096, 5001, 5002]))
     amp = 10.0 ** rng.uniform(-6, 6)
     yamp = 10.0 ** rng.uniform(-4, 4)
     a = torch.as_tensor((rng.normal(size=(R, Nc)) + 1j * rng.normal(size=(R, Nc))) * amp * np.exp(-6 * rng.uniform(size=(R, 1))))

@@ -35,7 +35,7 @@ def main():
                     dur[k][did] = float(row['End_Timestamp']) - float(row['Start_Timestamp'])
     res = {}
     for k in per:
-        if not any(s in k for s in ('fringe', 'reduce_vis', 'transpose_gvis', 'interp', 'beam_sky', 'sky_gather', 'sky_grad')):
+        if not any(s in k for s in ('fringe', 'reduce_vis', 'transpose_gvis', 'interp', 'beam_sky', 'sky_gather', 'sky_grad', 'alm')):
             continue
         entry = {}
         for c, vals in per[k].items():
