@@ -341,54 +341,60 @@ def all_reduce_grads(params, group=None, average=False):
 class GradSync:
     """
     Gradient exchange started from autograd: when `arm()`ed, the post-accumulate hook of every
-    registered parameter launches that parameter's collective asynchronously the moment its gradient
-    is final, so the exchange overlaps the rest of the backward pass; `finish()` waits for all of them.
+    registered parameter marks its gradient final, and the parameter's collective is launched
+    asynchronously as soon as every parameter BEFORE it in the registration order has been launched, so the
+    exchange overlaps the rest of the backward pass; `finish()` waits for all of them.
       shared parameters (used by every rank)            -> in-place all-reduce (sum)
       block parameters  [(param, axis)] + `bounds`      -> in-place all-gather of the per-rank blocks
-    Un-armed backward passes (earlier time chunks of a pipelined step) only accumulate.
+    The registration order (shared, then blocks) is the order of the collectives on EVERY rank whatever order
+    the hooks fire in: RCCL matches collectives by issue order, and ranks of a baseline-tile partition run
+    graphs of different shapes.  Un-armed backward passes (earlier time chunks of a pipelined step) only
+    accumulate.
     """
     def __init__(self, shared=(), blocks=(), bounds=None, group=None):
         self.group, self.bounds = group, bounds
         self.shared = [p for p in shared if p is not None]
         self.blocks = list(blocks)
+        self.entries = [(p, None) for p in self.shared] + [(p, ax) for p, ax in self.blocks]
+        self.index = {id(p): i for i, (p, _) in enumerate(self.entries)}
         self.armed = False
-        self.pending, self.done = [], set()
-        self.hooks = []
-        for p in self.shared:
-            self.hooks.append(p.register_post_accumulate_grad_hook(self._hook_shared))
-        for p, ax in self.blocks:
-            self.hooks.append(p.register_post_accumulate_grad_hook(lambda q, ax=ax: self._hook_block(q, ax)))
+        self.pending, self.ready, self.next = [], set(), 0
+        self.fired = []                     # entry indices in the order the hooks fired in the last armed backward
+        self.hooks = [p.register_post_accumulate_grad_hook(self._hook) for p, _ in self.entries]
 
-    def _hook_shared(self, p):
-        if self.armed and id(p) not in self.done:
-            self.done.add(id(p))
+    def _launch(self, i):
+        p, ax = self.entries[i]
+        if ax is None:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
             self.pending.append(_reduce_one(p, self.group, False, 1, True))
-
-    def _hook_block(self, p, ax):
-        if self.armed and id(p) not in self.done:
-            self.done.add(id(p))
+        else:
             self.pending.append((all_gather_block_grads(p, ax, self.bounds, self.group, async_op=True), None))
 
+    def _drain(self, everything=False):
+        while self.next < len(self.entries) and (everything or self.next in self.ready):
+            self._launch(self.next)
+            self.next += 1
+
+    def _hook(self, p):
+        if self.armed:
+            self.ready.add(self.index[id(p)])
+            self.fired.append(self.index[id(p)])
+            self._drain()
+
     def arm(self):
-        self.armed, self.pending, self.done = True, [], set()
+        self.armed, self.pending, self.ready, self.next, self.fired = True, [], set(), 0, []
 
     def finish(self):
-        """wait for the collectives the hooks started; exchange whatever the backward never touched"""
+        """launch what the backward never reached (or touched out of order), wait for every collective"""
         self.armed = False
-        for p in self.shared:
-            if id(p) not in self.done:
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-                self.pending.append(_reduce_one(p, self.group, False, 1, True))
-        for p, ax in self.blocks:
-            if id(p) not in self.done:
-                self.pending.append((all_gather_block_grads(p, ax, self.bounds, self.group, async_op=True), None))
+        self._drain(everything=True)
         for work, fin in self.pending:
             if work is not None:
                 work.wait()
             if fin is not None:
                 fin()
-        self.pending, self.done = [], set()
+        self.pending, self.ready, self.next = [], set(), 0
 
     def remove(self):
         for h in self.hooks:

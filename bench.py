@@ -441,7 +441,8 @@ def main():
                 # per-channel parameters: every block is produced by exactly one rank -> all-gather of the
                 # blocks; parameters shared by all channels -> all-reduce
                 pc = {id(p) for p, _ in per_channel}
-                gsync = rdist.GradSync(shared=[p for p in params if id(p) not in pc], blocks=per_channel, bounds=bounds)
+                # registration order = collective order; the hooks fire point sources, beam, sky (dist.grad_hook_order)
+                gsync = rdist.GradSync(shared=[p for p in params if id(p) not in pc], blocks=per_channel[::-1], bounds=bounds)
             else:
                 gsync = rdist.GradSync(shared=params)
         prof = []
@@ -498,7 +499,8 @@ def main():
         grad_bytes = sum(p.numel() * p.element_size() for p in params)
         vis_bytes = len(bls) * nt * cfg['Nf'] * 8
         res = dict(shard=shard, label=label, dt=dt, prof=list(prof), vis_bytes=vis_bytes, grad_bytes=grad_bytes,
-                   plan_load=None if plan is None else [round(x, 1) for x in plan['load']])
+                   plan_load=None if plan is None else [round(x, 1) for x in plan['load']],
+                   hook_order=None if gsync is None else list(gsync.fired))
         del rime, params, attach
         torch.cuda.empty_cache()
         return res
@@ -598,6 +600,7 @@ def main():
                                all_gather_vis_bytes_per_step=best['vis_bytes'],
                                gradient_bytes_per_step=best['grad_bytes'],
                                tile_plan_load=best['plan_load'],
+                               grad_hook_order=best['hook_order'],     # registration indices in firing order (rank 0)
                                overlap='vis all-gather of chunk k runs under the kernels of chunk k+1; gradient '
                                        'collectives start from autograd hooks inside the last backward')
             alts = [r for r in results if r is not best]

@@ -257,6 +257,48 @@ def test_all_reduce_grads_writes_back_through_noncontiguous_grads():
         assert np.array_equal(b, eb) and np.array_equal(s_, es)
 
 
+def _worker_hook_order(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        a = torch.full((300, 400), 1.0, dtype=torch.float64, requires_grad=True)     # different sizes: a mismatched
+        b = torch.full((50,), 2.0, dtype=torch.float64, requires_grad=True)          # pair of all-reduces would fail
+        c = torch.zeros(4, 6, dtype=torch.float64, requires_grad=True)               # never touched by the loss
+        sync = rdist.GradSync(shared=[a, b, c])
+        # the two ranks build their graphs in opposite orders, so the post-accumulate hooks of a and b fire in
+        # opposite orders (autograd runs the most recently created branch first)
+        if rank == 0:
+            loss = (a * 3.0).sum() + (b * 5.0).sum()
+        else:
+            loss = (b * 5.0).sum() + (a * 3.0).sum()
+        sync.arm()
+        loss.backward()
+        fired = list(sync.fired)
+        sync.finish()
+        q.put((rank, fired, a.grad.numpy().copy(), b.grad.numpy().copy(), c.grad.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_sync_collective_order_is_rank_invariant():
+    """hooks that fire in different orders on different ranks must still issue the collectives in one order"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hook_order, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] != res[1][1], 'the test did not produce different hook orders: %r' % (res[0][1],)
+    for rank, fired, ga, gb, gc in res:
+        assert np.array_equal(ga, np.full((300, 400), 6.0)) and np.array_equal(gb, np.full((50,), 10.0))
+        assert np.array_equal(gc, np.zeros((4, 6)))
+
+
 def test_tile_shard_plan():
     """whole blocks of the antenna pair matrix per rank: a partition of the baselines, balanced cost,
     and the inverse permutation restores the original order"""
