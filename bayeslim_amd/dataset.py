@@ -1,9 +1,12 @@
 """
 Minimal data containers with the reference's attribute layout: what RIME.forward emits
 (`VisData`, dataset.py:289-411) and what sky models emit (`MapData`, dataset.py:1867-1936).
-Only the tensor layout and metadata fields are mirrored -- HDF5 IO, selection, averaging etc.
-are outside the hot path.
+The tensor layout, the metadata fields and the index selection (`get_inds` / `get_data` / `get_cov`, what
+imaging.VisMapper reads visibilities and weights through) are mirrored -- HDF5 IO, averaging etc. are outside
+the hot path.
 """
+import copy as _copy
+
 import numpy as np
 import torch
 
@@ -79,6 +82,149 @@ class VisData(TensorData):
         self.freqs = utils.push(self.freqs, device)
         if return_obj:
             return self
+
+    def copy(self, copydata=False, copymeta=False, detach=True):
+        """new VisData sharing (or cloning) the tensors; copymeta re-instantiates telescope / antpos / axes, which
+        drops the telescope's conversion cache (dataset.py:556-605)"""
+        vd = VisData()
+        telescope, antpos = self.telescope, self.antpos
+        times, freqs, blnums = self.times, self.freqs, self.blnums
+        flags, cov, icov, data = self.flags, self.cov, self.icov, self.data
+        if copydata and data is not None:
+            data = (data.detach() if (data.requires_grad and detach) else data).clone()
+        if copymeta:
+            if telescope is not None:
+                telescope = telescope.__class__(telescope.location, tloc=getattr(telescope, 'tloc', None),
+                                                device=telescope.device)
+            if antpos is not None:
+                antpos = antpos.__class__(_copy.deepcopy(antpos.ants), antpos.antvecs.clone())
+            times, freqs, blnums = _copy.deepcopy(times), _copy.deepcopy(freqs), _copy.deepcopy(blnums)
+            flags, cov, icov = [x.clone() if isinstance(x, torch.Tensor) else x for x in (flags, cov, icov)]
+        vd.setup_meta(telescope=telescope, antpos=antpos)
+        vd.setup_data(blnums, times, freqs, pol=self.pol, data=data, flags=flags, cov=cov, cov_axis=self.cov_axis,
+                      icov=icov, history=self.history)
+        return vd
+
+    # ---- selection (dataset.py:607-1042): one fancy-indexed axis at most, everything else slices
+    def _bl2ind(self, bl):
+        if isinstance(bl, (list, np.ndarray, torch.Tensor)):
+            if isinstance(bl, torch.Tensor):
+                bl = bl.cpu().numpy()
+            elif isinstance(bl, list):
+                bl = utils.ants2blnum(bl)
+            return [self._bl2ind(b) for b in bl]
+        if isinstance(bl, tuple):
+            bl = utils.ants2blnum(bl)
+        idx = np.where(self.blnums == bl)[0]
+        if len(idx) == 0:
+            raise ValueError("Couldn't find bl {}".format(bl))
+        return idx[0]
+
+    def _time2ind(self, time, atol=None):
+        if isinstance(time, (list, np.ndarray)) or (isinstance(time, torch.Tensor) and time.ndim == 1):
+            return np.concatenate([self._time2ind(t, atol) for t in time]).tolist()
+        atol = atol if atol is not None else self.atol          # rtol 1e-13: 0.03 s on a Julian date
+        return np.where(np.isclose(np.asarray(self.times.cpu()), float(time), atol=atol, rtol=1e-13))[0].tolist()
+
+    def _freq2ind(self, freq, atol=None):
+        if isinstance(freq, (list, np.ndarray)) or (isinstance(freq, torch.Tensor) and freq.ndim == 1):
+            return np.concatenate([self._freq2ind(f, atol) for f in freq]).tolist()
+        atol = atol if atol is not None else self.atol
+        return torch.where(torch.isclose(self.freqs, torch.as_tensor(freq, dtype=self.freqs.dtype,
+                                                                     device=self.freqs.device), atol=atol))[0].tolist()
+
+    def _pol2ind(self, pol, data=None):
+        if isinstance(pol, list):
+            assert len(pol) == 1
+            pol = pol[0]
+        assert isinstance(pol, str)
+        if self.pol is not None:
+            if pol.lower() != self.pol.lower():
+                raise ValueError("cannot index pol from 1pol {}".format(self.pol))
+            return (slice(0, 1), slice(0, 1))
+        if pol.lower() == 'ee':
+            return (slice(0, 1), slice(0, 1))
+        if pol.lower() == 'nn':
+            data = data if data is not None else self.data
+            return (slice(1, 2), slice(0, 1)) if tuple(data.shape[:2]) == (2, 1) else (slice(1, 2), slice(1, 2))
+        raise ValueError("only 'ee' / 'nn' can be indexed")
+
+    def get_inds(self, bl=None, times=None, freqs=None, pol=None, bl_inds=None, time_inds=None, freq_inds=None,
+                 data=None, atol=None):
+        """5 index objects (pol, pol, bl, time, freq) for a selection by value or by index (dataset.py:776-862)"""
+        data = data if data is not None else self.data
+        if bl is not None:
+            assert bl_inds is None
+            bl_inds = self._bl2ind(bl)
+        elif bl_inds is None:
+            bl_inds = slice(None)
+        if times is not None:
+            assert time_inds is None
+            time_inds = self._time2ind(times, atol=atol)
+        elif time_inds is None:
+            time_inds = slice(None)
+        if freqs is not None:
+            assert freq_inds is None
+            freq_inds = self._freq2ind(freqs, atol=atol)
+        elif freq_inds is None:
+            freq_inds = slice(None)
+        pol_inds = self._pol2ind(pol, data=data) if pol is not None else (slice(None), slice(None))
+        inds = tuple(utils._list2slice(i) for i in (pol_inds[0], pol_inds[1], bl_inds, time_inds, freq_inds))
+        assert sum(isinstance(i, slice) for i in inds) > 3, "cannot fancy index more than 1 axis"
+        return inds
+
+    def _take(self, x, squeeze, try_view, **sel):
+        if x is None:
+            return None
+        inds = self.get_inds(data=x, **sel)
+        x = x[inds]
+        if not try_view and all(isinstance(i, slice) for i in inds):
+            x = x.clone()
+        return x.squeeze() if squeeze else x
+
+    def get_data(self, bl=None, times=None, freqs=None, pol=None, bl_inds=None, time_inds=None, freq_inds=None,
+                 squeeze=True, data=None, try_view=False, **kwargs):
+        """slice of the data tensor (dataset.py:864-911)"""
+        return self._take(self.data if data is None else data, squeeze, try_view, bl=bl, times=times, freqs=freqs,
+                          pol=pol, bl_inds=bl_inds, time_inds=time_inds, freq_inds=freq_inds, **kwargs)
+
+    def get_flags(self, bl=None, times=None, freqs=None, pol=None, bl_inds=None, time_inds=None, freq_inds=None,
+                  squeeze=True, flags=None, try_view=False, **kwargs):
+        return self._take(self.flags if flags is None else flags, squeeze, try_view, bl=bl, times=times, freqs=freqs,
+                          pol=pol, bl_inds=bl_inds, time_inds=time_inds, freq_inds=freq_inds, **kwargs)
+
+    def get_cov(self, bl=None, times=None, freqs=None, pol=None, bl_inds=None, time_inds=None, freq_inds=None,
+                squeeze=True, cov=None, try_view=False, atol=None, **kwargs):
+        """slice of the covariance (dataset.py:954-1035): data-shaped (cov_axis None) or one covariance matrix
+        along the named axis"""
+        cov = self.cov if cov is None else cov
+        if cov is None:
+            return None
+        if self.cov_axis is None:
+            return self._take(cov, squeeze, try_view, bl=bl, times=times, freqs=freqs, pol=pol, bl_inds=bl_inds,
+                              time_inds=time_inds, freq_inds=freq_inds)
+        if self.cov_axis == 'full':
+            raise NotImplementedError
+        inds = self.get_inds(bl=bl, times=times, freqs=freqs, pol=pol, bl_inds=bl_inds, time_inds=time_inds,
+                             freq_inds=freq_inds, data=self.data)
+        axis = self.cov_axis
+        if bl is not None or bl_inds is not None:
+            cov = cov[..., inds[2]][..., inds[2]] if axis == 'bl' else cov[:, :, inds[2]]
+        elif times is not None or time_inds is not None:
+            cov = (cov[..., inds[3]][..., inds[3]] if axis == 'time' else
+                   (cov[:, :, inds[3]] if axis == 'bl' else cov[:, :, :, inds[3]]))
+        elif freqs is not None or freq_inds is not None:
+            cov = cov[..., inds[4]][..., inds[4]] if axis == 'freq' else cov[:, :, :, inds[4]]
+        elif pol is not None:
+            cov = cov[inds[0], inds[0]]
+        if squeeze:
+            cov = cov.squeeze()
+        if not try_view and all(isinstance(i, slice) for i in inds):
+            cov = cov.clone()
+        return cov
+
+    def get_icov(self, bl=None, icov=None, try_view=False, **kwargs):
+        return self.get_cov(bl=bl, cov=self.icov if icov is None else icov, try_view=try_view, **kwargs)
 
     def _inflate_by_redundancy(self, new_bls, red_bl_inds, try_view=False):
         """

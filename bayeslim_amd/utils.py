@@ -143,6 +143,34 @@ class SimpleIndex:
 # ---------------------------------------------------------------------------------------
 # baselines / antennas
 # ---------------------------------------------------------------------------------------
+def _list2slice(inds):
+    """an index list / tuple / tensor / range / int as a slice when it is an increasing arithmetic run, else
+    unchanged (utils.py:2108-2133)"""
+    if isinstance(inds, range) and inds.step > 0:
+        return slice(inds.start, inds.stop, inds.step)
+    if isinstance(inds, (int, np.integer)):
+        return slice(int(inds), int(inds) + 1)
+    if isinstance(inds, (list, tuple, torch.Tensor, np.ndarray)):
+        if len(inds) == 0:
+            return inds
+        if len(inds) == 1:
+            return slice(int(inds[0]), int(inds[0]) + 1, 1)
+        steps = set(np.diff(inds.cpu() if isinstance(inds, torch.Tensor) else inds).tolist())
+        if len(steps) == 1:
+            step = int(steps.pop())
+            if step > 0:
+                return slice(int(inds[0]), int(inds[-1]) + step, step)
+    return inds
+
+
+def _slice2tensor(obj, device=None):
+    """a slice as the integer tensor it selects (utils.py:2136-2144)"""
+    if isinstance(obj, slice):
+        obj = torch.arange(obj.start if obj.start is not None else 0, obj.stop,
+                           obj.step if obj.step is not None else 1, device=device)
+    return obj
+
+
 def blnum2ants(blnum, separate=False):
     """baseline integer(s) 1000*(a1+100)+(a2+100) -> antenna pair(s) (utils.py:2352)"""
     if isinstance(blnum, tuple):

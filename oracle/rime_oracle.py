@@ -400,6 +400,57 @@ def compute_Pm(A, w, m, D=None):
     return Pm if D is None else Pm * D
 
 
+def compute_P(A, w, contract=None):
+    """PSF matrix A^T w conj(A) of one time step: full (Nf, P, P), its diagonal or its row sums (imaging.py:818-861)"""
+    if contract is None:
+        return torch.einsum('vfp,vfq->fpq', A, w[..., None] * A.conj()).real
+    if contract == 'diag':
+        return (w[..., None] * A.abs().pow(2)).sum(0)
+    return torch.einsum('vfp,vf,vfq->fp', A, w.to(A.dtype).expand(A.shape[:2]), A.conj()).real
+
+
+def vismapper_make_map(blvecs, zenaz, freqs, vis, weights, beam_fn=None, fov=180.0, method='A2w', clip=1e-8,
+                       contract='diag'):
+    """
+    VisMapper.make_map (imaging.py:360-466): per time step t the cut (beam: zen < fov/2 through gen_beam; no beam:
+    zen <= fov/2, :268-283), A_t = conj(fringe) beam, dirty map and PSF contraction scattered into the full pixel
+    axis, summed over t and divided by the normalisation sum -- 'w': sum_b w, 'Aw': sum_b w |A|, 'A2w': sum_b w Re(A^2)
+    (:442-447: the real part of the SQUARE, not |A|^2 as compute_Pm / compute_P use at :619 / :694) -- clipped from below.
+    vis (..., Nbl, Nt, Nf) complex, weights (Nbl, Nt, Nf), zenaz (Nt, 2, Npix) deg, beam_fn(zen, az) -> (Nf, P).
+    Returns (maps (..., Nf, Npix), P, D).
+    """
+    Nt, Npix, Nf = zenaz.shape[0], zenaz.shape[-1], len(freqs)
+    maps = torch.zeros(vis.shape[:-3] + (Nf, Npix), dtype=weights.dtype)
+    Aw = torch.zeros(Nf, 1 if method == 'w' else Npix, dtype=weights.dtype)
+    P = None if contract == 'none' else torch.zeros((Nf, Npix) + ((Npix,) if contract is None else ()), dtype=weights.dtype)
+    for t in range(Nt):
+        zen, az = zenaz[t]
+        if beam_fn is not None:
+            cut = fov_cut(zen, fov)
+            beam = beam_fn(zen[cut], az[cut])
+        else:
+            cut, beam = torch.where(zen <= fov / 2)[0], None
+        A = build_A(blvecs, zen[cut], az[cut], freqs, beam)
+        w = weights[:, t]
+        maps[..., cut] += make_map(vis[..., t, :], w, A)
+        if P is not None:
+            if contract is None:
+                P[:, cut[:, None], cut[None, :]] += compute_P(A, w, None)
+            else:
+                P[:, cut] += compute_P(A, w, contract)
+        if method == 'w':
+            Aw += w.sum(0)[:, None]
+        elif method == 'Aw':
+            Aw[..., cut] += (w[:, :, None] * A.abs()).sum(0)
+        else:
+            Aw[..., cut] += (w[:, :, None] * A.pow(2).real).sum(0)
+    D = 1 / Aw.clip(clip)
+    maps = maps * D
+    if P is not None:
+        P = P * (D[:, :, None] if contract is None else D)
+    return maps, P, D
+
+
 def apply_cal(vis, gains, g1_idx, g2_idx, cal_2pol=False):
     """
     calibration._apply_cal for complex visibilities without undo / covariance

@@ -792,6 +792,75 @@ def gen_imaging(ba):
          Pm=imaging.compute_Pm(A, w, m, D=D))
 
 
+def gen_vismapper(ba):
+    """imaging.VisMapper (imaging.py:12-714) end to end: hex-37 (666 baselines), 5 channels, 3 times, 160 map pixels
+    of which part set below the horizon, an Airy PixelBeam, random visibilities and weights; dirty maps + PSF
+    contractions for the three normalisations, a channel / time / baseline sub-selection, compute_Am / compute_Pm /
+    compute_P.  The telescope conversion cache of the mapper's own (re-instantiated) telescope is filled with the
+    LST-rotation angles, as for the RIME fixtures."""
+    import importlib
+    imaging = importlib.import_module('bayeslim.imaging')
+    rng = np.random.default_rng(21)
+    freqs = torch.linspace(120e6, 160e6, 5)
+    times = np.array([2459861.0 + k * 40.0 / 1440 for k in range(3)])
+    arr = hex_array(ba, 4, freqs)
+    tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+    bls = arr.get_bls(uniq_bls=False, keep_autos=False)
+    Nbl, Npix = len(bls), 160
+    ra = lst_of(times[1]) + rng.uniform(-75, 75, Npix)
+    dec = LAT + rng.uniform(-70, 70, Npix)
+    beam, theta_grid, phi_grid = airy_pixbeam(ba, freqs, parameter=False)
+    data = torch.as_tensor(rng.normal(size=(1, 1, Nbl, 3, 5)) + 1j * rng.normal(size=(1, 1, Nbl, 3, 5)))
+    icov = torch.as_tensor(rng.uniform(0.2, 2.0, size=(1, 1, Nbl, 3, 5)))
+    vd = ba.dataset.VisData()
+    vd.setup_meta(tel, arr.to_antpos())
+    vd.setup_data(bls, torch.as_tensor(times), freqs, pol='ee', data=data, icov=icov)
+
+    def mapper(beam_obj, **sel):
+        vm = imaging.VisMapper(vd, ra, dec, beam=beam_obj, fov=180)
+        for t in times:
+            zen, az = radec_to_zenaz(ra, dec, lst_of(float(t)), LAT)
+            vm.telescope.conv_cache[(float(t), Npix)] = torch.stack([torch.as_tensor(zen), torch.as_tensor(az)])
+        return vm
+
+    zenaz = np.stack([np.stack(radec_to_zenaz(ra, dec, lst_of(float(t)), LAT)) for t in times])
+    out = dict(freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(arr.ants), bls=np.array(bls), ra=ra, dec=dec,
+               zenaz=zenaz, data=data, icov=icov, beam_params=beam.params.detach(), theta_grid=theta_grid, phi_grid=phi_grid)
+    vm = mapper(beam)
+    for method in ('A2w', 'Aw', 'w'):
+        vm.set_normalization(method)
+        maps, P = vm.make_map(return_P=True, contract='diag')
+        out['maps_' + method], out['Pdiag_' + method], out['D_' + method] = maps, P, vm.D
+    vm.set_normalization('A2w')
+    _, out['Prowsum'] = vm.make_map(return_P=True, contract='rowsum')
+    m_in = torch.as_tensor(rng.normal(size=(2, 5, Npix)))
+    out['m_in'] = m_in
+    out['Am'] = vm.compute_Am(m_in)
+    out['Pm'] = vm.compute_Pm(m_in)
+    out['P_cdiag'] = vm.compute_P(contract='diag')
+    # a list of two VisData imaged together
+    vd2 = vd.copy(copydata=True)
+    vd2.data = vd2.data * (0.5 - 0.25j)
+    out['maps_list'], _ = vm.make_map(vd=[vd, vd2], return_P=False)
+    # sub-selection: channels 1..3, times 0 and 2, every third baseline, no beam, fov 120, full PSF matrix on a
+    # 40-pixel map
+    sub = rng.choice(Npix, 40, replace=False); sub.sort()
+    vms = imaging.VisMapper(vd, ra[sub], dec[sub], beam=None, fov=120)
+    for t in times:
+        vms.telescope.conv_cache[(float(t), 40)] = torch.as_tensor(zenaz[list(times).index(t)][:, sub])
+    vms.set_freq_inds(freq_inds=[1, 2, 3])
+    vms.set_time_inds(time_inds=[0, 2])
+    vms.set_bl_inds(bl_inds=list(range(0, Nbl, 3)))
+    vms.set_normalization('A2w', icov=torch.ones_like(icov) * 0.7)
+    out['sub_pix'] = sub
+    out['sub_maps'], out['sub_Pfull'] = vms.make_map(return_P=True, contract=None)
+    out['sub_Am'] = vms.compute_Am(m_in[0][1:4][:, sub])
+    A0, cut0 = vm.build_A(times[0])
+    out['A0_checksum'] = torch.stack([A0.real.sum(), A0.imag.sum(), (A0.abs() ** 2).sum()])
+    out['cut0'] = cut0
+    save('vismapper', **out)
+
+
 def gen_apply_cal(ba):
     """gain application G_p V G_q^dagger of calibration._apply_cal (calibration.py:2412-2487), 'com'
     visibilities, 1-pol / 2-pol (diagonal) / 4-pol, with gradients w.r.t. visibilities and gains.
@@ -861,6 +930,7 @@ def main():
         return
     gen_chisq(ba)
     gen_imaging(ba)
+    gen_vismapper(ba)
     gen_apply_cal(ba)
     gen_fringe_cases(ba)
     gen_apply_beam_cases(ba)

@@ -444,3 +444,30 @@ def test_eq2top_device_matches_host():
         assert np.abs(za[0].numpy() - zen).max() < 1e-9
         daz = np.abs(za[1].numpy() - az)
         assert np.minimum(daz, 360 - daz).max() < 1e-8          # (wraps at 0 / 360)
+
+
+def test_visdata_selection_and_copy():
+    """VisData.get_inds / get_data / get_icov / copy (dataset.py:556-1042): what imaging.VisMapper reads through"""
+    from bayeslim_amd import dataset, utils
+    bls = [(0, 1), (0, 2), (1, 2), (1, 3)]
+    times, freqs = [2459861.0, 2459861.1, 2459861.2], [1.0e8, 1.1e8, 1.2e8, 1.3e8, 1.4e8]
+    data = torch.arange(60, dtype=torch.float64).reshape(1, 1, 4, 3, 5) * (1 + 1j)
+    vd = dataset.VisData()
+    vd.setup_data(bls, times, freqs, pol='ee', data=data, icov=data.real + 1)
+    assert utils._list2slice([1, 3, 5]) == slice(1, 7, 2) and utils._list2slice([3, 1]) == [3, 1]
+    assert utils._list2slice(2) == slice(2, 3) and utils._slice2tensor(slice(1, 4)).tolist() == [1, 2, 3]
+    assert vd.get_inds(bl=[(0, 2), (1, 3)])[2] == slice(1, 5, 2)
+    assert vd.get_inds(times=2459861.1)[3] == slice(1, 2, 1) and vd.get_inds(freqs=[1.1e8, 1.4e8])[4] == slice(1, 7, 3)
+    assert vd.get_inds(pol='ee')[:2] == (slice(0, 1), slice(0, 1))
+    with pytest.raises(ValueError):
+        vd.get_inds(bl=(2, 3))
+    with pytest.raises(AssertionError):
+        vd.get_inds(bl_inds=[0, 2, 3], time_inds=[0, 2, 1])                        # two fancy-indexed axes
+    assert torch.equal(vd.get_data(bl=(1, 2)), data[0, 0, 2])
+    assert torch.equal(vd.get_data(bl_inds=[3, 0], squeeze=False), data[:, :, [3, 0]])
+    assert torch.equal(vd.get_icov(time_inds=2, freq_inds=slice(1, 3), squeeze=False), (data.real + 1)[:, :, :, 2:3, 1:3])
+    view = vd.get_data(time_inds=slice(0, 1), squeeze=False, try_view=True)
+    assert view.data_ptr() == data.data_ptr() and vd.get_data(time_inds=slice(0, 1), squeeze=False).data_ptr() != data.data_ptr()
+    c = vd.copy(copydata=True, copymeta=True)
+    assert c.data.data_ptr() != data.data_ptr() and torch.equal(c.data, data) and c.bls == vd.bls and c.pol == 'ee'
+    assert vd.copy().data.data_ptr() == data.data_ptr()

@@ -361,6 +361,35 @@ def test_imaging_functions():
     assert np.abs(orc.compute_Pm(A, T('w'), T('m'), T('D')).numpy() - g['Pm']).max() < 1e-11 * np.abs(g['Pm']).max()
 
 
+def test_vismapper_time_loop():
+    """VisMapper.make_map over times / normalisations / PSF contractions against what the reference's container produced"""
+    g = load_golden('vismapper')
+    T = lambda k: torch.as_tensor(g[k])
+    idx = {a: i for i, a in enumerate(g['ants'].tolist())}
+    antv = T('antvecs')
+    blvecs = torch.stack([antv[idx[b]] - antv[idx[a]] for a, b in g['bls'].tolist()])
+    freqs, zenaz = T('freqs'), T('zenaz')
+    bmap = orc.pixel_response_forward(T('beam_params'), powerbeam=True)[0, 0, 0]           # (Nf, Npix_beam)
+
+    def beam_fn(zen, az):
+        inds, wgts = orc.rect_interp_weights(T('theta_grid'), T('phi_grid'), zen, az, 'linear')
+        return orc.interp(bmap, inds, wgts)
+
+    vis, w = T('data')[0, 0], T('icov')[0, 0]
+    close = lambda a, k: np.abs(a.numpy() - g[k]).max() < 1e-10 * np.abs(g[k]).max()
+    for method in ('A2w', 'Aw', 'w'):
+        maps, P, D = orc.vismapper_make_map(blvecs, zenaz, freqs, vis, w, beam_fn, method=method)
+        assert close(maps, 'maps_' + method) and close(P, 'Pdiag_' + method) and close(D, 'D_' + method), method
+    _, Prow, _ = orc.vismapper_make_map(blvecs, zenaz, freqs, vis, w, beam_fn, contract='rowsum')
+    assert close(Prow, 'Prowsum')
+    both = torch.stack([vis, vis * (0.5 - 0.25j)])
+    assert close(orc.vismapper_make_map(blvecs, zenaz, freqs, both, w, beam_fn, contract='none')[0], 'maps_list')
+    sub = g['sub_pix']
+    smaps, Pfull, _ = orc.vismapper_make_map(blvecs[::3], zenaz[[0, 2]][:, :, sub], freqs[1:4], vis[::3][:, [0, 2]][..., 1:4],
+                                             torch.full((222, 2, 3), 0.7, dtype=torch.float64), None, fov=120.0, contract=None)
+    assert close(smaps, 'sub_maps') and close(Pfull, 'sub_Pfull')
+
+
 def test_apply_cal():
     """gain application G_p V G_q^dagger against the reference function, value and both gradients"""
     g = load_golden('apply_cal')
