@@ -20,9 +20,41 @@ class TensorData:
         self.cov = None
         self.icov = None
         self.cov_axis = None
+        self.cov_ndim = None
+        self.cov_logdet = torch.tensor(0.0)
 
     def set_cov(self, cov, cov_axis, icov=None):
-        self.cov, self.cov_axis, self.icov = cov, cov_axis, icov
+        """covariance (data-shaped variances for cov_axis None, a matrix for 'full', matrices along the last two axes
+        otherwise) with the log-determinant and dimension the likelihood normalisation uses (dataset.py:70-124)"""
+        logdet = None
+        if isinstance(cov, torch.Tensor):
+            if cov_axis is None:
+                logdet = torch.sum(torch.log(cov))
+            elif cov_axis == 'full':
+                logdet = torch.slogdet(cov).logabsdet
+            else:
+                logdet = torch.slogdet(cov.reshape((-1,) + tuple(cov.shape[-2:]))).logabsdet.sum()
+            if torch.is_complex(logdet):
+                logdet = logdet.real
+        elif isinstance(icov, torch.Tensor) and cov_axis is None:
+            logdet = torch.sum(-torch.log(icov))
+        self.cov = cov.clone() if isinstance(cov, torch.Tensor) else cov
+        self.icov = icov.clone() if isinstance(icov, torch.Tensor) else icov
+        self.cov_axis = cov_axis
+        self.cov_ndim = int(np.prod(self.data.shape)) if self.data is not None else None
+        self.cov_logdet = logdet if logdet is not None else torch.tensor(0.0)
+
+    def get_data(self, **kwargs):
+        return self.data
+
+    def get_flags(self, **kwargs):
+        return self.flags
+
+    def get_cov(self, **kwargs):
+        return self.cov
+
+    def get_icov(self, **kwargs):
+        return self.icov
 
     def push(self, device):
         for k in ('data', 'flags', 'cov', 'icov'):
@@ -314,3 +346,27 @@ def concat_VisData(vds, axis):
         times = torch.cat([torch.as_tensor(v.times) for v in vds])
     out.setup_data(bls, times, vds[0].freqs, pol=vds[0].pol, data=data, history=vds[0].history)
     return out
+
+
+def pass_data(obj, copy=False, **kwargs):
+    """read function of an in-memory Dataset (dataset.py:4127-4133)"""
+    import copy as _c
+    return _c.deepcopy(obj) if copy else obj
+
+
+class Dataset(torch.utils.data.Dataset):
+    """the minibatches of target (or input) data a LogProb iterates over, one data object per batch
+    (dataset.py:3611-3648); objects held in memory unless a read function is given"""
+    def __init__(self, data, read_fn=None, read_kwargs={}):
+        if isinstance(data, (str, TensorData)):
+            data = [data]
+        self.data = data
+        self.Ndata = len(data)
+        self.read_fn = read_fn if read_fn is not None else pass_data
+        self.read_kwargs = [read_kwargs for _ in data] if isinstance(read_kwargs, dict) else read_kwargs
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, idx):
+        return self.read_fn(self.data[idx], **self.read_kwargs[idx])

@@ -171,6 +171,21 @@ def _slice2tensor(obj, device=None):
     return obj
 
 
+def _idx2ten(idx, device=None):
+    """a 1-D index list / array (boolean masks included) as an integer tensor on `device`; slices and ints pass
+    through (utils.py:2147-2163)"""
+    if isinstance(idx, (list, np.ndarray, tuple)):
+        if isinstance(idx, np.ndarray) and idx.dtype == np.dtype(bool):
+            idx = torch.as_tensor(np.where(idx)[0])
+        else:
+            idx = torch.as_tensor(idx, dtype=torch.long)
+    if isinstance(idx, torch.Tensor) and idx.dtype == torch.bool:
+        idx = torch.where(idx)[0]
+    if device is not None and isinstance(idx, torch.Tensor):
+        idx = idx.to(device)
+    return idx
+
+
 def blnum2ants(blnum, separate=False):
     """baseline integer(s) 1000*(a1+100)+(a2+100) -> antenna pair(s) (utils.py:2352)"""
     if isinstance(blnum, tuple):

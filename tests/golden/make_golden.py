@@ -861,6 +861,99 @@ def gen_vismapper(ba):
     save('vismapper', **out)
 
 
+def gen_logprob(ba):
+    """optim.LogProb (optim.py:385-1389) driving RIME: hex-37 (666 baselines), diffuse pixel sky + Airy PixelBeam, 4
+    channels, 4 times in two minibatches; target data with per-visibility inverse covariance; Gaussian priors attached to
+    the sky (input params) and the beam; closure() loss and accumulated gradients (a) with the modules' own Parameters,
+    (b) through set_main_params with an indexed sky piece + the whole beam (non-leaf graph tensors on the modules), and
+    (c) grad_type 'stochastic' on batch 1, compute 'like' / 'prior', negate False, complex_circular False."""
+    import importlib
+    optim = importlib.import_module('bayeslim.optim')
+    Nf, Npix = 4, 400
+    freqs = torch.linspace(120e6, 180e6, Nf)
+    times = 2459861.0 + np.arange(4) * 10.0 / 1440
+    rng = np.random.default_rng(31)
+    arr = hex_array(ba, 4, freqs)
+    tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+    ra, dec = fib_sky(Npix)
+    px_area = 4 * np.pi / Npix
+    Rs = ba.sky_model.PixelSkyResponse(freqs, cosmo=object())
+    sp = torch.as_tensor(rng.normal(size=(1, 1, Nf, len(ra))))
+    sky = ba.sky_model.PixelSky(sp.clone(), torch.stack([ra, dec]), px_area, R=Rs, parameter=True, name='pixsky')
+    beam, tg, pg = airy_pixbeam(ba, freqs, parameter=True)
+    bp = beam.params.detach().clone()
+    ants = arr.ants
+    sim_bls = [(ants[i], ants[j]) for i in range(len(ants)) for j in range(i + 1, len(ants))]
+    groups = ba.utils.split_into_groups(times, Nelem=2)
+    rime = ba.rime_model.RIME(sky, tel, beam, arr, sim_bls, groups, freqs)
+    zenaz = fill_eq2top(tel, sky.name, ra, dec, times)
+    # priors on the modules
+    sky_mean, sky_var = torch.as_tensor(rng.normal(size=sp.shape) * 0.3), torch.as_tensor(rng.uniform(0.5, 2.0, size=sp.shape))
+    beam_var = torch.as_tensor(rng.uniform(0.01, 0.05, size=bp.shape))
+    sky.set_priors(priors_inp_params=[optim.LogGaussPrior(sky_mean, sky_var)])
+    beam.set_priors(priors_inp_params=[optim.LogGaussPrior(bp - 0.01, beam_var, side='upper'),
+                                       optim.LogUniformPrior(-1.0, 2.0, index=(0, 0, 0, slice(0, 2)))])
+    model = ba.utils.Sequential(dict(rime=rime))
+    # target: two VisData minibatches with noise-like offsets from the model and a random diagonal icov
+    targets, dvis, dicov = [], [], []
+    with torch.no_grad():
+        for i in range(2):
+            model.batch_idx = i
+            v = model().data
+            d = v + torch.as_tensor(rng.normal(size=tuple(v.shape)) + 1j * rng.normal(size=tuple(v.shape))) * 0.05 * v.abs().mean()
+            ic = torch.as_tensor(rng.uniform(0.5, 2.0, size=tuple(v.shape))) / (0.05 * v.abs().mean()) ** 2
+            vd = ba.dataset.VisData()
+            vd.setup_meta(tel, arr.to_antpos())
+            vd.setup_data(sim_bls, torch.as_tensor(groups[i]), freqs, pol='ee', data=d, icov=ic)
+            targets.append(vd); dvis.append(d); dicov.append(ic)
+    model.batch_idx = 0
+    target = ba.dataset.Dataset(targets)
+    out = dict(freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(arr.ants), sim_bls=np.array(sim_bls), ra=ra, dec=dec,
+               zenaz=zenaz, px_area=np.array(px_area), sky_params=sp, beam_params=bp, theta_grid=tg, phi_grid=pg,
+               data0=dvis[0], data1=dvis[1], icov0=dicov[0], icov1=dicov[1], sky_mean=sky_mean, sky_var=sky_var,
+               beam_var=beam_var)
+    prob = optim.LogProb(model, target)
+    out['loss_a'] = prob.closure()
+    out['g_sky_a'], out['g_beam_a'] = sky.params.grad.clone(), beam.params.grad.clone()
+    chisq0, _ = prob.forward_chisq(0)
+    out['chisq0'] = chisq0.detach()
+    out['like1'] = prob.forward_like(1).detach()
+    prob.batch_idx = 0
+    prob.clear_prior_cache()
+    prob.forward_chisq(0)                      # fills the prior cache as the forward pass does
+    out['prior'] = prob.forward_prior().detach()
+    # (b) main params: pixels 10..59 of channels 1 and 3 of the sky in two pieces + the whole beam
+    pieces = [(0, 0, 1, range(10, 60)), (0, 0, 3, range(10, 60))]
+    prob.set_main_params([('rime.sky.params', pieces, 'sky'), ('rime.beam.params', None, 'beam')])
+    assert not model['rime.sky.params'].is_leaf
+    out['main0'] = prob.main_params.detach().clone()
+    out['loss_b'] = prob.closure()
+    out['g_main_b'] = prob.main_params.grad.clone()
+    # a step along -grad, then re-evaluate: the modules must see the new values
+    with torch.no_grad():
+        prob.main_params -= 1e-9 * prob.main_params.grad / prob.main_params.grad.abs().max() * 1e6
+    out['main1'] = prob.main_params.detach().clone()
+    out['loss_b2'] = prob.closure()
+    prob.set_main_params(None)
+    assert model['rime.sky.params'].is_leaf
+    out['sky_after_main'] = model['rime.sky.params'].detach().clone()
+    # (c) variants
+    prob.grad_type = 'stochastic'
+    prob.batch_idx = 1
+    out['loss_c_stoch1'] = prob.closure()
+    out['g_sky_c_stoch1'] = sky.params.grad.clone()
+    prob.grad_type = 'accumulate'
+    prob.compute = 'like'
+    out['loss_c_like'] = prob.closure()
+    prob.compute = 'prior'
+    out['loss_c_prior'] = prob.closure()
+    out['g_beam_c_prior'], out['g_sky_c_prior'] = beam.params.grad.clone(), sky.params.grad.clone()
+    prob.compute, prob.negate, prob.complex_circular = 'post', False, False
+    out['loss_c_pos_real'] = prob.closure()
+    out['g_sky_c_pos_real'] = sky.params.grad.clone()
+    save('logprob', **out)
+
+
 def gen_apply_cal(ba):
     """gain application G_p V G_q^dagger of calibration._apply_cal (calibration.py:2412-2487), 'com'
     visibilities, 1-pol / 2-pol (diagonal) / 4-pol, with gradients w.r.t. visibilities and gains.
@@ -931,6 +1024,7 @@ def main():
     gen_chisq(ba)
     gen_imaging(ba)
     gen_vismapper(ba)
+    gen_logprob(ba)
     gen_apply_cal(ba)
     gen_fringe_cases(ba)
     gen_apply_beam_cases(ba)

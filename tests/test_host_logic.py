@@ -471,3 +471,79 @@ def test_visdata_selection_and_copy():
     c = vd.copy(copydata=True, copymeta=True)
     assert c.data.data_ptr() != data.data_ptr() and torch.equal(c.data, data) and c.bls == vd.bls and c.pol == 'ee'
     assert vd.copy().data.data_ptr() == data.data_ptr()
+
+
+def test_logprob_container_on_a_toy_model():
+    """optim.LogProb on CPU with a two-minibatch toy model: closure() accumulation and averaging, priors counted once,
+    main-parameter tensor (non-leaf tensors on the module, values follow main_params, Parameters restored), stochastic
+    mode, gradient modifiers, negate / compute switches (optim.py:385-1389)"""
+    from bayeslim_amd import optim, dataset, utils
+
+    class Toy(utils.Module):
+        def __init__(self):
+            super().__init__(name='toy')
+            self.params = torch.nn.Parameter(torch.tensor([[1.0, 2.0, 3.0], [0.5, -1.0, 2.0]], dtype=torch.float64))
+            self.Nbatch, self.batch_idx = 2, 0
+
+        def forward(self, inp=None, prior_cache=None, **kw):
+            self.eval_prior(prior_cache)
+            td = dataset.TensorData()
+            td.data = self.params[self.batch_idx] * torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
+            return td
+
+    toy = Toy()
+    toy.set_priors(priors_inp_params=[optim.LogGaussPrior(torch.zeros(2, 3, dtype=torch.float64), torch.full((2, 3), 4.0, dtype=torch.float64),
+                                                          density=False)])
+    tds = []
+    for i in range(2):
+        td = dataset.TensorData()
+        td.data = torch.tensor([0.5, 3.0, 10.0], dtype=torch.float64) * (i + 1)
+        td.set_cov(None, None, icov=torch.tensor([1.0, 0.5, 2.0], dtype=torch.float64))
+        tds.append(td)
+    prob = optim.LogProb(toy, dataset.Dataset(tds), complex_circular=False)
+    w, ic = np.array([1.0, 2.0, 3.0]), np.array([1.0, 0.5, 2.0])
+    p = toy.params.detach().numpy().copy()
+
+    def expect(p):
+        like = []
+        for i in range(2):
+            res = p[i] * w - np.array([0.5, 3.0, 10.0]) * (i + 1)
+            like.append(0.5 * (res ** 2 * ic).sum() + 0.5 * (3 * np.log(2 * np.pi) + (-np.log(ic)).sum()))
+        prior = 0.5 * (p ** 2 / 4.0).sum()
+        grad = np.stack([(p[i] * w - np.array([0.5, 3.0, 10.0]) * (i + 1)) * ic * w for i in range(2)]) + p / 4.0
+        return (like[0] + like[1] + prior) / 2, grad, like, prior
+
+    loss, grad, like, prior = expect(p)
+    assert abs(float(prob.closure()) - loss) < 1e-12 and np.allclose(toy.params.grad.numpy(), grad, atol=1e-12)
+    assert prob.batch_idx == 0 and prob.closure_eval == 1 and prob.prior_cache == {}
+    assert abs(float(prob.forward_like(1).detach()) - like[1]) < 1e-12
+    prob.grad_type = 'stochastic'
+    prob.batch_idx = 1
+    assert abs(float(prob.closure()) - like[1]) < 1e-12                  # the prior belongs to batch 0 only
+    assert np.allclose(toy.params.grad.numpy()[0], 0) and np.allclose(toy.params.grad.numpy()[1], grad[1] - p[1] / 4.0)
+    prob.grad_type = 'accumulate'
+    # main parameters: row 1 only
+    prob.set_main_params([('params', (1, [0, 2]), 'row1')])
+    assert prob.main_params.tolist() == [0.5, 2.0] and not toy.params.is_leaf
+    assert abs(float(prob.closure()) - loss) < 1e-12 and np.allclose(prob.main_params.grad.numpy(), grad[1][[0, 2]], atol=1e-12)
+    with torch.no_grad():
+        prob.main_params += torch.tensor([1.0, -1.0], dtype=torch.float64)
+    p2 = p.copy()
+    p2[1, [0, 2]] += [1.0, -1.0]
+    assert abs(float(prob.closure()) - expect(p2)[0]) < 1e-12 and np.allclose(toy.params.detach().numpy(), p2)
+    prob.set_main_params(None)
+    assert isinstance(toy.params, torch.nn.Parameter) and np.allclose(toy.params.detach().numpy(), p2)
+    # gradient modifiers, sign and distribution switches
+    prob.set_grad_mod([('model.params', {'mod_type': 'mult', 'value': 2.0, 'index': (0,)}),
+                       ('model.params', {'mod_type': 'replace', 'value': 7.0, 'index': (1, 1)})], alpha=0.5)
+    prob.closure()
+    g2 = expect(p2)[1]
+    assert np.allclose(toy.params.grad.numpy()[0], g2[0]) and toy.params.grad[1, 1] == 3.5        # 2.0 * alpha = 1, 7 * alpha
+    prob.set_grad_mod()
+    prob.negate = False
+    assert abs(float(prob.closure()) + expect(p2)[0]) < 1e-12
+    prob.negate, prob.compute = True, 'prior'
+    assert abs(float(prob.closure()) - expect(p2)[3] / 2) < 1e-12
+    u = optim.LogUniformPrior(torch.tensor(0.0), torch.tensor(2.0))
+    # the normalisation is summed over the BOUNDS' shape (scalar bounds: once), as in the reference
+    assert float(u(torch.tensor([0.5, 1.5]))) == float(np.log(0.5)) and float(u(torch.tensor([0.5, 2.5]))) == -np.inf

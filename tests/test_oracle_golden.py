@@ -390,6 +390,39 @@ def test_vismapper_time_loop():
     assert close(smaps, 'sub_maps') and close(Pfull, 'sub_Pfull')
 
 
+def test_logprob_posterior_on_oracle_arithmetic():
+    """the posterior the reference's LogProb.closure returned (optim.py:1032-1226), rebuilt from the oracle's RIME and
+    chi-square and the build's host-side priors: minibatch likelihoods with their normalisation, the prior counted
+    once, the average over the two minibatches, gradients w.r.t. sky and beam parameters"""
+    from bayeslim_amd import optim
+    g = load_golden('logprob')
+    sc = lambda k: float(np.ravel(g[k])[0])
+    freqs = T(g['freqs'])
+    sp = T(g['sky_params']).clone().requires_grad_(True)
+    bp = T(g['beam_params']).clone().requires_grad_(True)
+    pri = [(optim.LogGaussPrior(T(g['sky_mean']), T(g['sky_var'])), sp),
+           (optim.LogGaussPrior(T(g['beam_params']) - 0.01, T(g['beam_var']), side='upper'), bp),
+           (optim.LogUniformPrior(-1.0, 2.0, index=(0, 0, 0, slice(0, 2))), bp)]
+    logprior = sum(p(x) for p, x in pri)
+    assert abs(float(-logprior) - sc('prior')) < 1e-9 * abs(sc('prior'))
+    total = 0
+    for i in range(2):
+        vis = orc.rime_forward(sp * float(g['px_area']), T(g['zenaz'])[2 * i:2 * i + 2], _pixbeam_fn(g, bp), _blvecs(g),
+                               [(0, 0)] * 666, freqs)
+        d, ic = T(g['data%d' % i]), T(g['icov%d' % i])
+        chisq = orc.chisq(vis, d, ic)
+        if i == 0:
+            assert abs(float(chisq) - sc('chisq0')) < 1e-10 * sc('chisq0')
+        like = chisq + d.numel() * np.log(np.pi) + torch.sum(-torch.log(ic))            # -log L, complex circular
+        if i == 1:
+            assert abs(float(like) - sc('like1')) < 1e-10 * abs(sc('like1'))
+        total = total + like
+    loss = (total - logprior) / 2                                                         # closure averages the batches
+    assert abs(float(loss) - sc('loss_a')) < 1e-10 * abs(sc('loss_a'))
+    gs, gb = torch.autograd.grad(total - logprior, [sp, bp])                              # .grad accumulates the SUM
+    assert maxrel(gs.numpy(), g['g_sky_a']) < 1e-9 and maxrel(gb.numpy(), g['g_beam_a']) < 1e-9
+
+
 def test_apply_cal():
     """gain application G_p V G_q^dagger against the reference function, value and both gradients"""
     g = load_golden('apply_cal')
