@@ -510,6 +510,56 @@ class ShardedRIME:
         all_reduce_grads(params, self.group)
 
 
+class DistributedLogProb:
+    """
+    Data-parallel posterior: ONE optim.LogProb per rank (= per GPU), each predicting and comparing against its own
+    shard of the target data (baselines, channels or times) from a replicated main-parameter tensor.  The
+    reference's DistributedLogProb (optim.py:1391-1629) holds a list of LogProbs on several devices inside one
+    process, sums their losses and adds their main_params gradients on a master device by hand (:1539-1566); here
+    the main-parameter tensor itself is the flat bucket: closure() runs the local closure and finishes with ONE
+    in-place all-reduce of main_params.grad over RCCL plus a scalar all-reduce of the loss.  As there, the prior
+    is evaluated on one rank only ('post' becomes 'like' on the others), and main_params starts identical on
+    every rank (broadcast from rank 0).
+    """
+    def __init__(self, prob, group=None):
+        self.prob, self.group = prob, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        assert prob.main_params is not None and prob.main_params.is_leaf, "run LogProb.set_main_params() first"
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        with torch.no_grad():
+            dist.broadcast(prob.main_params.data, src=src, group=group)
+        prob.send_main_params()
+        if prob.compute == 'post' and self.rank != 0:
+            prob.compute = 'like'                      # the prior is counted once
+
+    @property
+    def main_params(self):
+        return self.prob.main_params
+
+    @property
+    def Nbatch(self):
+        return self.prob.Nbatch
+
+    @property
+    def closure_eval(self):
+        return self.prob.closure_eval
+
+    def closure(self, **kwargs):
+        """summed loss over ranks; main_params.grad = the sum of the ranks' gradients, on every rank"""
+        mp = self.prob.main_params
+        if self.prob.compute == 'prior' and self.rank != 0:
+            mp.grad = None
+            loss = torch.zeros(1, device=mp.device, dtype=torch.float64)
+        else:
+            loss = self.prob.closure(**kwargs)
+        if torch.is_grad_enabled():
+            if mp.grad is None:
+                mp.grad = torch.zeros_like(mp)
+            dist.all_reduce(mp.grad, op=dist.ReduceOp.SUM, group=self.group)
+        # float64 on every rank: a (1,)-shaped float32 prior term demotes a 0-dim float64 likelihood on the prior's rank
+        return reduce_scalar(loss.reshape(-1)[:1].to(mp.device, torch.float64), self.group)
+
+
 # ---------------------------------------------------------------------------------------------
 # the same two collectives behind the library's C ABI (include/rime_hip.h: rime_comm_*)
 # ---------------------------------------------------------------------------------------------

@@ -299,6 +299,86 @@ def test_grad_sync_collective_order_is_rank_invariant():
         assert np.array_equal(gc, np.zeros((4, 6)))
 
 
+def _toy_logprob(shard, nshard):
+    """LogProb over a shard of a 6-visibility toy problem with two minibatches (shard None: the whole problem)"""
+    from bayeslim_amd import optim, dataset, utils
+    w = torch.tensor([1.0, 2.0, 3.0, -1.0, 0.5, 2.5], dtype=torch.float64)
+    d = torch.tensor([0.5, 3.0, 10.0, -2.0, 1.0, 4.0], dtype=torch.float64)
+    ic = torch.tensor([1.0, 0.5, 2.0, 1.5, 0.7, 3.0], dtype=torch.float64)
+    sl = slice(None) if shard is None else slice(shard * 6 // nshard, (shard + 1) * 6 // nshard)
+
+    class Toy(utils.Module):
+        def __init__(self):
+            super().__init__(name='toy')
+            self.params = torch.nn.Parameter(torch.tensor([[1.0, 2.0, 3.0], [0.5, -1.0, 2.0]], dtype=torch.float64))
+            self.Nbatch, self.batch_idx = 2, 0
+
+        def forward(self, inp=None, prior_cache=None, **kw):
+            self.eval_prior(prior_cache)
+            p = self.params[self.batch_idx]
+            td = dataset.TensorData()
+            td.data = (torch.cat([p, p ** 2]) * w)[sl]                # every parameter reaches every shard
+            return td
+
+    toy = Toy()
+    toy.set_priors(priors_inp_params=[optim.LogGaussPrior(torch.zeros(2, 3, dtype=torch.float64),
+                                                          torch.full((2, 3), 4.0, dtype=torch.float64))])
+    tds = []
+    for i in range(2):
+        td = dataset.TensorData()
+        td.data = (d * (i + 1))[sl]
+        td.set_cov(None, None, icov=ic[sl])
+        tds.append(td)
+    prob = optim.LogProb(toy, dataset.Dataset(tds), complex_circular=False)
+    prob.set_main_params(['params'])
+    return prob
+
+
+def _worker_dist_logprob(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_default_dtype(torch.float64)       # LogProb's zero-initialised sums take the default dtype, as the reference's
+        prob = _toy_logprob(rank, world)
+        if rank == 1:
+            with torch.no_grad():
+                prob.main_params += 5.0                  # must be overwritten by rank 0's values
+        dprob = rdist.DistributedLogProb(prob)
+        assert prob.compute == ('post' if rank == 0 else 'like')
+        loss = dprob.closure()
+        q.put((rank, float(loss), dprob.main_params.detach().numpy().copy(), dprob.main_params.grad.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_logprob_equals_single_process():
+    """one LogProb per rank on its shard of the data: summed loss and gradient of the main-parameter tensor equal the
+    unsharded LogProb's (the pattern of optim.py:1539-1566), the prior counted once"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dist_logprob, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = _toy_logprob(None, 1)
+        loss = float(ref.closure())
+    finally:
+        torch.set_default_dtype(old)
+    # the two shards each carry half of the likelihood normalisation constants: the summed loss is the same
+    for rank, l, mpv, g in res:
+        assert abs(l - loss) < 1e-10 * abs(loss), (rank, l, loss)
+        assert np.allclose(mpv, ref.main_params.detach().numpy())
+        assert np.allclose(g, ref.main_params.grad.numpy(), rtol=1e-12, atol=1e-12)
+
+
 def test_tile_shard_plan():
     """whole blocks of the antenna pair matrix per rank: a partition of the baselines, balanced cost,
     and the inverse permutation restores the original order"""
