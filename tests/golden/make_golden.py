@@ -954,6 +954,128 @@ def gen_logprob(ba):
     save('logprob', **out)
 
 
+def load_calibration_module(ba):
+    """bayeslim.calibration does not parse under Python 3.10 (one py>=3.11 subscript, `A[*self.idx]`, at :2279 in a class
+    unrelated to the path); the module is executed from its own source, read from the reference checkout at generation
+    time, with that token spelled `A[tuple(self.idx)]`."""
+    import importlib
+    importlib.import_module('bayeslim.optim')
+    src = open(os.path.join(REF, 'calibration.py')).read().replace('[*self.idx]', '[tuple(self.idx)]')
+    mod = types.ModuleType('bayeslim.calibration')
+    mod.__package__ = 'bayeslim'
+    mod.__file__ = os.path.join(REF, 'calibration.py')
+    sys.modules['bayeslim.calibration'] = mod
+    exec(compile(src, mod.__file__, 'exec'), mod.__dict__)
+    return mod
+
+
+class AxisLM:
+    """a linear basis along one axis (the protocol JonesResponse expects of freq_LM / time_LM: callable + push)"""
+    def __init__(self, A, axis):
+        self.A, self.axis = A, axis
+
+    def __call__(self, p):
+        return torch.movedim(torch.movedim(p, self.axis, -1) @ self.A.to(p.dtype).T, -1, self.axis)
+
+    def push(self, device):
+        self.A = self.A.to(device)
+
+
+def gen_jones(ba):
+    """calibration.JonesModel / JonesResponse (calibration.py:416-875) applied to a VisData: every gain type, the
+    reference-antenna conventions, p0, 1 / 2 / 4-pol, single_ant, undo, a time minibatch through the index cache, linear
+    bases over frequency and time; outputs and gradients w.r.t. the parameters"""
+    cal = load_calibration_module(ba)
+    rng = np.random.default_rng(41)
+    freqs = torch.linspace(120e6, 180e6, 6)
+    times = torch.as_tensor(2459861.0 + np.arange(4) * 10.0 / 1440)
+    arr = hex_array(ba, 2, freqs)
+    ants = arr.ants
+    bls = arr.get_bls(uniq_bls=False, keep_autos=False)
+    Nant, Nbl, Nt, Nf = len(ants), len(bls), 4, 6
+    antpos = arr.to_antpos()
+
+    def rc(*shape):
+        return torch.as_tensor(rng.normal(size=shape) + 1j * rng.normal(size=shape))
+
+    def visdata(npol, tsel=slice(None)):
+        vd = ba.dataset.VisData()
+        vd.setup_meta(None, antpos)
+        data = rc(npol, npol, Nbl, Nt, Nf)
+        vd.setup_data(bls, times[tsel], freqs, pol='ee' if npol == 1 else None, data=data[:, :, :, tsel])
+        return vd, data
+
+    out = dict(freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(ants), bls=np.array(bls))
+    # the reference's time index cache needs the response to know the time axis (calibration.py:327-336)
+    JR = lambda **kw: cal.JonesResponse(times=times, **kw)
+
+    def run(tag, jm, vd, **fw):
+        vout = jm(vd, **fw)
+        cot = rc(*vout.data.shape) if vout.data.is_complex() else torch.as_tensor(rng.normal(size=tuple(vout.data.shape)))
+        if jm.params.requires_grad:
+            ((vout.data * cot.conj()).real.sum() if vout.data.is_complex() else (vout.data * cot).sum()).backward()
+            out['g_' + tag] = jm.params.grad.clone()
+            jm.params.grad = None
+        out['vout_' + tag], out['cot_' + tag], out['params_after_' + tag] = vout.data.detach(), cot, jm.params.detach().clone()
+
+    vd1, d1 = visdata(1)
+    out['vis1'] = d1
+    # complex gains, reference antenna (rephase mode), p0
+    p = rc(1, 1, Nant, Nt, Nf); p0 = 0.1 * rc(1, 1, Nant, Nt, Nf)
+    out['p_com'], out['p0_com'] = p.clone(), p0.clone()
+    run('com', cal.JonesModel(p.clone(), ants, p0=p0.clone(), refant=ants[2], R=JR(param_type='com')), vd1)
+    # real-view complex parameters
+    pr = torch.view_as_real(rc(1, 1, Nant, Nt, Nf)).clone()
+    out['p_comreal'] = pr.clone()
+    run('comreal', cal.JonesModel(pr.clone(), ants, refant=ants[0], R=JR(param_type='com')), vd1)
+    for ptype in ('amp', 'phs', 'real'):
+        pp = torch.as_tensor(rng.normal(size=(1, 1, Nant, Nt, Nf)) * 0.3)
+        out['p_' + ptype] = pp.clone()
+        run(ptype, cal.JonesModel(pp.clone(), ants, refant=ants[1] if ptype == 'phs' else None,
+                                  R=JR(param_type=ptype)), vd1)
+    pap = torch.as_tensor(rng.normal(size=(1, 1, Nant, Nt, Nf, 2)) * 0.3)
+    out['p_amp_phs'] = pap.clone()
+    run('amp_phs', cal.JonesModel(pap.clone(), ants, refant=ants[3], R=JR(param_type='amp_phs')), vd1)
+    # delays [ns] on complex visibilities, one delay per antenna and time
+    pd = torch.as_tensor(rng.normal(size=(1, 1, Nant, Nt, 1)) * 5.0)
+    out['p_dly'] = pd.clone()
+    run('dly', cal.JonesModel(pd.clone(), ants, refant=ants[0], R=JR(param_type='dly', freqs=freqs)), vd1)
+    # phase / delay gradients over the array: antenna axis = (EW, NS)
+    for ptype, scale in (('phs_slope', 0.02), ('dly_slope', 0.05)):
+        ps = torch.as_tensor(rng.normal(size=(1, 1, 2, Nt, 1)) * scale)
+        out['p_' + ptype] = ps.clone()
+        run(ptype, cal.JonesModel(ps.clone(), ants, R=JR(param_type=ptype, antpos=antpos, freqs=freqs)), vd1)
+    # one gain for the whole array; undo
+    pg = rc(1, 1, 1, Nt, Nf)
+    out['p_single'] = pg.clone()
+    run('single', cal.JonesModel(pg.clone(), ants, single_ant=True, R=JR()), vd1)
+    run('undo', cal.JonesModel(p.clone(), ants, R=JR()), vd1, undo=True)
+    out['p_undo'] = p.clone()
+    # time minibatch: the response knows all times, the VisData holds times 1 and 3
+    vdt, _ = visdata(1, tsel=[1, 3])
+    out['vis_tsel'] = vdt.data.clone()
+    run('tsel', cal.JonesModel(p.clone(), ants, R=JR(param_type='com')), vdt)
+    # polynomial bases: 3 coefficients over frequency, 2 over time ('zero' reference-antenna mode)
+    Af = torch.as_tensor(np.vander(np.linspace(-1, 1, Nf), 3, increasing=True))
+    At = torch.as_tensor(np.vander(np.linspace(-1, 1, Nt), 2, increasing=True))
+    out['Af'], out['At'] = Af, At
+    pl = rc(1, 1, Nant, 2, 3)
+    out['p_linear'] = pl.clone()
+    run('linear', cal.JonesModel(pl.clone(), ants, refant=ants[2],
+                                 R=JR(param_type='com', freq_mode='linear', time_mode='linear',
+                                                     freq_LM=AxisLM(Af, -1), time_LM=AxisLM(At, -2))), vd1)
+    # 2-pol (diagonal) and 4-pol
+    vd2, d2 = visdata(2)
+    out['vis2'] = d2
+    p2 = rc(2, 2, Nant, Nt, Nf); p2[0, 1] = 0; p2[1, 0] = 0
+    out['p_2pol'] = p2.clone()
+    run('2pol', cal.JonesModel(p2.clone(), ants, polmode='2pol', refant=ants[0], R=JR()), vd2)
+    p4 = rc(2, 2, Nant, Nt, Nf)
+    out['p_4pol'] = p4.clone()
+    run('4pol', cal.JonesModel(p4.clone(), ants, polmode='4pol', R=JR()), vd2)
+    save('jones', **out)
+
+
 def gen_apply_cal(ba):
     """gain application G_p V G_q^dagger of calibration._apply_cal (calibration.py:2412-2487), 'com'
     visibilities, 1-pol / 2-pol (diagonal) / 4-pol, with gradients w.r.t. visibilities and gains.
@@ -1025,6 +1147,7 @@ def main():
     gen_imaging(ba)
     gen_vismapper(ba)
     gen_logprob(ba)
+    gen_jones(ba)
     gen_apply_cal(ba)
     gen_fringe_cases(ba)
     gen_apply_beam_cases(ba)

@@ -423,6 +423,64 @@ def test_logprob_posterior_on_oracle_arithmetic():
     assert maxrel(gs.numpy(), g['g_sky_a']) < 1e-9 and maxrel(gb.numpy(), g['g_beam_a']) < 1e-9
 
 
+def test_jones_response_chain_on_oracle_apply_cal():
+    """the reference JonesModel's outputs rebuilt on CPU from the build's host-side pieces (reference-antenna
+    rephasing, JonesResponse gain types and linear bases, time index cache) and the oracle's G_p V G_q^dagger"""
+    from bayeslim_amd import calibration as cal, utils
+    g = load_golden('jones')
+    freqs, times = T(g['freqs']), T(g['times'])
+    ants = g['ants'].tolist()
+    where = {a: i for i, a in enumerate(ants)}
+    g1 = [where[a] for a, b in g['bls'].tolist()]
+    g2 = [where[b] for a, b in g['bls'].tolist()]
+    antpos = utils.AntposDict(ants, T(g['antvecs']))
+
+    class LM:
+        def __init__(self, A, axis):
+            self.A, self.axis = A, axis
+
+        def __call__(self, p):
+            return torch.movedim(torch.movedim(p, self.axis, -1) @ self.A.to(p.dtype).T, -1, self.axis)
+
+    def check(tag, params, R, vis, refant=None, p0=None, mode='rephase', two=False, single=False, tsel=None):
+        params = params.clone()
+        p0 = None if p0 is None else p0.clone()
+        if refant is not None:
+            cal.rephase_to_refant(params, R.param_type, where[refant], p0=p0, mode=mode, inplace=True)
+        assert maxrel(params.numpy(), g['params_after_' + tag]) < 1e-12, tag
+        jones = R(params if p0 is None else params + p0)
+        if tsel is not None:
+            ic = cal.IndexCache(times=times)
+            jones = ic.index_params(jones, times=times[tsel])
+        i1, i2 = ([0] * len(g1), [0] * len(g2)) if single else (g1, g2)
+        vout = orc.apply_cal(vis, jones.to(vis.dtype), i1, i2, cal_2pol=two)
+        assert maxrel(vout.numpy(), g['vout_' + tag]) < 1e-11, tag
+
+    v1, v2 = T(g['vis1']), T(g['vis2'])
+    JR = cal.JonesResponse
+    check('com', T(g['p_com']), JR(param_type='com'), v1, refant=ants[2], p0=T(g['p0_com']))
+    check('comreal', T(g['p_comreal']), JR(param_type='com'), v1, refant=ants[0])
+    check('amp', T(g['p_amp']), JR(param_type='amp'), v1)
+    check('phs', T(g['p_phs']), JR(param_type='phs'), v1, refant=ants[1])
+    check('real', T(g['p_real']), JR(param_type='real'), v1)
+    check('amp_phs', T(g['p_amp_phs']), JR(param_type='amp_phs'), v1, refant=ants[3])
+    check('dly', T(g['p_dly']), JR(param_type='dly', freqs=freqs), v1, refant=ants[0])
+    check('phs_slope', T(g['p_phs_slope']), JR(param_type='phs_slope', antpos=antpos, freqs=freqs), v1)
+    check('dly_slope', T(g['p_dly_slope']), JR(param_type='dly_slope', antpos=antpos, freqs=freqs), v1)
+    check('single', T(g['p_single']), JR(), v1, single=True)
+    check('tsel', T(g['p_com']), JR(), T(g['vis_tsel']), tsel=[1, 3])
+    check('linear', T(g['p_linear']), JR(freq_mode='linear', time_mode='linear', freq_LM=LM(T(g['Af']), -1),
+                                         time_LM=LM(T(g['At']), -2)), v1, refant=ants[2], mode='zero')
+    check('2pol', T(g['p_2pol']), JR(), v2, refant=ants[0], two=True)
+    check('4pol', T(g['p_4pol']), JR(), v2)
+    # conversions are inverse to each other
+    x = T(g['p_com'])
+    for ptype in ('amp', 'phs', 'amp_phs', 'real'):
+        back = cal.params2complex(cal.complex2params(x, ptype), ptype)
+        want = {'amp': x.abs() + 0j, 'phs': x / x.abs(), 'amp_phs': x, 'real': x.real + 0j}[ptype]
+        assert maxrel(back.numpy(), want.numpy()) < 1e-12, ptype
+
+
 def test_apply_cal():
     """gain application G_p V G_q^dagger against the reference function, value and both gradients"""
     g = load_golden('apply_cal')
