@@ -147,12 +147,18 @@ constexpr int MF_ROWB = 4 * MF_KP + 16;         // [re KP x f16][im KP x f16][pa
 // Block shapes.  Diagonal block: one group of <= 128 antennas against itself, upper-triangular
 // tiles, 4 waves.  Cross block (arrays with more than 128 antennas): group I (image rows 0..127,
 // the sign-carrying L side) against group J (rows 128..255), all 16 tiles, 8 waves, 1 block per CU.
-template <int TI_, int TJ_, bool CROSS_>
+// SELF (complex psky, forward): a diagonal block run as the cross block of a group with ITSELF -- rows 0..32 TI - 1
+// hold L = 2^7 E, rows 32 TI.. hold B = psky E of the SAME antennas, both written from one evaluation of E, and only
+// the upper-triangular tiles (12 MFMAs each: L and B differ, no diagonal-tile symmetry) are contracted: one pass
+// instead of the two real-plane passes of the diagonal kernel (12 TA (TA + 1) / 2 against 2 x (12 TA (TA - 1) / 2
+// + 7 TA) MFMAs per K step, half the trigonometry).
+template <int TI_, int TJ_, bool CROSS_, bool SELF_ = false>
 struct FwdShape {
+    static_assert(!SELF_ || (CROSS_ && TI_ == TJ_), "a self block is a cross block of a group with itself");
     static constexpr int TA = TI_;                                 // diagonal block: tiles per side
     static constexpr int TI = TI_, TJ = CROSS_ ? TJ_ : TI_;        // cross block: row tiles (group I) x column tiles (group J)
-    static constexpr bool CROSS = CROSS_;
-    static constexpr int NT = CROSS ? TI * TJ : TA * (TA + 1) / 2; // 32x32 output tiles
+    static constexpr bool CROSS = CROSS_, SELF = SELF_;
+    static constexpr int NT = SELF ? TI * (TI + 1) / 2 : (CROSS ? TI * TJ : TA * (TA + 1) / 2);   // 32x32 output tiles
     static constexpr int NU = 2 * NT;
     // a single tile has two (re | im) units for four waves: the two K steps of a panel go to different
     // waves and the partial tiles are added in the epilogue
@@ -183,12 +189,14 @@ __host__ __device__ constexpr int tri4_col(int t) { return t < 4 ? t : (t == 4 ?
 // [4,6): 6, 6, 7, 7 MFMAs per wave and K step (two units per wave in row-major order: 7, 12, 7, 0)
 template <class SH> __host__ __device__ constexpr int tile_row(int t)
 {
+    if (SH::SELF) return tri_row(SH::TI, t);
     return SH::CROSS ? t / SH::TJ : (SH::TA == 4 ? tri4_row(t) : (SH::TA == 2 ? (t == 2 ? 1 : 0) : tri_row(SH::TA, t)));
 }
 template <class SH> __host__ __device__ constexpr int tile_col(int t)
 {
     // 65..96 antennas: (0,1) (0,0) (0,2) (1,1) (1,2) (2,2) -- off-diagonal and diagonal tiles alternate, so the
     // three-unit ranges cost 16, 15, 13, 13 MFMAs per K step (row-major order: 13, 18, 13, 13)
+    if (SH::SELF) return tri_col(SH::TI, t);
     return SH::CROSS ? t % SH::TJ : (SH::TA == 4 ? tri4_col(t) : (SH::TA == 2 ? (t == 1 ? 0 : 1)
                               : (SH::TA == 3 && t < 2 ? 1 - t : tri_col(SH::TA, t))));
 }
@@ -196,6 +204,8 @@ template <class SH> __host__ __device__ constexpr int tile_col(int t)
 template <class SH> __host__ __device__ constexpr int unit_begin(int w)
 {
     if (SH::KSPLIT) return w >> 1;                 // waves (0, 1): unit 0, waves (2, 3): unit 1; K step = w & 1
+    if (SH::SELF && SH::TI == 4) return w < 4 ? 3 * w : 12 + 2 * (w - 4);      // 20 units over 8 waves: 3 3 3 3 2 2 2 2
+    if (SH::SELF && SH::TI == 2) return w < 2 ? 2 * w : (w == 2 ? 4 : (w == 3 ? 5 : 6));     // 6 units: 2 2 1 1
     if (!SH::CROSS && SH::TA == 2) return w <= 2 ? w : (w == 3 ? 4 : 6);
     return SH::UPW * w < SH::NU ? SH::UPW * w : SH::NU;
 }
@@ -258,7 +268,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // 3 sweeps per wave instead of 4 (padding rows of the images are never written: they only reach
     // the result rows / columns of padding antennas, which have no baseline slot)
     constexpr bool OCT = !SH::CROSS && SH::TA == 2;
-    constexpr int NGEN = OCT ? SH::ROWS / 16 : SH::GEN;
+    constexpr int NGEN = OCT ? SH::ROWS / 16 : (SH::SELF ? SH::GEN_I : SH::GEN);
     const int nk = OCT ? min(NGEN, (A.Nant - (W >> 1) + 15) / 16) : NGEN;     // uniform
     double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
@@ -333,25 +343,31 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
             for (int hf = 0; hf < MF_NH; ++hf) {
                 const float ar0 = av[hf].x * sb, ar1 = av[hf].y * sb, ai0 = aw[hf].x * si, ai1 = aw[hf].y * si;
 #pragma unroll
-                for (int u = 0; u < SH::GEN; ++u) {
+                for (int u = 0; u < NGEN; ++u) {
                     const double ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
                     const double ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
                     const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
                     const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                     const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
                     uint32_t rh, rl, ih, il;
-                    if (u < SH::GEN_I) {             // group I: L = 2^7 E
+                    unsigned char* o = buf + goff + u * SH::GROWS * MF_ROWB + 32 * hf;
+                    if (SH::SELF || u < SH::GEN_I) { // group I: L = 2^7 E
                         split2(128.0f * c0, 128.0f * c1, rh, rl);
                         split2(128.0f * s0, 128.0f * s1, ih, il);
-                    } else {                         // group J: B = psky E (complex product)
+                        *reinterpret_cast<uint32_t*>(o) = rh;
+                        *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+                        *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+                        *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+                        if constexpr (SH::SELF) o += SH::GEN_I * SH::GROWS * MF_ROWB;     // the same antenna's B row
+                    }
+                    if (SH::SELF || u >= SH::GEN_I) { // group J: B = psky E (complex product)
                         split2(fmaf(ar0, c0, -ai0 * s0), fmaf(ar1, c1, -ai1 * s1), rh, rl);
                         split2(fmaf(ar0, s0, ai0 * c0), fmaf(ar1, s1, ai1 * c1), ih, il);
+                        *reinterpret_cast<uint32_t*>(o) = rh;
+                        *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+                        *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+                        *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
                     }
-                    unsigned char* o = buf + goff + u * SH::GROWS * MF_ROWB + 32 * hf;
-                    *reinterpret_cast<uint32_t*>(o) = rh;
-                    *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
-                    *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
-                    *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
                 }
                 fetch(next_panel, hf);
             }
@@ -586,6 +602,16 @@ fringe_ant_fwd_cross_kernel(AntArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     ant_fwd_dispatch<FwdShape<TI, TJ, true>, SIGNED, CPLX>(A, smem);
+}
+
+// self blocks (complex psky): the diagonal block of TI x 32 antennas as a triangular cross block
+template <int TI>
+__global__ void __launch_bounds__((cross_threads<TI, TI>()), (cross_minwaves<TI, TI>()))
+fringe_ant_fwd_self_kernel(AntArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    static_assert(FwdShape<TI, TI, true, true>::NW == FwdShape<TI, TI, true>::NW, "launch bounds follow the cross shape");
+    ant_fwd_dispatch<FwdShape<TI, TI, true, true>, false, true>(A, smem);
 }
 
 
@@ -1390,7 +1416,9 @@ static bool ant_common_ok(int Nrows, int cross, int Nbl, int Nt, int Nf, int Pst
     if (st_p != 1 && st_p != 2) return false;
     if (cplx != 0 && (cplx != 1 && cplx != -1)) return false;
     if (cplx != 0 && st_p != 2) return false;                      // complex psky: interleaved (re, im)
-    if (cross ? !cross_shape_ok(cross, Nrows - cross) : (Nrows <= 0 || Nrows > MF_NA)) return false;
+    if (cross && cross == Nrows) {                                  // self block: complex psky, 32 / 64 / 128 rows
+        if (cplx == 0 || !(Nrows == 32 || Nrows == 64 || Nrows == 128)) return false;
+    } else if (cross ? !cross_shape_ok(cross, Nrows - cross) : (Nrows <= 0 || Nrows > MF_NA)) return false;
     if (Nbl <= 0 || Nt <= 0 || Nt > 65535 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0) return false;
     return sign == 1 || sign == -1;
 }
@@ -1425,6 +1453,18 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
     if (!workspace || workspace_bytes < rime_fringe_ant_workspace(Nbl, Nt, Nf, Pstride)) return RIME_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
+    if (cross && cross == Nrows) {
+#define RIME_FWD_SELF(TI)                                                                                      \
+    do {                                                                                                       \
+        using SH = FwdShape<TI, TI, true, true>;                                                               \
+        hipLaunchKernelGGL((fringe_ant_fwd_self_kernel<TI>), grid, dim3(SH::NW * 64), SH::LDS, st, A);         \
+    } while (0)
+        if (Nrows == 32) RIME_FWD_SELF(1);
+        else if (Nrows == 64) RIME_FWD_SELF(2);
+        else RIME_FWD_SELF(4);
+#undef RIME_FWD_SELF
+        return check_launch();
+    }
     if (cross) {
         const int ti = cross / 32, tj = (Nrows - cross) / 32;
         if (ti == 1 && tj == 1) launch_fwd_cross<1, 1>(A, grid, st, rowmin != nullptr, psky_complex);

@@ -125,6 +125,9 @@ class FringeGeometry:
 MFMA_MIN_ANTS = int(os.environ.get('RIME_MFMA_MIN_ANTS', '33'))   # 'auto' threshold (see _setup_antenna_path)
 MFMA_GROUP = 128          # antennas per group of the matrix-core path (4 x 4 tiles of 32)
 MFMA_MAX_ANTS = 2048      # table memory only: 136 blocks x 128 KB at 2048 antennas
+# complex psky, forward: diagonal blocks of 32 / 64 / 128 antenna rows whose baselines all have one orientation run as
+# triangular self-cross blocks in ONE pass (RIME_SELF_BLOCKS=0: the two real-plane passes of the diagonal kernel)
+SELF_BLOCKS = os.environ.get('RIME_SELF_BLOCKS', '1') != '0'
 
 
 def _group_capacity(n, group):
@@ -286,6 +289,13 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
         def launch(blk, pp, c, cflag):
             mp = blk['mp']
             src = ctypes.c_void_p(inp.data_ptr() + 4 * (mp * st_mp + pp * st_pp + c))
+            if cflag != 0 and blk['cross'] == 0:             # diagonal block, complex single pass: self block
+                n = int(blk['self_pos'].shape[0])
+                rc = lib.rime_fringe_ant_fwd_block(_ptr(blk['self_pos']), n, n, *geo, src, _ptr(scale[mp, pp]),
+                                                   _ptr(rowmin[c][mp, pp]), _ptr(blk['direct']), _ptr(blk['conj']),
+                                                   *shape, cflag, _ptr(ws), ws.numel(), _stream())
+                check(rc, 'rime_fringe_ant_fwd_block')
+                return blk['mf_self']
             rc = lib.rime_fringe_ant_fwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], *geo, src,
                                                _ptr(scale[mp, pp]), _ptr(rowmin[c][mp, pp]),
                                                _ptr(blk['direct']), _ptr(blk['conj']),
@@ -389,8 +399,18 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
             rows, TA = pi.contiguous(), (pi.shape[0] + 31) // 32
             mf_fwd = 12 * (TA * (TA - 1) // 2) + 7 * TA      # diagonal tiles: symmetric products folded
             mf_bwd = 12 * (TA * (TA + 1) // 2)
-            cross, fwd_cpass = 0, 0                          # forward diagonal blocks: one real plane per call
+            cross, fwd_cpass = 0, 0                          # forward diagonal blocks: one real plane per call ...
+            self_pos, mf_self = None, 0
+            if SELF_BLOCKS and TA in (1, 2, 4) and blk['cpass'] != 0:
+                # ... unless psky is complex and every baseline has one orientation: then the block runs as the
+                # triangular cross block of the group with itself, ONE complex pass (rime_fringe_ant_fwd_block
+                # with cross == Nrows)
+                self_pos = torch.zeros(TA * 32, 3, dtype=torch.float64, device=dev)
+                self_pos[:pi.shape[0]] = pi
+                mf_self = 12 * (TA * (TA + 1) // 2)
+                fwd_cpass = blk['cpass']
         else:
+            self_pos, mf_self = None, 0
             pj = pos[torch.as_tensor(blk['ants_j'], device=dev)]
             rows = torch.zeros(blk['rows_i'] + blk['rows_j'], 3, dtype=torch.float64, device=dev)
             rows[:pi.shape[0]] = pi
@@ -402,6 +422,7 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
             two_pass_mask[torch.as_tensor(slots, dtype=torch.int64, device=dev)] = 1.0
         blocks.append(dict(pos=rows, nrows=int(rows.shape[0]), cross=int(cross), mp=blk['mp'],
                            cpass=blk['cpass'], fwd_cpass=fwd_cpass, mf_fwd=mf_fwd, mf_bwd=mf_bwd,
+                           self_pos=self_pos, mf_self=mf_self,
                            direct=torch.as_tensor(blk['direct'].reshape(-1), device=dev),
                            conj=torch.as_tensor(blk['conj'].reshape(-1), device=dev)))
         mfma_fwd += mf_fwd

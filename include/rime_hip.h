@@ -146,9 +146,13 @@ int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* 
  *       (Nrows - cross rows), each zero-padded to a multiple of 32; supported (rows I, rows J): (32, 32),
  *       (32, 64), (64, 64), (128, 128); pair_direct[i*128 + j] = slot of baseline (I_i -> J_j),
  *       pair_conj[i*128 + j] = slot of baseline (J_j -> I_i), or -1
+ *   self block (forward only, cross == Nrows in {32, 64, 128}, psky_complex != 0): the diagonal block of one
+ *       group as the cross block of the group with ITSELF -- antpos [Nrows, 3] zero-padded, the tables of the
+ *       diagonal block (entries i < j); L and B images of the same antennas come from one evaluation of the
+ *       phase, only the upper-triangular tiles are contracted
  *   psky_complex: 0 = psky / gpsky is one real plane (st_p 1 or 2); +1 = interleaved complex (st_p == 2)
- *       handled in ONE pass (forward: cross blocks only -- a diagonal block returns RIME_EUNSUPPORTED and
- *       takes one call per real plane; the block must hold direct entries only); -1 = as +1 but the
+ *       handled in ONE pass (forward: cross and self blocks -- a diagonal block (cross = 0) returns
+ *       RIME_EUNSUPPORTED and takes one call per real plane; the block must hold direct entries only); -1 = as +1 but the
  *       block contracts conj(psky) (a block built with its groups swapped: conj entries only).  The
  *       backward writes both gradient planes from one pass for either block kind.
  * Forward blocks fill disjoint baseline slots of the slab workspace (every baseline must belong

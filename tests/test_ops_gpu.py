@@ -373,6 +373,35 @@ def test_fringe_sum_matrix_core_complex_single_pass(ops, Nant, orient, Npp, conj
     elif orient == 'down':
         assert all((c == -1) == bool(b['cross']) for c, b in zip(cp, geom.ant['blocks']))     # diagonal blocks: mixed tables
     _check_ant_path(ops, geom, psky, blvecs, zenaz, freqs, [0] * len(pairs), P, Ps, True, conj=conj)
+    if orient == 'up':
+        # diagonal blocks of 1, 2 or 4 row tiles run as triangular self-cross blocks in the complex forward
+        for b in geom.ant['blocks']:
+            if not b['cross']:
+                assert (b['self_pos'] is not None) == ((b['nrows'] + 31) // 32 in (1, 2, 4))
+                assert b['fwd_cpass'] == (1 if b['self_pos'] is not None else 0)
+
+
+@pytest.mark.parametrize('Nant,group', [(60, 32), (64, 64), (128, 128), (37, 128)])
+def test_fringe_sum_self_blocks_equal_two_real_passes(ops, Nant, group):
+    """complex psky, forward: a diagonal block as ONE self-cross pass (1 / 2 / 4 row tiles) against the two real-plane
+    passes of the diagonal kernel and against the fp64 oracle"""
+    ant, pairs, blvecs, freqs, zenaz, sdir, Ps = _ant_setup(ops, Nant, 2, 3, 700, 1.0, 0, orient='up')
+    rng = np.random.default_rng(9)
+    P = zenaz.shape[-1]
+    shape = (2, 1, 2, 3, P)
+    psky = torch.as_tensor(rng.normal(size=shape) * np.exp(-9.0 * rng.uniform(size=shape))
+                           + 1j * rng.normal(size=shape) * np.exp(-9.0 * rng.uniform(size=shape)))
+    out = []
+    for flag in (True, False):
+        ops.SELF_BLOCKS = flag
+        try:
+            geom = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, antpos=ant.cuda(), bl_ants=pairs, mfma=True, group=group)
+        finally:
+            ops.SELF_BLOCKS = True
+        diag = [b for b in geom.ant['blocks'] if not b['cross']]
+        assert all((b['self_pos'] is not None) == flag for b in diag) and diag
+        out.append(_check_ant_path(ops, geom, psky, blvecs, zenaz, freqs, [0] * len(pairs), P, Ps, True))
+    assert relmax(out[0], out[1]) < 3e-6
 
 
 def test_fringe_sum_full_size_properties(ops):
