@@ -605,12 +605,14 @@ fringe_ant_fwd_cross_kernel(AntArgs A)
 }
 
 // self blocks (complex psky): the diagonal block of TI x 32 antennas as a triangular cross block
+template <int TI> constexpr int self_threads() { return FwdShape<TI, TI, true, true>::NW * 64; }
+template <int TI> constexpr int self_minwaves() { return FwdShape<TI, TI, true, true>::NW == 8 ? 1 : 2; }
+
 template <int TI>
-__global__ void __launch_bounds__((cross_threads<TI, TI>()), (cross_minwaves<TI, TI>()))
+__global__ void __launch_bounds__((self_threads<TI>()), (self_minwaves<TI>()))
 fringe_ant_fwd_self_kernel(AntArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    static_assert(FwdShape<TI, TI, true, true>::NW == FwdShape<TI, TI, true>::NW, "launch bounds follow the cross shape");
     ant_fwd_dispatch<FwdShape<TI, TI, true, true>, false, true>(A, smem);
 }
 
@@ -1416,8 +1418,8 @@ static bool ant_common_ok(int Nrows, int cross, int Nbl, int Nt, int Nf, int Pst
     if (st_p != 1 && st_p != 2) return false;
     if (cplx != 0 && (cplx != 1 && cplx != -1)) return false;
     if (cplx != 0 && st_p != 2) return false;                      // complex psky: interleaved (re, im)
-    if (cross && cross == Nrows) {                                  // self block: complex psky, 32 / 64 / 128 rows
-        if (cplx == 0 || !(Nrows == 32 || Nrows == 64 || Nrows == 128)) return false;
+    if (cross && cross == Nrows) {                                  // self block: complex psky, 32 / 64 / 96 / 128 rows
+        if (cplx == 0 || !(Nrows == 32 || Nrows == 64 || Nrows == 96 || Nrows == 128)) return false;
     } else if (cross ? !cross_shape_ok(cross, Nrows - cross) : (Nrows <= 0 || Nrows > MF_NA)) return false;
     if (Nbl <= 0 || Nt <= 0 || Nt > 65535 || Nf <= 0 || Pstride <= 0 || Pstride % 64 != 0) return false;
     return sign == 1 || sign == -1;
@@ -1461,6 +1463,7 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
     } while (0)
         if (Nrows == 32) RIME_FWD_SELF(1);
         else if (Nrows == 64) RIME_FWD_SELF(2);
+        else if (Nrows == 96) RIME_FWD_SELF(3);
         else RIME_FWD_SELF(4);
 #undef RIME_FWD_SELF
         return check_launch();

@@ -125,7 +125,7 @@ class FringeGeometry:
 MFMA_MIN_ANTS = int(os.environ.get('RIME_MFMA_MIN_ANTS', '33'))   # 'auto' threshold (see _setup_antenna_path)
 MFMA_GROUP = 128          # antennas per group of the matrix-core path (4 x 4 tiles of 32)
 MFMA_MAX_ANTS = 2048      # table memory only: 136 blocks x 128 KB at 2048 antennas
-# complex psky, forward: diagonal blocks of 32 / 64 / 128 antenna rows whose baselines all have one orientation run as
+# complex psky, forward: diagonal blocks whose baselines all have one orientation run as
 # triangular self-cross blocks in ONE pass (RIME_SELF_BLOCKS=0: the two real-plane passes of the diagonal kernel)
 SELF_BLOCKS = os.environ.get('RIME_SELF_BLOCKS', '1') != '0'
 
@@ -401,7 +401,7 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
             mf_bwd = 12 * (TA * (TA + 1) // 2)
             cross, fwd_cpass = 0, 0                          # forward diagonal blocks: one real plane per call ...
             self_pos, mf_self = None, 0
-            if SELF_BLOCKS and TA in (1, 2, 4) and blk['cpass'] != 0:
+            if SELF_BLOCKS and blk['cpass'] != 0:
                 # ... unless psky is complex and every baseline has one orientation: then the block runs as the
                 # triangular cross block of the group with itself, ONE complex pass (rime_fringe_ant_fwd_block
                 # with cross == Nrows)

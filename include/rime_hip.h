@@ -146,7 +146,7 @@ int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* 
  *       (Nrows - cross rows), each zero-padded to a multiple of 32; supported (rows I, rows J): (32, 32),
  *       (32, 64), (64, 64), (128, 128); pair_direct[i*128 + j] = slot of baseline (I_i -> J_j),
  *       pair_conj[i*128 + j] = slot of baseline (J_j -> I_i), or -1
- *   self block (forward only, cross == Nrows in {32, 64, 128}, psky_complex != 0): the diagonal block of one
+ *   self block (forward only, cross == Nrows in {32, 64, 96, 128}, psky_complex != 0): the diagonal block of one
  *       group as the cross block of the group with ITSELF -- antpos [Nrows, 3] zero-padded, the tables of the
  *       diagonal block (entries i < j); L and B images of the same antennas come from one evaluation of the
  *       phase, only the upper-triangular tiles are contracted

@@ -377,13 +377,12 @@ def test_fringe_sum_matrix_core_complex_single_pass(ops, Nant, orient, Npp, conj
         # diagonal blocks of 1, 2 or 4 row tiles run as triangular self-cross blocks in the complex forward
         for b in geom.ant['blocks']:
             if not b['cross']:
-                assert (b['self_pos'] is not None) == ((b['nrows'] + 31) // 32 in (1, 2, 4))
-                assert b['fwd_cpass'] == (1 if b['self_pos'] is not None else 0)
+                assert b['self_pos'] is not None and b['fwd_cpass'] == 1
 
 
-@pytest.mark.parametrize('Nant,group', [(60, 32), (64, 64), (128, 128), (37, 128)])
+@pytest.mark.parametrize('Nant,group', [(60, 32), (64, 64), (128, 128), (37, 128), (90, 128)])
 def test_fringe_sum_self_blocks_equal_two_real_passes(ops, Nant, group):
-    """complex psky, forward: a diagonal block as ONE self-cross pass (1 / 2 / 4 row tiles) against the two real-plane
+    """complex psky, forward: a diagonal block as ONE self-cross pass (1 to 4 row tiles) against the two real-plane
     passes of the diagonal kernel and against the fp64 oracle"""
     ant, pairs, blvecs, freqs, zenaz, sdir, Ps = _ant_setup(ops, Nant, 2, 3, 700, 1.0, 0, orient='up')
     rng = np.random.default_rng(9)
