@@ -321,10 +321,10 @@ def all_reduce_grads(params, group=None, average=False):
         if p.grad.numel() * p.grad.element_size() < BUCKET_BYTES:
             small.setdefault((p.grad.dtype, p.grad.device), []).append(p)
             continue
-        work, finish = _reduce_one(p, group, average, world, False)
+        _, finish = _reduce_one(p, group, average, world, False)
         if finish is not None:
             finish()
-    for (dt, dev), ps in small.items():
+    for ps in small.values():
         real = [torch.view_as_real(p.grad.contiguous()) if p.grad.is_complex() else p.grad.contiguous() for p in ps]
         flat = torch.cat([r.reshape(-1) for r in real])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

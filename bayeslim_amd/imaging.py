@@ -75,7 +75,6 @@ def compute_P(geom, w, beam=None, D=None, contract=None):
       None     : P[f, p, q] = (P @ e_q)[f, p]: the unit maps through compute_Pm -- (Nf, P, P), small problems only
     """
     Nf, P = geom.Nf, geom.P
-    dev = geom.blvecs.device if hasattr(geom, 'blvecs') else w.device
     rdt = w.dtype
     if contract == 'diag':
         out = (w.sum(0) * torch.ones(Nf, dtype=rdt, device=w.device))[:, None].expand(Nf, P)
@@ -270,7 +269,7 @@ class VisMapper:
         quirk: VisMapper.make_map sums w Re(A^2) for 'A2w' (imaging.py:446-447) where compute_Pm / compute_P sum
         w |A|^2 (:619, :694); Re(A^2) = beam^2 cos(2 phase) is the dirty map of unit visibilities on DOUBLED
         baselines -- one more adjoint pass, no A."""
-        geom, geom2, beam, cut = op
+        geom, geom2, beam, _ = op
         Nf = self.Nfreqs
         wsum = (w.sum(0) * torch.ones(Nf, dtype=w.dtype, device=w.device))[:, None]      # (Nf, 1)
         if self.method == 'w':
