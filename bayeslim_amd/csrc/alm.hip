@@ -390,25 +390,42 @@ alm2pix_fwd_f16_kernel(const uint4* __restrict__ a_hi, const uint4* __restrict__
     load_b(0, bcur);
     fetch_a(0);
     for (int c0 = 0; c0 < Ncoeff; c0 += 32) {
+#if !defined(RIME_ALM_ABL) || RIME_ALM_ABL != 2
         __syncthreads();                               // previous chunk consumed
 #pragma unroll
         for (int u = 0; u < PT; ++u) { lds_hi[tid + u * 256] = ahq[u]; lds_lo[tid + u * 256] = alq[u]; }
         __syncthreads();
         if (c0 + 32 < Ncoeff) { load_b(c0 + 32, bnxt); fetch_a(c0 / 8 + 4); }
+#else
+        if (c0 + 32 < Ncoeff) { load_b(c0 + 32, bnxt); }
+#endif
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             uint4 bh, bl;
+#if defined(RIME_ALM_ABL) && RIME_ALM_ABL == 1
+            bh = make_uint4(__float_as_uint(bcur[ks * 4 + 0].x), __float_as_uint(bcur[ks * 4 + 1].x), __float_as_uint(bcur[ks * 4 + 2].x), __float_as_uint(bcur[ks * 4 + 3].x));
+            bl = make_uint4(__float_as_uint(bcur[ks * 4 + 0].y), __float_as_uint(bcur[ks * 4 + 1].y), __float_as_uint(bcur[ks * 4 + 2].y), __float_as_uint(bcur[ks * 4 + 3].y));
+#else
             split2h(bcur[ks * 4 + 0].x * y_scale, bcur[ks * 4 + 0].y * y_scale, bh.x, bl.x);
             split2h(bcur[ks * 4 + 1].x * y_scale, bcur[ks * 4 + 1].y * y_scale, bh.y, bl.y);
             split2h(bcur[ks * 4 + 2].x * y_scale, bcur[ks * 4 + 2].y * y_scale, bh.z, bl.z);
             split2h(bcur[ks * 4 + 3].x * y_scale, bcur[ks * 4 + 3].y * y_scale, bh.w, bl.w);
+#endif
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
+#if defined(RIME_ALM_ABL) && RIME_ALM_ABL == 2
+                const uint4 ah = make_uint4(m, ks, h, 1), al = make_uint4(ks, m, 2, h);
+#else
                 const int gi = (ks * 2 + h) * ROWS + m * 32 + (lane & 31);
                 const uint4 ah = lds_hi[gi], al = lds_lo[gi];
+#endif
+#if defined(RIME_ALM_ABL) && RIME_ALM_ABL == 3
+                acc[m][0] += __uint_as_float(ah.x ^ bh.x ^ al.y ^ bl.z ^ bh.w ^ bl.x ^ bh.y ^ bh.z ^ bl.y ^ bl.w);
+#else
                 acc[m] = ALM_MFMA(ah, bh, acc[m]);
                 acc[m] = ALM_MFMA(ah, bl, acc[m]);
                 acc[m] = ALM_MFMA(al, bh, acc[m]);
+#endif
             }
         }
 #pragma unroll
