@@ -444,7 +444,8 @@ def main():
                 # registration order = collective order; the hooks fire point sources, beam, sky (dist.grad_hook_order)
                 gsync = rdist.GradSync(shared=[p for p in params if id(p) not in pc], blocks=per_channel[::-1], bounds=bounds)
             else:
-                gsync = rdist.GradSync(shared=params)
+                # registration order = collective order: the sky gradient (the large one) is final last (dist.grad_hook_order)
+                gsync = rdist.GradSync(shared=params[1:] + params[:1])
         prof = []
         ops.PROFILE = prof
 
