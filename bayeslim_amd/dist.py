@@ -348,8 +348,9 @@ class GradSync:
       block parameters  [(param, axis)] + `bounds`      -> in-place all-gather of the per-rank blocks
     The registration order (shared, then blocks) is the order of the collectives on EVERY rank whatever order
     the hooks fire in: RCCL matches collectives by issue order, and ranks of a baseline-tile partition run
-    graphs of different shapes.  Un-armed backward passes (earlier time chunks of a pipelined step) only
-    accumulate.
+    graphs of different shapes.  After the first step the order in which the hooks actually fired replaces it, but
+    only if all ranks report the same one (`adapted`).  Un-armed backward passes (earlier time chunks of a
+    pipelined step) only accumulate.
     """
     def __init__(self, shared=(), blocks=(), bounds=None, group=None):
         self.group, self.bounds = group, bounds
@@ -360,6 +361,7 @@ class GradSync:
         self.armed = False
         self.pending, self.ready, self.next = [], set(), 0
         self.fired = []                     # entry indices in the order the hooks fired in the last armed backward
+        self.adapted = None                 # None: not decided yet; True / False after the first finish()
         self.hooks = [p.register_post_accumulate_grad_hook(self._hook) for p, _ in self.entries]
 
     def _launch(self, i):
@@ -395,6 +397,27 @@ class GradSync:
             if fin is not None:
                 fin()
         self.pending, self.ready, self.next = [], set(), 0
+        if self.adapted is None:
+            self._adopt_fired_order()
+
+    def _adopt_fired_order(self):
+        """after the first armed backward: if EVERY rank saw the hooks fire in the same order, make that order the
+        collective order from now on (a gradient then leaves the moment it is final instead of waiting for entries
+        registered before it); one tiny MIN / MAX all-reduce pair, once"""
+        n = len(self.entries)
+        order = list(dict.fromkeys(self.fired)) + [i for i in range(n) if i not in self.fired]
+        self.adapted = False
+        if n < 2 or not self.entries:
+            return
+        dev = self.entries[0][0].device
+        lo = torch.tensor(order, dtype=torch.int64, device=dev)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if torch.equal(lo, hi) and order != list(range(n)):
+            self.entries = [self.entries[i] for i in order]
+            self.index = {id(p): i for i, (p, _) in enumerate(self.entries)}
+            self.adapted = True
 
     def remove(self):
         for h in self.hooks:

@@ -501,7 +501,8 @@ def main():
         vis_bytes = len(bls) * nt * cfg['Nf'] * 8
         res = dict(shard=shard, label=label, dt=dt, prof=list(prof), vis_bytes=vis_bytes, grad_bytes=grad_bytes,
                    plan_load=None if plan is None else [round(x, 1) for x in plan['load']],
-                   hook_order=None if gsync is None else list(gsync.fired))
+                   hook_order=None if gsync is None else list(gsync.fired),
+                   order_adapted=None if gsync is None else gsync.adapted)
         del rime, params, attach
         torch.cuda.empty_cache()
         return res
@@ -601,7 +602,8 @@ def main():
                                all_gather_vis_bytes_per_step=best['vis_bytes'],
                                gradient_bytes_per_step=best['grad_bytes'],
                                tile_plan_load=best['plan_load'],
-                               grad_hook_order=best['hook_order'],     # registration indices in firing order (rank 0)
+                               grad_hook_order=best['hook_order'],     # collective-order indices in firing order (rank 0)
+                               grad_order_adapted=best['order_adapted'],   # the ranks agreed on the firing order and use it
                                overlap='vis all-gather of chunk k runs under the kernels of chunk k+1; gradient '
                                        'collectives start from autograd hooks inside the last backward')
             alts = [r for r in results if r is not best]

@@ -275,7 +275,23 @@ def _worker_hook_order(rank, world, port, q):
         loss.backward()
         fired = list(sync.fired)
         sync.finish()
-        q.put((rank, fired, a.grad.numpy().copy(), b.grad.numpy().copy(), c.grad.numpy().copy()))
+        assert sync.adapted is False                     # the ranks disagree: registration order stays
+        out = (rank, fired, a.grad.numpy().copy(), b.grad.numpy().copy(), c.grad.numpy().copy())
+        # same graph on both ranks, hooks fire b before a: that order is adopted after the first step
+        sync.remove()
+        for p in (a, b, c):
+            p.grad = None
+        sync2 = rdist.GradSync(shared=[a, b, c])
+        for step in range(2):
+            for p in (a, b, c):
+                p.grad = None
+            sync2.arm()
+            ((a * 3.0).sum() + (b * 5.0).sum()).backward()
+            sync2.finish()
+            assert sync2.adapted is True and [p is q_ for (p, _), q_ in zip(sync2.entries, (b, a, c))] == [True] * 3
+            assert torch.equal(a.grad, torch.full((300, 400), 6.0, dtype=torch.float64))
+            assert torch.equal(b.grad, torch.full((50,), 10.0, dtype=torch.float64))
+        q.put(out)
     finally:
         dist.destroy_process_group()
 
