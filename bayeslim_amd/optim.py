@@ -3,14 +3,16 @@ The likelihood epilogue of the RIME path -- the 
 optim.py that touches the visibility tensor right after RIME.forward: the residual, the inverse
 covariance weighting and the chi-square sum of LogProb.forward_chisq (optim.py:959-1030) with
 apply_icov (optim.py:1836-1915), and the LogProb container that drives RIME from an optimiser (optim.py:385-1389:
-minibatch iteration, main-parameter tensor, priors, closure) with the likelihood on the fused chi-square kernel.
-Optimisers, samplers, Hessians and the single-process DistributedLogProb (replaced by dist.py) are out of scope
+minibatch iteration, main-parameter tensor, priors, closure) with the likelihood on the fused chi-square kernel, and the
+Trainer loop around it (optim.py:1631-1833).  Optimisers, samplers, Hessians and the single-process DistributedLogProb (replaced by dist.py) are out of scope
 (SURVEY.md section 2).
 
 Only the diagonal inverse covariance (cov_axis=None) runs on the fused HIP kernel; the reference's
 'bl' / 'time' / 'freq' / 'pix' branches reference an undefined name (`d`, optim.py:1899-1913) and
 cannot run there either, and 'full' is a dense matrix product left to torch.
 """
+import time
+
 import numpy as np
 import torch
 
@@ -440,3 +442,77 @@ class LogProb(utils.Module):
 
     def clear_prior_cache(self):
         self.prior_cache = {}
+
+
+class Trainer:
+    """
+    The training loop around a LogProb (optim.py:1631-1833): `opt` a torch optimiser class (instantiated on
+    prob.parameters()) or instance; every epoch runs prob.Nbatch optimiser steps in 'stochastic' mode, one in
+    'accumulate' mode, each step calling prob.closure; losses, cumulative times and (optionally) the parameter
+    history are kept.
+    """
+    def __init__(self, prob, opt=None, track=False, track_params=None):
+        self.prob = prob
+        self._epoch_loss, self._epoch_times = [], []
+        self.track = track
+        self.set_opt(opt)
+        self.Nbatch = prob.Nbatch if prob.grad_type == 'stochastic' else 1
+        self.chain = {}
+        if track:
+            self.init_chain(track_params)
+
+    def init_chain(self, track_params=None):
+        """names (attributes of prob) whose values are recorded before every step: given, else the main-parameter
+        pieces, else every model parameter"""
+        if track_params is not None:
+            names = list(track_params)
+        elif self.prob.main_params is not None:
+            names = ['model.' + k for k in self.prob._main_names.values()]
+        else:
+            names = ['model.' + k for k, _ in self.prob.model.named_parameters()]
+        self.chain = {k: [] for k in names}
+
+    def set_opt(self, opt, *args, **kwargs):
+        if opt is not None:
+            self.opt = opt(self.prob.parameters(), *args, **kwargs) if isinstance(opt, type) else opt
+
+    def train(self, Nepochs=1, Nreport=None):
+        start = time.time()
+        for epoch in range(Nepochs):
+            t0 = time.time()
+            if Nreport is not None and epoch > 0 and epoch % Nreport == 0:
+                print("epoch {}, {:.1f} sec".format(epoch, time.time() - start))
+            self.opt.zero_grad()
+            L = 0
+            for _ in range(self.Nbatch):
+                if self.track:
+                    for k in self.chain:
+                        self.chain[k].append(self.prob[k].detach().clone())
+                L = L + self.opt.step(self.prob.closure)
+            self._epoch_loss.append(L / self.Nbatch)
+            self._epoch_times.append((self._epoch_times[-1] if self._epoch_times else 0.0) + (time.time() - t0))
+        return dict(duration=time.time() - start)
+
+    def get_chain(self, name=None, idx=None):
+        assert self.track
+        pick = (lambda c: torch.stack(c)) if idx is None else (lambda c: c[idx])
+        return pick(self.chain[name]) if name is not None else {k: pick(c) for k, c in self.chain.items()}
+
+    def revert_chain(self, Nepochs):
+        """step the tracked parameters back by Nepochs recorded states (the current state is not in the chain)"""
+        if self.track and Nepochs > 0:
+            for k in self.chain:
+                with torch.no_grad():
+                    self.prob[k] = self.chain[k][-Nepochs]
+                    self.chain[k] = self.chain[k][:-Nepochs]
+            self._epoch_loss = self._epoch_loss[:-Nepochs]
+            self._epoch_times = self._epoch_times[:-Nepochs]
+            self.prob.collect_main_params()
+
+    @property
+    def loss(self):
+        return torch.as_tensor(self._epoch_loss)
+
+    @property
+    def times(self):
+        return torch.as_tensor(self._epoch_times)

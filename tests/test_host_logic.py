@@ -547,3 +547,34 @@ def test_logprob_container_on_a_toy_model():
     u = optim.LogUniformPrior(torch.tensor(0.0), torch.tensor(2.0))
     # the normalisation is summed over the BOUNDS' shape (scalar bounds: once), as in the reference
     assert float(u(torch.tensor([0.5, 1.5]))) == float(np.log(0.5)) and float(u(torch.tensor([0.5, 2.5]))) == -np.inf
+
+
+def test_trainer_loop_and_chain():
+    """optim.Trainer (optim.py:1631-1833): epochs of optimiser steps on LogProb.closure, loss / time records, parameter
+    chain and revert"""
+    from bayeslim_amd import optim, dataset, utils
+
+    class Line(utils.Module):
+        def __init__(self):
+            super().__init__(name='line')
+            self.params = torch.nn.Parameter(torch.tensor([0.0, 0.0], dtype=torch.float64))
+
+        def forward(self, inp=None, prior_cache=None, **kw):
+            td = dataset.TensorData()
+            td.data = self.params[0] + self.params[1] * torch.arange(5, dtype=torch.float64)
+            return td
+
+    td = dataset.TensorData()
+    td.data = 1.0 + 2.0 * torch.arange(5, dtype=torch.float64)
+    prob = optim.LogProb(Line(), dataset.Dataset([td]), complex_circular=False)
+    tr = optim.Trainer(prob, torch.optim.SGD, track=True)
+    assert list(tr.chain) == ['model.params'] and tr.Nbatch == 1
+    tr.set_opt(torch.optim.SGD, lr=0.02)
+    info = tr.train(Nepochs=200)
+    assert info['duration'] > 0 and len(tr.loss) == 200 and tr.times[-1] >= tr.times[0]
+    assert float(tr.loss[-1]) < 1e-6 * float(tr.loss[0]) + 1e-9
+    assert torch.allclose(prob.model.params.detach(), torch.tensor([1.0, 2.0], dtype=torch.float64), atol=1e-3)
+    chain = tr.get_chain('model.params')
+    assert chain.shape == (200, 2) and torch.equal(chain[0], torch.zeros(2, dtype=torch.float64))
+    tr.revert_chain(150)
+    assert len(tr.loss) == 50 and torch.equal(prob.model.params.detach(), chain[50])
