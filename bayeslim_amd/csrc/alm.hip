@@ -174,6 +174,7 @@ alm2pix_fwd_mfma_kernel(const float* __restrict__ alm, const float* __restrict__
 #pragma unroll
         for (int cc = 0; cc < CT; ++cc) bcur[cc] = bnxt[cc];
     }
+    RIME_MFMA_SETTLE();
     const int col = j0 + (lane & 31);
     if (col < Npix) {
 #pragma unroll
@@ -261,6 +262,7 @@ alm2pix_bwd_mfma_kernel(const float* __restrict__ gout, const float* __restrict_
     }
     // D[row][col = (c,q)] -> part[split][r][c][q]
     const int c = c0 + (n >> 1);
+    RIME_MFMA_SETTLE();
     if (c < Ncoeff) {
         float* dst = part + (size_t)blockIdx.y * R * Ncoeff * 2;
 #pragma unroll
@@ -431,6 +433,7 @@ alm2pix_fwd_f16_kernel(const uint4* __restrict__ a_hi, const uint4* __restrict__
 #pragma unroll
         for (int u = 0; u < 16; ++u) bcur[u] = bnxt[u];
     }
+    RIME_MFMA_SETTLE();
     const int col = j0 + (lane & 31);
     if (col < Npix) {
         const float iy = 1.0f / y_scale;
@@ -555,6 +558,7 @@ alm2pix_bwd_f16_kernel(const uint4* __restrict__ g_hi, const uint4* __restrict__
             }
         }
     }
+    RIME_MFMA_SETTLE();
     if (c < Ncoeff) {
         float* dst = part + (size_t)split * R * Ncoeff * 2;
         const float iy = 1.0f / y_scale;
@@ -727,6 +731,7 @@ alm2pix_bwd_f16_dma_kernel(const uint4* __restrict__ g_hi, const uint4* __restri
         slot = slot + 1 == NSLOT ? 0 : slot + 1;
         nslot = nslot + 1 == NSLOT ? 0 : nslot + 1;
     }
+    RIME_MFMA_SETTLE();
     if (c < Ncoeff) {
         float* dst = part + (size_t)split * R * Ncoeff * 2;
         const float iy = 1.0f / y_scale;

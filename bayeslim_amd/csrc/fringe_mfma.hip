@@ -506,6 +506,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     float* dst = A.ws + (((size_t)split * A.Nt + t) * A.Nf + f) * 2 * A.Nbl;
     const float inv = 1.0f / scl;
     const int col = lane & 31;
+    RIME_MFMA_SETTLE();
     // the image buffers are free after the loop's last barrier: a private 32 x 33 float tile per wave
     // transposes the accumulators of diagonal-tile units (written and read by this wave only)
     float* tr = reinterpret_cast<float*>(smem) + W * (32 * 33);
@@ -895,6 +896,7 @@ __device__ __forceinline__ void ant_fwd_v2_body(const AntArgs& A, unsigned char*
     float* dst = A.ws + (((size_t)split * A.Nt + t) * A.Nf + f) * 2 * A.Nbl;
     const float inv = 1.0f / scl;
     const int col = lane & 31;
+    RIME_MFMA_SETTLE();
     float* tr = reinterpret_cast<float*>(smem) + W * (32 * 33);
 #pragma unroll
     for (int q = 0; q < NTW; ++q) {
@@ -1126,14 +1128,21 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                     }
                 }
                 // row tile tj is complete: contract with E_i of the same antennas (lane-local)
+                if constexpr (CPLX) RIME_MFMA_SETTLE();      // see rime_common.h: packed readers of fresh accumulators
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     part = fmaf(ec[e], accR[tj][e], part);
                     part = fmaf(es[e], accI[tj][e], part);
-                    if constexpr (CPLX) {
-                        parti = fmaf(es[e], accR[tj][e], parti);
-                        parti = fmaf(-ec[e], accI[tj][e], parti);
+                }
+                if constexpr (CPLX) {
+                    // the imaginary plane in chains of its own (fused with `part` the compiler emits v_pk_fma_f32)
+                    float pa = 0.f, pb = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        pa = fmaf(es[e], accR[tj][e], pa);
+                        pb = fmaf(ec[e], accI[tj][e], pb);
                     }
+                    parti += pa - pb;
                 }
             }
         }

@@ -461,6 +461,68 @@ def test_fringe_sum_full_size_properties(ops):
         assert float((ggot - gref).abs().max()) < 1e-4 * float(gx.abs().max())
 
 
+def test_fringe_sum_c5_size_complex_blocks_sampled_oracle(ops):
+    """BASELINE config 5's array and pixel count (512 stations / 130 816 baselines, 393 216 pixels, complex psky; 4 of
+    the 512 channels): every block kind of the complex single pass -- self blocks on the diagonal, (128, 128) cross
+    blocks -- against float64 sums of the defining formula for sampled visibilities and gradient entries, plus the
+    adjoint identity between the forward and backward kernels"""
+    rng = np.random.default_rng(12)
+    Nant, Nf, P = 512, 4, 393216
+    ant = rng.normal(0, 300.0, (Nant, 3)); ant[:, 2] = 0.0
+    pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
+    antp = T64(ant).cuda()
+    i1 = torch.as_tensor([a for a, _ in pairs], device='cuda')
+    i2 = torch.as_tensor([b for _, b in pairs], device='cuda')
+    blvecs = antp[i2] - antp[i1]
+    cz, az = rng.uniform(0, 1, P), rng.uniform(0, 2 * np.pi, P)
+    sz = np.sqrt(1 - cz ** 2)
+    sdir = T64(np.stack([sz * np.sin(az), sz * np.cos(az), cz])[None]).cuda()
+    freqs = torch.linspace(120e6, 121e6, Nf, dtype=torch.float64)
+    geom = ops.FringeGeometry(blvecs, sdir, freqs, antpos=antp, bl_ants=pairs)
+    blocks = geom.ant['blocks']
+    assert len(blocks) == 10 and sum(1 for b in blocks if b['self_pos'] is not None) == 4
+    assert all(b['fwd_cpass'] == 1 and b['cpass'] == 1 for b in blocks)
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    env = torch.exp(-9.0 * torch.rand(1, 1, 1, Nf, P, device='cuda', generator=gen))
+    x1 = torch.complex(torch.randn(1, 1, 1, Nf, P, device='cuda', generator=gen),
+                       torch.randn(1, 1, 1, Nf, P, device='cuda', generator=gen)) * env
+    x = x1.clone().requires_grad_(True)
+    v = ops.fringe_sum(x, geom)
+    assert v.shape == (1, len(pairs), 1, Nf)
+    scale = float(v.detach().abs().max())
+    srng = np.random.default_rng(4)
+    # one sampled baseline from every block: self blocks (same group) and cross blocks (different groups)
+    grp = lambda a: a // 128
+    want = {(gi, gj) for gi in range(4) for gj in range(gi, 4)}
+    bsel = []
+    for k in srng.permutation(len(pairs)):
+        key = (grp(pairs[k][0]), grp(pairs[k][1]))
+        if key in want:
+            want.discard(key)
+            bsel.append(int(k))
+        if not want:
+            break
+    bsel += srng.choice(len(pairs), 14, replace=False).tolist()
+    bsel = torch.as_tensor(bsel, device='cuda')
+    tau = blvecs[bsel] @ sdir[0]
+    ph = 2j * np.pi / 2.99792458e8 * freqs.cuda()[None, :, None] * tau[:, None, :]
+    ref = (torch.exp(ph) * x1[0, 0, 0].to(torch.complex128)[None]).sum(-1)              # (24, Nf)
+    assert float((v.detach()[0][bsel][:, 0] - ref).abs().max()) < 1e-5 * scale
+    G = torch.complex(torch.randn(v.shape, device='cuda', generator=gen), torch.randn(v.shape, device='cuda', generator=gen))
+    lhs = (v.detach() * G.conj()).real.double().sum()
+    (v * G.conj()).real.sum().backward()
+    rhs = (x.grad.conj() * x1).real.double().sum()
+    assert abs(float(lhs - rhs)) < 1e-4 * abs(float(lhs)) + 1e-6
+    psel = torch.as_tensor(srng.choice(P, 16, replace=False), device='cuda')
+    tau = blvecs @ sdir[0][:, psel]                                                     # (Nbl, 16)
+    gref = torch.zeros(Nf, 16, dtype=torch.complex128, device='cuda')
+    for f in range(Nf):                                                                 # grad = sum_b conj(F) g
+        ph = 2j * np.pi / 2.99792458e8 * float(freqs[f]) * tau
+        gref[f] = (torch.exp(ph).conj() * G[0][:, 0, f].to(torch.complex128)[:, None]).sum(0)
+    ggot = x.grad.detach()[0, 0, 0][:, psel]
+    assert float((ggot - gref).abs().max()) < 1e-4 * float(x.grad.abs().max())
+
+
 def test_fringe_sum_matrix_core_splits_and_degenerate_rows(ops):
     """MFMA path with several pixel splits (partial slabs + transposing reduction), an all-zero
     psky row (power-of-two scale of an empty row), an all-negative row (sign masks on every
