@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'librime_hip.so')
+LIB_PATH = os.environ.get('RIME_LIB_PATH') or os.path.join(_HERE, 'lib', 'librime_hip.so')   # override: lab builds only
 
 RIME_F32, RIME_F64 = 0, 1
 ERRORS = {-1: 'RIME_EINVAL (bad shape/flag/null pointer)', -2: 'RIME_EWORKSPACE (workspace too small)',

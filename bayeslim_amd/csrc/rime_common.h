@@ -27,12 +27,16 @@ inline int check_launch()
 // stale accumulator (wrong imaginary-plane gradients in a few hundred of 12 288 pixel tiles, different from run to run;
 // the high half -- the real plane -- was always right).  Epilogues that read accumulators therefore start with 16 more
 // wait states, fenced so that the scheduler keeps them between the last MFMA and the reads.
+#if defined(RIME_NO_SETTLE)          /* lab: measure what the margin costs */
+#define RIME_MFMA_SETTLE() do { } while (0)
+#else
 #define RIME_MFMA_SETTLE()                                   \
     do {                                                     \
         __builtin_amdgcn_sched_barrier(0);                   \
         asm volatile("s_nop 15" ::: "memory");               \
         __builtin_amdgcn_sched_barrier(0);                   \
     } while (0)
+#endif
 
 template <typename T> __device__ __forceinline__ T tfma(T a, T b, T c);
 template <> __device__ __forceinline__ float tfma<float>(float a, float b, float c) { return fmaf(a, b, c); }
