@@ -6,6 +6,8 @@ import os
 import re
 import ctypes
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -65,3 +67,23 @@ def test_bad_arguments_are_rejected_without_launching():
     ws = lib.rime_fringe_sum_workspace(0, 8128, 4, 256, 108032, 1, 1, 0, 0)
     assert ws % (8128 * 4 * 256 * 8) == 0 and ws > 0
     assert lib.rime_fringe_sum_workspace(0, 3, 2, 33, 9024, 1, 1, 0, 0) > 0
+
+
+@pytest.mark.parametrize('src', ['alm.hip', 'fringe_mfma.hip'])
+def test_no_packed_f32_reader_close_to_an_mfma(src, tmp_path):
+    """regression guard for the round-2 defect (rime_common.h, RIME_MFMA_SETTLE): in the gfx950 assembly of the
+    matrix-core sources no v_pk_*_f32 instruction reads an MFMA destination register within 24 wait states of the MFMA
+    (the failing kernel had 46 such readers, the closest at 13)"""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = str(tmp_path / (src + '.s'))
+    subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=fast', '-S', '--cuda-device-only',
+                    os.path.join(root, 'bayeslim_amd', 'csrc', src), '-o', asm], check=True, capture_output=True)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'scan_packed_readers.py'), asm, '24'],
+                         check=True, capture_output=True, text=True).stdout
+    assert out.startswith('no packed-f32 reader'), out
