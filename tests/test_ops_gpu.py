@@ -785,6 +785,68 @@ def test_beam_sky_product(ops, dtype, Nnn):
     assert float(out.detach().reshape(R, Nt, Ps)[:, 0, 150:].abs().max()) == 0.0
 
 
+def test_side_kernels_at_c4_size(ops):
+    """the HBM-bound kernels either side of the fringe sum at BASELINE config 4's sizes, float32 against the same
+    kernels in float64 (themselves pinned to the oracle at small sizes) and against torch compositions: the fused
+    beam-interpolate x cut-sky product with both gradients (256 channels, 2 times x 98 304 points, 32 760-node beam
+    grid, 196 608 sky pixels), the chi-square epilogue and the gain application on (1, 1, 8128, 8, 256) visibilities"""
+    from bayeslim_amd import calibration
+    gen = torch.Generator(device='cuda').manual_seed(7)
+    R, Npb, Npix, Nt, Ps, Nnn = 256, 32760, 196608, 2, 98304, 4
+    rng = np.random.default_rng(7)
+    cut = np.full((Nt, Ps), Npix, dtype=np.int64)
+    pos = np.full((Nt, Npix), -1, dtype=np.int64)
+    for t in range(Nt):
+        c = np.sort(rng.choice(Npix, Ps - 1000 * t, replace=False))
+        cut[t, :len(c)] = c
+        pos[t, c] = np.arange(len(c))
+    inds = torch.randint(0, Npb, (Nt * Ps, Nnn), device='cuda', generator=gen)
+    wgts = torch.rand(Nt * Ps, Nnn, device='cuda', generator=gen, dtype=torch.float64)
+    bmap = torch.randn(R, Npb, device='cuda', generator=gen, dtype=torch.float64)
+    sky = torch.randn(R, Npix, device='cuda', generator=gen, dtype=torch.float64)
+    gv = torch.randn(R, Nt * Ps, device='cuda', generator=gen, dtype=torch.float64)
+    cut_d = torch.as_tensor(cut.reshape(-1), dtype=torch.int32).cuda()
+    pos_d = torch.as_tensor(pos, dtype=torch.int32).cuda()
+    res = []
+    for rdt in (torch.float32, torch.float64):
+        st = ops.InterpStencil(inds, wgts.to(rdt), Npb)
+        b, s_ = bmap.to(rdt).requires_grad_(True), sky.to(rdt).requires_grad_(True)
+        out = ops.beam_sky_product(b, s_, st, cut_d, pos_d, Nt, Ps)
+        (out * gv.to(rdt)).sum().backward()
+        res.append((out.detach().double(), b.grad.double(), s_.grad.double()))
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
+    del res, bmap, sky, gv, inds, wgts
+    # chi-square and gain application on the headline visibility tensor
+    shape = (1, 1, 8128, 8, 256)
+    pred = torch.complex(torch.randn(shape, device='cuda', generator=gen), torch.randn(shape, device='cuda', generator=gen))
+    data = torch.complex(torch.randn(shape, device='cuda', generator=gen), torch.randn(shape, device='cuda', generator=gen))
+    icov = torch.rand(shape, device='cuda', generator=gen) + 0.5
+    x = pred.clone().requires_grad_(True)
+    c = ops.chisq(x, data, icov)
+    c.backward()
+    r64 = (pred - data).to(torch.complex128)
+    ref = float((r64.abs() ** 2 * icov.double()).sum())
+    assert abs(float(c.detach()) - ref) < 1e-5 * ref
+    assert float((x.grad - 2 * (pred - data) * icov).abs().max()) < 1e-5 * float(x.grad.abs().max())
+    Nant = 128
+    pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
+    g1 = torch.as_tensor([p[0] for p in pairs], device='cuda')
+    g2 = torch.as_tensor([p[1] for p in pairs], device='cuda')
+    gains = torch.complex(torch.randn(1, 1, Nant, 8, 256, device='cuda', generator=gen),
+                          torch.randn(1, 1, Nant, 8, 256, device='cuda', generator=gen))
+    cot = data
+    v, gn = pred.clone().requires_grad_(True), gains.clone().requires_grad_(True)
+    out, _ = calibration._apply_cal(v, gn, g1.int(), g2.int())
+    (out * cot.conj()).real.sum().backward()
+    v2, gn2 = pred.clone().requires_grad_(True), gains.clone().requires_grad_(True)
+    ref = gn2.index_select(2, g1) * v2 * gn2.index_select(2, g2).conj()
+    (ref * cot.conj()).real.sum().backward()
+    assert float((out - ref).detach().abs().max()) < 1e-5 * float(ref.detach().abs().max())
+    assert float((v.grad - v2.grad).abs().max()) < 1e-5 * float(v2.grad.abs().max())
+    assert float((gn.grad - gn2.grad).abs().max()) < 1e-4 * float(gn2.grad.abs().max())
+
+
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
 def test_alm2pix(ops, dtype):
     g = load_golden('sph_harm')
