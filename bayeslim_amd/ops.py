@@ -97,7 +97,7 @@ class FringeGeometry:
             self.uniform, self.df = 1, 0.0
         # antenna factorisation (matrix-core path): baselines given as antenna-index pairs
         self.ant = None
-        if ant_like is not None and ant_like.ant is not None and ant_like.Nbl == self.Nbl:
+        if mfma is not False and ant_like is not None and ant_like.ant is not None and ant_like.Nbl == self.Nbl:
             # same baseline set as an existing geometry (another time minibatch): share its pair tables
             per16 = self.Nt * self.Nf * (self.Pstride // 16) * 32768
             self.ant = dict(ant_like.ant, mfma_flops_fwd=per16 * ant_like.ant['mfma_fwd'],

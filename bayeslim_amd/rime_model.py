@@ -240,14 +240,14 @@ class RIME(utils.Module):
         # pair tables of the matrix-core path depend on the baseline group only: built once, shared by
         # the geometries of all time minibatches
         # (keyed on the antenna positions too: the blocks hold them)
-        lkey = (self.bl_group_id, av.data_ptr(), av._version)
+        lkey = (self.bl_group_id, av.data_ptr(), av._version, getattr(self, 'mfma_group', None), getattr(self, 'mfma_mode', 'auto'))
         like = self._ant_like.get(lkey)
         geom = ops.FringeGeometry(self._current_blvecs().detach().to(dev), sdir, self.freqs, bl_mp=bl_mp,
                                   Nmp=len(pairs), npix=[c.numel() for c in cuts],
                                   antpos=self.array.antvecs, bl_ants=bl_ants, ant_like=like, mp_pairs=pairs,
                                   group=getattr(self, 'mfma_group', None), mfma=getattr(self, 'mfma_mode', 'auto'))
         if like is None:
-            for k in [k for k in self._ant_like if k[0] == self.bl_group_id]:      # tables of superseded positions
+            for k in [k for k in self._ant_like if k[0] == self.bl_group_id and k[3:] == lkey[3:]]:      # tables of superseded positions
                 del self._ant_like[k]
             self._ant_like[lkey] = geom
         # for the fused psky builder: int32 cut and its inverse per time step
