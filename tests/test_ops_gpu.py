@@ -578,6 +578,48 @@ def test_fringe_sum_large_pixel_count_block_kinds(ops, group, nmodel):
         assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
 
 
+@pytest.mark.parametrize('world', [4, 8])
+def test_tile_shards_stitch_to_the_unsharded_result_at_c4_size(ops, world):
+    """dist.plan_tile_shards at the headline array (128 antennas, 8128 baselines, 98 304 pixels): every rank's shard
+    evaluated with the plan's block grouping on this GPU, stitched with the plan's inverse permutation, equals the
+    unsharded matrix-core result (visibilities; and the summed per-rank psky gradients the all-reduce would form)"""
+    from bayeslim_amd import dist as rdist
+    rng = np.random.default_rng(21)
+    Nant, Nf, P = 128, 8, 98304
+    ant = rng.normal(0, 120.0, (Nant, 3)); ant[:, 2] = 0.0
+    pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
+    antp = T64(ant).cuda()
+    blv = antp[torch.as_tensor([b for _, b in pairs], device='cuda')] - antp[torch.as_tensor([a for a, _ in pairs], device='cuda')]
+    cz, az = rng.uniform(0, 1, P), rng.uniform(0, 2 * np.pi, P)
+    sz = np.sqrt(1 - cz ** 2)
+    sdir = T64(np.stack([sz * np.sin(az), sz * np.cos(az), cz])[None]).cuda()
+    freqs = torch.linspace(150e6, 152e6, Nf, dtype=torch.float64)
+    gen = torch.Generator(device='cuda').manual_seed(8)
+    x0 = torch.randn(1, 1, 1, Nf, P, device='cuda', generator=gen)
+    full = ops.FringeGeometry(blv, sdir, freqs, antpos=antp, bl_ants=pairs, mfma=True)
+    x = x0.clone().requires_grad_(True)
+    v_full = ops.fringe_sum(x, full)
+    G = torch.complex(torch.randn(v_full.shape, device='cuda', generator=gen), torch.randn(v_full.shape, device='cuda', generator=gen))
+    (v_full * G.conj()).real.sum().backward()
+    plan = rdist.plan_tile_shards(pairs, Nant, world)
+    assert sorted(i for r in plan['rank_bls'] for i in r) == list(range(len(pairs)))
+    inv = torch.as_tensor(plan['inverse'], device='cuda')
+    parts, gsum = [], torch.zeros_like(x0)
+    for r in range(world):
+        sel = torch.as_tensor(plan['rank_bls'][r], device='cuda')
+        geom = ops.FringeGeometry(blv[sel], sdir, freqs, antpos=antp, bl_ants=[pairs[i] for i in plan['rank_bls'][r]],
+                                  mfma=True, group=plan['group'])
+        assert geom.ant is not None and len(geom.ant['blocks']) == plan['nblocks'][r]
+        xr = x0.clone().requires_grad_(True)
+        vr = ops.fringe_sum(xr, geom)
+        (vr * G[:, sel].conj()).real.sum().backward()
+        parts.append(vr.detach())
+        gsum += xr.grad
+    stitched = torch.cat(parts, dim=1).index_select(1, inv)
+    assert float((stitched - v_full.detach()).abs().max()) < 3e-6 * float(v_full.detach().abs().max())
+    assert float((gsum - x.grad).abs().max()) < 1e-5 * float(x.grad.abs().max())
+
+
 def test_alm2pix_c3_size_against_float64(ops):
     """alm2pix at the C3 shape (128 rows, lmax 128 -> 8385 coefficients, 49 152 pixels): the f16-split matrix-core
     kernels (forward, LDS-DMA backward) against the float64 kernels on every entry, and run-to-run identity"""
