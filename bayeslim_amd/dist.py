@@ -126,6 +126,8 @@ def plan_tile_shards(bl_ants, Nant, world_size, bl_mp=None, ant_model=None, grou
             if best is None or max(load) < 0.98 * max(best['load']):
                 rank_bls = [sorted(int(i) for k in owner[r] for i in items[k][1]) for r in range(world_size)]
                 best = dict(group=g, rank_bls=rank_bls, load=load, nblocks=[len(o) for o in owner], slabs=slabs)
+    if best is None or min(len(b) for b in best['rank_bls']) == 0:
+        return None                                    # fewer blocks than ranks: the caller falls back to contiguous blocks
     order = np.asarray([i for bl in best['rank_bls'] for i in bl], dtype=np.int64)
     assert len(order) == len(bl_ants) and len(set(order.tolist())) == len(order)
     inverse = np.empty_like(order)
@@ -348,11 +350,14 @@ class GradSync:
       block parameters  [(param, axis)] + `bounds`      -> in-place all-gather of the per-rank blocks
     The registration order (shared, then blocks) is the order of the collectives on EVERY rank whatever order
     the hooks fire in: RCCL matches collectives by issue order, and ranks of a baseline-tile partition run
-    graphs of different shapes.  After the first step the order in which the hooks actually fired replaces it, but
-    only if all ranks report the same one (`adapted`).  Un-armed backward passes (earlier time chunks of a
-    pipelined step) only accumulate.
+    graphs of different shapes.  That order must therefore be the SAME on every rank: the constructor proves it
+    (`verify`: one all-gather of a digest of the planned sequence -- kind, shape, dtype, axis and block bounds of
+    every entry -- and a RuntimeError on EVERY rank when the digests differ; under RCCL a mismatch would otherwise be
+    a hang or a silent sum of unrelated buffers).  After the first step the order in which the hooks actually fired
+    replaces it, but only if all ranks report the same one (`adapted`, again an explicit exchange).  Un-armed backward
+    passes (earlier time chunks of a pipelined step) only accumulate.
     """
-    def __init__(self, shared=(), blocks=(), bounds=None, group=None):
+    def __init__(self, shared=(), blocks=(), bounds=None, group=None, verify=True):
         self.group, self.bounds = group, bounds
         self.shared = [p for p in shared if p is not None]
         self.blocks = list(blocks)
@@ -362,7 +367,30 @@ class GradSync:
         self.pending, self.ready, self.next = [], set(), 0
         self.fired = []                     # entry indices in the order the hooks fired in the last armed backward
         self.adapted = None                 # None: not decided yet; True / False after the first finish()
+        if verify:
+            self.verify()
         self.hooks = [p.register_post_accumulate_grad_hook(self._hook) for p, _ in self.entries]
+
+    def plan_digest(self):
+        """64-bit digest of the planned collective sequence (what RCCL will be asked to do, in order)"""
+        import hashlib
+        desc = repr([('reduce' if ax is None else 'gather%d' % ax, tuple(p.shape), str(p.dtype)) for p, ax in self.entries]
+                    + [None if self.bounds is None else [tuple(b) for b in self.bounds]])
+        return int.from_bytes(hashlib.sha256(desc.encode()).digest()[:8], 'big') >> 1        # fits int64
+
+    def verify(self):
+        """every rank must plan the same collectives in the same order; raises on ALL ranks otherwise"""
+        world = dist.get_world_size(self.group)
+        if world == 1 or not self.entries:
+            return
+        dev = self.entries[0][0].device
+        mine = torch.tensor([self.plan_digest(), len(self.entries)], dtype=torch.int64, device=dev)
+        every = torch.empty(world * 2, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(every, mine, group=self.group)
+        every = every.view(world, 2).cpu()
+        if not bool((every == every[0]).all()):
+            raise RuntimeError('GradSync: the ranks plan different gradient collectives (digest, entries per rank: %s); '
+                               'register the parameters in the same order on every rank' % every.tolist())
 
     def _launch(self, i):
         p, ax = self.entries[i]

@@ -328,6 +328,78 @@ def cpu_baseline(inp, nbl_sample=48):
                 seconds=dts[8] + dts[16])
 
 
+
+# ---------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` invoked plainly: start N fresh rank processes (one per GPU)
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(nproc, script_argv, env=None, timeout=None, out=None):
+    """
+    Run `script_argv` (a script path + its arguments) as `nproc` rank processes through
+    `python -m torch.distributed.run` (one node, rendezvous on 127.0.0.1, a free port) as CHILD
+    processes of this one, which never touches the GPU itself.  Returns (exit code, the ONE JSON
+    result line rank 0 printed, or None).  Non-zero exit code when the launcher or any rank failed,
+    when the ranks did not finish within `timeout` seconds (the whole process group is killed), or
+    when no result line / a result for a different world size came back.  Everything else the
+    children write to stdout is passed on to stderr.  The replaced pattern is the reference's
+    single-process device loop (optim.py:1539-1566).
+    """
+    import signal
+    import subprocess
+    env = dict(os.environ if env is None else env)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK'):
+        env.pop(k, None)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cpus() // int(nproc))))
+    port = _free_port()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(int(nproc)),
+           '--master-addr', '127.0.0.1', '--master-port', str(port)] + list(script_argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=timeout)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        # the ranks are this launcher's own process group (start_new_session): end exactly that group
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+            try:
+                proc.wait(timeout=15)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        stdout, _ = proc.communicate()
+        sys.stderr.write('bench.py launcher: %d ranks did not finish within %s s; killed\n' % (nproc, timeout))
+        rc = 124
+    line = None
+    for ln in stdout.decode(errors='replace').splitlines():
+        try:
+            obj = json.loads(ln)
+        except ValueError:
+            obj = None
+        if isinstance(obj, dict) and 'metric' in obj and 'value' in obj:
+            line = ln
+            if rc == 0 and obj.get('n_gpus') != int(nproc):
+                sys.stderr.write('bench.py launcher: result reports n_gpus=%r, expected %d\n' % (obj.get('n_gpus'), nproc))
+                rc = 3
+        elif ln.strip():
+            sys.stderr.write(ln + '\n')
+    if rc == 0 and line is None:
+        sys.stderr.write('bench.py launcher: the ranks exited 0 but printed no result line\n')
+        rc = 4
+    if rc != 0:
+        line = None if rc in (3, 4, 124) else line
+    if out is not None and line is not None and rc == 0:
+        out.write(line + '\n')
+        out.flush()
+    return rc, line
+
+
 # ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -348,6 +420,15 @@ def main():
                     help='N > 1: time chunks per step (the all-gather of one chunk overlaps the kernels of the next)')
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher around it: become the launcher.  Decided BEFORE anything touches the
+    # GPU (no torch.cuda call yet); the ranks are fresh child processes, this process only relays the result
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        rc, _ = launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:],
+                             timeout=float(os.environ.get('BENCH_LAUNCH_TIMEOUT', '1500')), out=sys.stdout)
+        raise SystemExit(rc)
+
     # stdout carries exactly ONE JSON line: libraries that chat on fd 1 (RCCL's version banner, gloo's
     # connection notes) are sent to stderr for the whole run, the result goes to the saved descriptor
     t_start = time.perf_counter()
@@ -357,11 +438,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: bayeslim_amd has no CPU path')
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     # BENCH_DEVICE / BENCH_BACKEND exist only to rehearse the N > 1 code path on a one-GPU box
     # (all ranks on device 0 over gloo); the driver's runs use one rank per GPU over RCCL
     devidx = int(os.environ.get('BENCH_DEVICE', local_rank))
+    if devidx >= torch.cuda.device_count():              # counting devices does not initialise the GPU
+        raise SystemExit('bench.py: rank %d needs GPU %d but %d device(s) are visible (--gpus %d = one rank per GPU)'
+                         % (rank, devidx, torch.cuda.device_count(), args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: bayeslim_amd has no CPU path')
     torch.cuda.set_device(devidx)
     dev = torch.device('cuda', devidx)
     import torch.distributed as dist
@@ -371,11 +457,17 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         import datetime
-        # 'nccl' == RCCL on ROCm; device chosen above.  A collective that does not complete within 10 minutes aborts the
-        # job instead of hanging it (the steps of every workload here take seconds)
+        # 'nccl' == RCCL on ROCm; device chosen above.  The rendezvous gets minutes (the first `import torch` on a fresh
+        # box pages the image in, ranks arrive staggered); after the first barrier the watchdog drops to
+        # BENCH_COLLECTIVE_TIMEOUT seconds (default 60; a step of any workload here takes < 6 s), so a collective that some
+        # rank never joins aborts the job within a minute instead of hanging it
         kw = dict(device_id=dev) if backend == 'nccl' else {}        # bind the communicator to this rank's GPU up front
         dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10), **kw)
-    assert world == args.gpus or world == 1, 'launch N ranks with torch.distributed.run for --gpus N'
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit('bench.py: %d ranks joined, --gpus %d asked for' % (dist.get_world_size(), args.gpus))
+        dist.barrier()
+        from torch.distributed import distributed_c10d as _c10d
+        _c10d._set_pg_timeout(datetime.timedelta(seconds=float(os.environ.get('BENCH_COLLECTIVE_TIMEOUT', '60'))))
 
     from bayeslim_amd import ops, dist as rdist
 
@@ -522,11 +614,9 @@ def main():
         k[3] += mflops
     roof = None
     if kstat:
-        # dominant kernel = largest total time; forward and backward fringe kernels are within 1-2 % of each other at
-        # C4 and trade places from box to box, so kernels within 3 % of the longest are ranked by the work they
-        # execute (the backward: no symmetric folding of the diagonal tiles) -- a stable choice, both are listed below
-        tmax = max(v[1] for v in kstat.values())
-        dom = max((nm for nm in kstat if kstat[nm][1] >= 0.97 * tmax), key=lambda nm: (kstat[nm][3], kstat[nm][2], kstat[nm][1]))
+        # dominant kernel = the one with the largest total time over the timed region, nothing else; the hot kernel with
+        # the LOWEST fraction of its roof is named beside it (min_frac_kernel / min_frac)
+        dom = max(kstat, key=lambda nm: kstat[nm][1])
         n, ms, elems, mflops = kstat[dom]
         flop_per_elem = 10.0                 # 6 (phase rotation) + 4 (real psky accumulate), SURVEY 8(d)
         algorithmic = elems * flop_per_elem / (ms * 1e-3) / 1e12
@@ -545,7 +635,7 @@ def main():
         # committed summary of separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over this same
         # command is quoted when one exists for the workload (else null) and its path is given
         traffic, traffic_source = None, None
-        for rel in ('profiles/r02/traffic.json', 'profiles/r01/traffic.json'):
+        for rel in ('profiles/r03/traffic.json', 'profiles/r02/traffic.json', 'profiles/r01/traffic.json'):
             tpath = os.path.join(ROOT, rel)
             if args.workload == 'c4' and world == 1 and not args.nf and os.path.exists(tpath):
                 try:
@@ -557,20 +647,36 @@ def main():
                     break
         # the chip holds ~1.75 GHz of its 2.4 GHz under this load (GRBM_GUI_ACTIVE / kernel time in the committed PMC
         # summary): the same executed rate against the peak AT THAT CLOCK, as information only
-        clock = None
-        cpath = os.path.join(ROOT, 'profiles', 'r02', 'pmc_summary.json')
-        if mflops > 0 and args.workload == 'c4' and os.path.exists(cpath):
-            try:
-                pm = json.load(open(cpath))
-                clock = next((v.get('clock_GHz') for k, v in pm.items() if k.startswith(dom) and v.get('clock_GHz')), None)
-            except Exception:
-                clock = None
+        clock, clock_src = None, None
+        for rel in ('profiles/r03/pmc_summary.json', 'profiles/r02/pmc_summary.json'):
+            cpath = os.path.join(ROOT, rel)
+            if clock is None and mflops > 0 and args.workload == 'c4' and os.path.exists(cpath):
+                try:
+                    pm = json.load(open(cpath))
+                    clock = next((v.get('clock_GHz') for k, v in pm.items() if k.startswith(dom) and v.get('clock_GHz')), None)
+                    clock_src = rel
+                except Exception:
+                    clock = None
+        # every kernel's fraction of ITS roof (f16 MFMA peak on executed flops / fp32 peak on algorithmic flops)
+        per_kernel = {k: dict(launches=v[0], total_ms=round(v[1], 3),
+                              **({'executed_tflops': round(v[3] / (v[1] * 1e-3) / 1e12, 2),
+                                  'frac': round(v[3] / (v[1] * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4),
+                                  'useful_tflops': round(v[2] * 8.0 / (v[1] * 1e-3) / 1e12, 2)} if v[3] > 0 else
+                                 {'algorithmic_tflops': round(v[2] * flop_per_elem / (v[1] * 1e-3) / 1e12, 2),
+                                  'frac': round(v[2] * flop_per_elem / (v[1] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}))
+                      for k, v in kstat.items()}
+        hot = [k for k in kstat if kstat[k][1] >= 0.10 * kstat[dom][1]]      # kernels that matter for the step time
+        worst = min(hot, key=lambda k: per_kernel[k]['frac'])
         roof = dict(bound=bound, kernel=dom, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
-                    frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source, pipe=pipe,
+                    frac=round(achieved / peak, 4),
+                    min_frac_kernel=worst, min_frac=per_kernel[worst]['frac'],
+                    min_frac_note='lowest fraction of its roof among the kernels with >= 10 % of the dominant kernel\'s time',
+                    traffic=traffic, traffic_source=traffic_source, pipe=pipe,
                     sustained_clock_GHz=None if clock is None else round(clock, 3),
                     frac_of_peak_at_sustained_clock=None if clock is None else round(achieved / (peak * clock / 2.4), 4),
-                    sustained_clock_source=None if clock is None else 'profiles/r02/pmc_summary.json (separate PMC pass, not this run)',
+                    sustained_clock_source=None if clock is None else clock_src + ' (separate PMC pass, not this run)',
                     useful_tflops=round(useful, 2),
+                    useful_frac_of_pipe_peak=round(useful / peak, 4),
                     useful_note='8 flop (one complex MAC) per antenna pair x pixel x channel x time; the fp32 vector / matrix '
                                 'peak that bounds an exact-f32 contraction is %.1f TFLOP/s' % FP32_PEAK_TFLOPS,
                     algorithmic_tflops=round(algorithmic, 2),
@@ -579,18 +685,13 @@ def main():
                     hbm_equiv_frac=round(elems * 16.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
                     note='algorithmic = 10 flop per fringe element (SURVEY 8d) of the baseline formulation; '
                          'hbm_equiv_frac = 16 B per fringe element of the unfused formulation / 8 TB/s',
-                    kernels={k: dict(launches=v[0], total_ms=round(v[1], 3),
-                                     **({'executed_tflops': round(v[3] / (v[1] * 1e-3) / 1e12, 2),
-                                         'frac': round(v[3] / (v[1] * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4)} if v[3] > 0 else
-                                        {'algorithmic_tflops': round(v[2] * flop_per_elem / (v[1] * 1e-3) / 1e12, 2),
-                                         'frac': round(v[2] * flop_per_elem / (v[1] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}))
-                             for k, v in kstat.items()})
+                    kernels=per_kernel)
 
     if rank == 0:
         nvis = len(bls) * nt * cfg['Nf']
         mfma_run = bool(kstat) and max(kstat, key=lambda n: kstat[n][1]).startswith('fringe_ant')
         out = dict(metric='visibilities/sec (Nbl x Ntime x Nfreq) fwd+bwd', value=nvis * args.steps / dt,
-                   unit='vis/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   unit='vis/s', n_gpus=(dist.get_world_size() if distributed else 1), steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='strong',
                    vs_baseline=None,
                    dtype=('f32 (fringe sum: f16x3 split operands on the f16 MFMA -- 22-bit operands, f32 accumulate; '

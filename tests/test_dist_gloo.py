@@ -315,6 +315,61 @@ def test_grad_sync_collective_order_is_rank_invariant():
         assert np.array_equal(gc, np.zeros((4, 6)))
 
 
+def _worker_misordered(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import datetime
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        a = torch.nn.Parameter(torch.zeros(300, 400, dtype=torch.float64))
+        b = torch.nn.Parameter(torch.zeros(50, dtype=torch.float64))
+        order = [a, b] if rank == 0 else [b, a]              # rank 1 registers the collectives the other way round
+        try:
+            rdist.GradSync(shared=order)
+            q.put((rank, 'no error'))
+        except RuntimeError as e:
+            q.put((rank, 'raised: ' + str(e)))
+        # same order, but rank 1 plans different block bounds for a block parameter
+        c = torch.nn.Parameter(torch.zeros(1, 1, 8, 5, dtype=torch.float64))
+        bounds = [(0, 4), (4, 8)] if rank == 0 else [(0, 3), (3, 8)]
+        try:
+            rdist.GradSync(shared=[b], blocks=[(c, 2)], bounds=bounds)
+            q.put((rank, 'no error'))
+        except RuntimeError as e:
+            q.put((rank, 'raised: ' + str(e)))
+        # and an identical plan passes
+        rdist.GradSync(shared=[a, b], blocks=[(c, 2)], bounds=[(0, 4), (4, 8)]).remove()
+        q.put((rank, 'ok'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_sync_misordered_rank_raises_instead_of_hanging():
+    """a rank that registers its gradient collectives in another order (or with other block bounds) makes the
+    constructor raise on EVERY rank; under RCCL the mismatch would be a hang"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_misordered, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(3 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        mine = [m for r, m in res if r == rank]
+        assert mine[0].startswith('raised: GradSync: the ranks plan different') and mine[1].startswith('raised:'), mine
+        assert mine[2] == 'ok'
+
+
+def test_tile_shard_plan_falls_back_when_a_rank_would_be_empty():
+    """hex-37 over 8 ranks has fewer blocks than ranks: no plan (callers use contiguous baseline blocks)"""
+    pairs = [(i, j) for i in range(37) for j in range(i + 1, 37)]
+    assert rdist.plan_tile_shards(pairs, 37, 8) is None
+    assert rdist.plan_tile_shards(pairs, 37, 2) is not None
+
+
 def _toy_logprob(shard, nshard):
     """LogProb over a shard of a 6-visibility toy problem with two minibatches (shard None: the whole problem)"""
     from bayeslim_amd import optim, dataset, utils
