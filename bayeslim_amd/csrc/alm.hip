@@ -886,12 +886,16 @@ static hipError_t launch_bwd_dma(dim3 grid, hipStream_t st, const uint4* hi, con
     const int NB = S * CT * RT;
     grid = dim3(8 * ((NB + 7) / 8));
     constexpr int LDS = BwdDma<MT, KS, NSLOT>::LDS;
-    static bool configured = false;
-    if (!configured) {
+    // the attribute belongs to the (function, device) pair: remembered per device of the calling thread
+    static unsigned long long configured = 0ull;
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) devid = 0;
+    const unsigned long long bit = 1ull << (devid & 63);
+    if (!(configured & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&alm2pix_bwd_f16_dma_kernel<MT, KS, NSLOT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured |= bit;
     }
     hipLaunchKernelGGL((alm2pix_bwd_f16_dma_kernel<MT, KS, NSLOT>), grid, dim3(256), LDS, st, hi, lo, inv, Y, zero16, ys, R, Rpad,
                        Ncoeff, Npix, S, CT, RT, part);

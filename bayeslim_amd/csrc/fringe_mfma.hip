@@ -1128,7 +1128,7 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                     }
                 }
                 // row tile tj is complete: contract with E_i of the same antennas (lane-local)
-                if constexpr (CPLX) RIME_MFMA_SETTLE();      // see rime_common.h: packed readers of fresh accumulators
+                RIME_MFMA_SETTLE();                          // see rime_common.h: packed readers of fresh accumulators
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     part = fmaf(ec[e], accR[tj][e], part);
@@ -1284,11 +1284,15 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
                 __builtin_amdgcn_sched_barrier(0);      // keep the live ranges of one K step apart
             }
         }
-        // contraction with E_i of group I: the D rows this lane holds
+        // contraction with E_i of group I: the D rows this lane holds.  As in the diagonal kernel: a margin before
+        // the first accumulator read, and the imaginary plane in chains of its own (pa, pb) so that the compiler
+        // has no (part, parti) pair to fuse into packed f32 operations (rime_common.h)
+        RIME_MFMA_SETTLE();
         float part = 0.f, parti = 0.f;
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
             if (ti >= TI) continue;                                     // uniform
+            float pa = 0.f, pb = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int an = 32 * ti + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -1298,11 +1302,12 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
                 part = fmaf(ce, accR[ti][e], part);
                 part = fmaf(se, accI[ti][e], part);
                 if constexpr (CPLX) {
-                    parti = fmaf(se, accR[ti][e], parti);
-                    parti = fmaf(-ce, accI[ti][e], parti);
+                    pa = fmaf(se, accR[ti][e], pa);
+                    pb = fmaf(ce, accI[ti][e], pb);
                 }
                 if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (CPLX) parti += pa - pb;
         }
         part += __shfl_xor(part, 32, 64);
         if constexpr (CPLX) parti += __shfl_xor(parti, 32, 64);

@@ -171,14 +171,15 @@ class RIME(utils.Module):
     def _zenaz(self, key, time, ra, dec, dev):
         src = self.telescope.conv_cache.get(key)
         hit = self._zenaz_cache.get(key)
-        if hit is not None and hit[0] == id(src) and src is not None:
+        if hit is not None and hit[0] is src and src is not None:
             return hit[1]
         angs = self.telescope.eq2top(time, ra, dec, store=self.cache_eq2top, key=key)
         zen = torch.as_tensor(angs[0]).to(device=dev, dtype=torch.float64)
         az = torch.as_tensor(angs[1]).to(device=dev, dtype=torch.float64)
-        # remembered together with the identity of the conv_cache entry it came from: replacing that
-        # entry (new coordinates for the same key) is seen on the next forward
-        self._zenaz_cache[key] = (id(self.telescope.conv_cache.get(key)), (zen, az))
+        # remembered together with the conv_cache entry it came from (the OBJECT, held alive here, compared with
+        # `is`: an id() alone can be handed to a new entry after clear_cache()): replacing that entry (new
+        # coordinates for the same key) is seen on the next forward
+        self._zenaz_cache[key] = (self.telescope.conv_cache.get(key), (zen, az))
         return zen, az
 
     def _batch_geometry(self, name, ra, dec, Npix, dev, pairs, bl_mp):
@@ -254,8 +255,11 @@ class RIME(utils.Module):
         pos = torch.full((Nt, Npix), -1, dtype=torch.int32, device=dev)
         for j, cut in enumerate(cuts):
             pos[j, cut] = torch.arange(cut.numel(), dtype=torch.int32, device=dev)
+        # `alive`: the objects whose addresses the key is made of stay referenced for as long as the entry lives, so
+        # neither CPython nor the caching allocator can hand the same id() / data_ptr() to a successor
         bg = dict(zen=zen_all, az=az_all, cut=cut_all, geom=geom, Nt=Nt, Ps=Ps,
-                  cut32=cut_all.to(torch.int32), pos=pos)
+                  cut32=cut_all.to(torch.int32), pos=pos,
+                  alive=(av, fq, tuple(cc.get((name, Npix, float(t))) for t in self.sim_times)))
         self._geom_cache[gkey] = bg
         return bg
 

@@ -578,3 +578,27 @@ def test_trainer_loop_and_chain():
     assert chain.shape == (200, 2) and torch.equal(chain[0], torch.zeros(2, dtype=torch.float64))
     tr.revert_chain(150)
     assert len(tr.loss) == 50 and torch.equal(prob.model.params.detach(), chain[50])
+
+
+def test_astrometry_host_chain_against_the_independent_oracle():
+    """the product's numpy float64 chain (astrometry.icrs_to_topo: what host tensors take, and what the device kernel
+    is compared with to 1e-10 deg) against oracle/eq2top_oracle.py -- independent factorisation, pinned end to end
+    to SOFA's atci13 / atio13 / atco13 known answers (tests/test_oracle_golden.py).  20 mas on the sky."""
+    import numpy as np
+    from bayeslim_amd import astrometry as A
+    from oracle import eq2top_oracle as E
+    rng = np.random.default_rng(0)
+    ra = rng.uniform(0, 360, 5000)
+    dec = np.rad2deg(np.arcsin(rng.uniform(-1, 1, 5000)))
+    for loc in [(21.42827, -30.72148, 1050.0), (-107.6, 34.08, 2124.0)]:
+        for jd, dut1 in [(2459861.37, -0.02), (2451545.0, 0.3), (2462000.25, 0.0)]:
+            zen, az = A.icrs_to_topo(loc, jd, ra, dec, dut1=dut1)
+            z2, a2 = E.eq2top(loc, jd, ra, dec, dut1)
+            da = np.abs(az - a2)
+            da = np.minimum(da, 360 - da) * np.sin(np.deg2rad(zen))
+            assert np.abs(zen - z2).max() * 3600 < 0.020 and da.max() * 3600 < 0.020
+    # a bare LST rotation (round 1's stand-in) is 0.3 deg away from the same oracle: the tolerance has teeth
+    from bayeslim_amd import telescope_model
+    zen, az = telescope_model.eq2top((21.42827, -30.72148), 2459861.37, ra, dec)
+    z2, _ = E.eq2top((21.42827, -30.72148, 0.0), 2459861.37, ra, dec)
+    assert np.abs(np.asarray(zen) - z2).max() > 0.1

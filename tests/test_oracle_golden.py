@@ -5,7 +5,9 @@ reference (tests/golden/make_golden.py).  float64 throughout; tolerances are rou
 import numpy as np
 import torch
 
-from conftest import load_golden
+import os
+
+from conftest import load_golden, GOLDEN
 from oracle import rime_oracle as orc
 
 torch.set_default_dtype(torch.float64)
@@ -492,3 +494,107 @@ def test_apply_cal():
         (out * torch.as_tensor(g['cot_' + tag]).conj()).real.sum().backward()
         assert np.abs(vis.grad.numpy() - g['gvis_' + tag]).max() < 1e-12
         assert np.abs(gains.grad.numpy() - g['ggains_' + tag]).max() < 1e-11
+
+
+# ---------------------------------------------------------------------------------------------
+# eq2top oracle (oracle/eq2top_oracle.py) against SOFA's published known answers, end to end
+# ---------------------------------------------------------------------------------------------
+def _sofa():
+    import json
+    return json.load(open(os.path.join(GOLDEN, 'sofa_vectors.json')))
+
+
+def test_sofa_end_to_end_cases_are_self_consistent():
+    """transcription check of the end-to-end vectors that needs no astrometric model at all"""
+    import math
+    g = _sofa()
+    for name in ('atio13', 'atco13'):
+        c = g[name]
+        E, N, U = math.sin(c['zob']) * math.sin(c['aob']), math.sin(c['zob']) * math.cos(c['aob']), math.cos(c['zob'])
+        sp, cp = math.sin(c['phi']), math.cos(c['phi'])
+        x, y, z = -N * sp + U * cp, E, N * cp + U * sp
+        assert abs(math.asin(z) - c['dob']) < 1e-15 and abs(math.atan2(-y, x) - c['hob']) < 1e-15
+        # observed RA + observed HA = local Earth rotation angle (up to the polar-motion adjustment of the longitude)
+        from oracle import eq2top_oracle as eo
+        era = eo.earth_rotation_angle(c['utc1'] + c['utc2'], c['dut1'])
+        # (2e-9 rad = 0.4 mas: the two-part UTC date is added into ONE float64 Julian date here, 4e-5 s of rounding)
+        assert abs((era + c['elong']) % (2 * math.pi) - (c['rob'] + c['hob'])) < 2e-9
+    h = g['hd2ae']
+    sh, ch, sd, cd, sp, cp = (f(v) for v in (h['h'], h['d'], h['p']) for f in (math.sin, math.cos))
+    x, y, z = -ch * cd * sp + sd * cp, -sh * cd, ch * cd * cp + sd * sp
+    assert abs(math.atan2(y, x) % (2 * math.pi) - h['az']) < 1e-15 and abs(math.atan2(z, math.hypot(x, y)) - h['el']) < 1e-15
+
+
+def test_eq2top_oracle_components_against_sofa():
+    import math
+    from oracle import eq2top_oracle as eo
+    g = _sofa()
+    mas = eo.AS * 1e-3
+    assert abs(eo.earth_rotation_angle(g['era00']['mjd'] + 2400000.5) - g['era00']['value']) < 1e-13
+    t = (g['pmat06']['mjd'] + 2400000.5 - 2451545.0) / 36525.0
+    gam, phi, psi, eps = eo.fw_angles(t)
+    assert np.abs(eo.fw_matrix(gam, phi, psi, eps) - np.asarray(g['pmat06']['value'])).max() < 1e-14     # Fukushima-Williams route
+    t = (g['nut80']['mjd'] + 2400000.5 - 2451545.0) / 36525.0
+    dp, de = eo.nutation(t)
+    assert abs(dp - g['nut80']['dpsi']) < 7 * mas and abs(de - g['nut80']['deps']) < 2 * mas            # 31 of 106 terms
+    _, eqo, _ = eo.c2i_matrix(t)
+    gast = (eo.earth_rotation_angle(g['gst06a']['mjd'] + 2400000.5) - eqo) % (2 * math.pi)              # GAST = ERA - EO
+    assert abs(gast - g['gst06a']['value']) < 10 * mas
+    t = (g['epv00']['mjd'] + 2400000.5 - 2451545.0) / 36525.0
+    v, vh = eo.earth_velocity_gcrs(t), np.asarray(g['epv00']['vel_helio_au_per_day'])
+    assert np.linalg.norm(v - vh) / np.linalg.norm(vh) < 1e-4                                          # truncated VSOP87, differentiated
+    h = g['hd2ae']
+    zen, az = eo.hadec_to_zenaz(np.asarray(h['h']), np.asarray(h['d']), h['p'])
+    assert abs(float(az) - h['az']) < h['tol'] and abs(math.pi / 2 - float(zen) - h['el']) < h['tol']
+    for name in ('atci13', 'atco13'):
+        c = g[name]
+        t = ((c['date1'] + c['date2'] - 2451545.0) / 36525.0) if name == 'atci13' else eo.tt_century(c['utc1'] + c['utc2'])
+        assert abs(eo.c2i_matrix(t)[1] - c['eo']) < c['tol_eo_mas'] * mas
+
+
+def test_eq2top_oracle_end_to_end_against_sofa():
+    """ICRS -> CIRS (atci13), CIRS -> observed (atio13) and ICRS -> observed (atco13): the oracle reproduces SOFA's
+    published answers to a few milli-arcseconds once the test star's space motion / parallax / light deflection and
+    the refraction of the observed values are accounted for on the known-answer side (tolerances in the fixture: 5 mas
+    for the celestial part -- truncated nutation, low-precision ephemeris; 15 mas for the observed part -- the
+    inversion of the A tan z + B tan^3 z refraction at z = 80.7 deg contributes ~10 mas)"""
+    import math
+    from oracle import eq2top_oracle as eo
+    g = _sofa()
+    mas = eo.AS * 1e-3
+    c = g['atci13']
+    jd_tt = c['date1'] + c['date2']
+    p = eo.sofa_case_star_direction(c['rc'], c['dc'], c['pr'], c['pd'], c['px'], c['rv'], jd_tt)
+    jd_utc = jd_tt - (eo.dat(jd_tt) + 32.184) / 86400.0
+    ri, di, _ = eo.gcrs_to_cirs_radec(p, jd_utc)
+    assert abs(ri[0] - c['ri']) * math.cos(c['di']) < c['tol_mas'] * mas and abs(di[0] - c['di']) < c['tol_mas'] * mas
+    # without the adaptor the same comparison is off by the star's proper motion (26 arcsec): the test has teeth
+    ri0, di0, _ = eo.gcrs_to_cirs_radec(eo.unit_from_radec(c['rc'], c['dc']).reshape(3, 1), jd_utc)
+    assert abs(di0[0] - c['di']) > 1e4 * mas
+
+    ap = g['apco13']
+    c = g['atio13']
+    jd = c['utc1'] + c['utc2']
+    # atio13 starts from CIRS: only the diurnal aberration, the Earth rotation, polar motion and the local triangle
+    theta = eo.earth_rotation_angle(jd, c['dut1']) + c['elong']
+    vsite = eo.observer_velocity_gcrs(c['elong'], c['phi'], c['hm'], theta, np.eye(3), 0.0) \
+        - eo.earth_velocity_gcrs(0.0) * eo.AU_KM / eo.DAY_S / eo.C_KMS
+    q = eo.unit_from_radec(c['ri'], c['di']).reshape(3) + vsite
+    q /= np.linalg.norm(q)
+    zen, az = eo.cirs_to_zenaz(math.atan2(q[1], q[0]), math.asin(q[2]), jd, c['elong'], c['phi'], c['dut1'], c['xp'], c['yp'])
+    ztrue = eo.sofa_case_remove_refraction(c['zob'], ap['refa'], ap['refb'])
+    assert abs(float(az) - c['aob']) * math.sin(c['zob']) < c['tol_mas'] * mas and abs(float(zen) - ztrue) < c['tol_mas'] * mas
+
+    c = g['atco13']
+    jd = c['utc1'] + c['utc2']
+    p = eo.sofa_case_star_direction(c['rc'], c['dc'], c['pr'], c['pd'], c['px'], c['rv'], jd + (eo.dat(jd) + 32.184) / 86400.0)
+    ra, dec = math.degrees(math.atan2(p[1, 0], p[0, 0])), math.degrees(math.asin(p[2, 0]))
+    loc = (math.degrees(c['elong']), math.degrees(c['phi']), c['hm'])
+    zen, az = eo.eq2top(loc, jd, [ra], [dec], c['dut1'], c['xp'], c['yp'])
+    ztrue = eo.sofa_case_remove_refraction(c['zob'], ap['refa'], ap['refb'])
+    daz = abs(math.radians(az[0]) - c['aob']) * math.sin(c['zob'])
+    dzen = abs(math.radians(zen[0]) - ztrue)
+    assert daz < c['tol_mas'] * mas and dzen < c['tol_mas'] * mas, (daz / mas, dzen / mas)
+    # and the part the product does not model, polar motion, is visible at the size the fixture's xp, yp imply
+    zen0, az0 = eo.eq2top(loc, jd, [ra], [dec], c['dut1'])
+    assert 0.15 < abs(zen0[0] - zen[0]) * 3600 < 0.30
