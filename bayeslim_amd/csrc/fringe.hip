@@ -550,7 +550,8 @@ static Plan plan_bwd(int bl_cnt, int Nt, int Nf, int Pstride, int CH, int PIX)
     const int nchunk = (Nf + CH - 1) / CH;
     const long nblk = (Pstride + pl.block * PIX - 1) / (pl.block * PIX);
     const long waves = nblk * (pl.block / 64) * (long)nchunk * Nt;
-    const int ntiles = (bl_cnt + TB - 1) / TB;
+    // a model-pair group without baselines (bl_cnt == 0) still launches: its gradient plane must be written (zeros)
+    const int ntiles = std::max(1, (bl_cnt + TB - 1) / TB);
     pl.S = pick_splits(waves, ntiles);
     pl.tiles_per_split = (ntiles + pl.S - 1) / pl.S;
     pl.S = (ntiles + pl.tiles_per_split - 1) / pl.tiles_per_split;

@@ -373,6 +373,59 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
             }
             return;
         }
+#if defined(RIME_LAB_CHAIN)      /* lab, TIMING ONLY (tools/fringe_mfma_lab.hip; -DRIME_LAB_CHAIN=1 or 2): rows u >= 1 by recurrence E_u = E_(u-1) D */
+#pragma unroll
+        for (int hf = 0; hf < MF_NH; ++hf) {
+            const float w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
+            if (SIGNED && tid < 8)
+                *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
+                    ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
+            float c0, s0, c1, s1, dc0, ds0, dc1, ds1;
+            {
+                const double ph0 = ax[0] * sx[hf].x + ay[0] * sy[hf].x + az[0] * sz[hf].x;
+                const double ph1 = ax[0] * sx[hf].y + ay[0] * sy[hf].y + az[0] * sz[hf].y;
+                const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                s0 = w0 * __builtin_amdgcn_sinf(r0); c0 = w0 * __builtin_amdgcn_cosf(r0);
+                s1 = w1 * __builtin_amdgcn_sinf(r1); c1 = w1 * __builtin_amdgcn_cosf(r1);
+                constexpr int U1 = SH::GEN > 1 ? 1 : 0;
+                const double pd0 = ax[U1] * sx[hf].x + ay[U1] * sy[hf].x + az[U1] * sz[hf].x;
+                const double pd1 = ax[U1] * sx[hf].y + ay[U1] * sy[hf].y + az[U1] * sz[hf].y;
+                const float q0 = (float)__builtin_amdgcn_fract(pd0), q1 = (float)__builtin_amdgcn_fract(pd1);
+                ds0 = __builtin_amdgcn_sinf(q0); dc0 = __builtin_amdgcn_cosf(q0);
+                ds1 = __builtin_amdgcn_sinf(q1); dc1 = __builtin_amdgcn_cosf(q1);
+            }
+#if RIME_LAB_CHAIN == 2          /* powers of D first: rows are independent of each other (no serial chain through E) */
+            float pc0[4] = {1.f, dc0, 0.f, 0.f}, ps0[4] = {0.f, ds0, 0.f, 0.f}, pc1[4] = {1.f, dc1, 0.f, 0.f}, ps1[4] = {0.f, ds1, 0.f, 0.f};
+            pc0[2] = dc0 * dc0 - ds0 * ds0; ps0[2] = 2.f * dc0 * ds0; pc1[2] = dc1 * dc1 - ds1 * ds1; ps1[2] = 2.f * dc1 * ds1;
+            pc0[3] = pc0[2] * dc0 - ps0[2] * ds0; ps0[3] = pc0[2] * ds0 + ps0[2] * dc0;
+            pc1[3] = pc1[2] * dc1 - ps1[2] * ds1; ps1[3] = pc1[2] * ds1 + ps1[2] * dc1;
+            const float bc0 = c0, bs0 = s0, bc1 = c1, bs1 = s1;
+#endif
+#pragma unroll
+            for (int u = 0; u < SH::GEN; ++u) {
+                if (u > 0) {
+#if RIME_LAB_CHAIN == 2
+                    c0 = bc0 * pc0[u] - bs0 * ps0[u]; s0 = bc0 * ps0[u] + bs0 * pc0[u];
+                    c1 = bc1 * pc1[u] - bs1 * ps1[u]; s1 = bc1 * ps1[u] + bs1 * pc1[u];
+#else
+                    const float nc0 = c0 * dc0 - s0 * ds0, ns0 = c0 * ds0 + s0 * dc0;
+                    const float nc1 = c1 * dc1 - s1 * ds1, ns1 = c1 * ds1 + s1 * dc1;
+                    c0 = nc0; s0 = ns0; c1 = nc1; s1 = ns1;
+#endif
+                }
+                uint32_t rh, rl, ih, il;
+                split2_plain(c0, c1, rh, rl);
+                split2_plain(s0, s1, ih, il);
+                unsigned char* o = buf + goff + u * SH::GROWS * MF_ROWB + 32 * hf;
+                *reinterpret_cast<uint32_t*>(o) = rh;
+                *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+            }
+            fetch(next_panel, hf);
+        }
+        return;
+#endif
 #pragma unroll
         for (int hf = 0; hf < MF_NH; ++hf) {
             const float w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
@@ -453,15 +506,21 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh, Brh, acc[sR][0]);
                 if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh, Bih, acc[sI][0]);
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih, Bih, acc[sR][0]);
+#if !defined(RIME_LAB_3M_UPPER)   /* lab, TIMING ONLY: 9 instead of 12 MFMAs per off-diagonal tile, nothing else changed */
                 if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih, Brh, acc[sI][1]);
+#endif
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh, Brl, acc[sR][0]);
                 if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh, Bil, acc[sI][0]);
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih, Bil, acc[sR][0]);
+#if !defined(RIME_LAB_3M_UPPER)
                 if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih, Brl, acc[sI][1]);
+#endif
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrl, Brh, acc[sR][0]);
                 if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrl, Bih, acc[sI][0]);
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lil, Bih, acc[sR][0]);
+#if !defined(RIME_LAB_3M_UPPER)
                 if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lil, Brh, acc[sI][1]);
+#endif
             });
         }
     };
@@ -1087,6 +1146,24 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                     uint4 Erh, Erl, Eih, Eil;
                     uint32_t* erh = reinterpret_cast<uint32_t*>(&Erh); uint32_t* erl = reinterpret_cast<uint32_t*>(&Erl);
                     uint32_t* eih = reinterpret_cast<uint32_t*>(&Eih); uint32_t* eil = reinterpret_cast<uint32_t*>(&Eil);
+#if defined(RIME_LAB_CHAIN)      /* lab, TIMING ONLY: antennas 4g + 1..3 by recurrence from antenna 4g */
+#pragma unroll
+                    for (int jq = 0; jq < 2; ++jq) {
+                        const int an = 32 * tj + 8 * (2 * ks + jq) + 4 * h;
+                        const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
+                        const double pd = ant_lds[3 * an + 3] * sx + ant_lds[3 * an + 4] * sy + ant_lds[3 * an + 5] * sz;
+                        const float rr = (float)__builtin_amdgcn_fract(ph), rd = (float)__builtin_amdgcn_fract(pd);
+                        float c = __builtin_amdgcn_cosf(rr), sn = __builtin_amdgcn_sinf(rr);
+                        const float dc = __builtin_amdgcn_cosf(rd), dsn = __builtin_amdgcn_sinf(rd);
+                        ec[8 * ks + 4 * jq] = c; es[8 * ks + 4 * jq] = sn;
+#pragma unroll
+                        for (int u = 1; u < 4; ++u) {
+                            const float nc = c * dc - sn * dsn, ns = c * dsn + sn * dc;
+                            c = nc; sn = ns;
+                            ec[8 * ks + 4 * jq + u] = c; es[8 * ks + 4 * jq + u] = sn;
+                        }
+                    }
+#else
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
                         const int an = 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
@@ -1095,6 +1172,7 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                         ec[8 * ks + jj] = __builtin_amdgcn_cosf(rr);
                         es[8 * ks + jj] = __builtin_amdgcn_sinf(rr);
                     }
+#endif
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         split2_plain(ec[8 * ks + 2 * q], ec[8 * ks + 2 * q + 1], erh[q], erl[q]);

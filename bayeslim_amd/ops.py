@@ -379,7 +379,7 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
                 elif ant_model[ant] != mdl:
                     return
         ant_model = [0 if mdl is None else mdl for mdl in ant_model]
-    elif bl_mp is not None and (len(set(int(x) for x in bl_mp)) > 1 or (self.Nmp > 1 and any(int(x) != 0 for x in bl_mp))):
+    elif bl_mp is not None and any(int(x) != 0 for x in bl_mp):          # (bl_mp is only passed when Nmp > 1)
         # without a model table the blocks read psky plane 0: several planes, or one plane that is not plane 0,
         # stay on the baseline-formulation kernels
         return
