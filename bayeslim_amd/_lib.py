@@ -59,6 +59,10 @@ SIGNATURES = {
     'rime_alm2pix_fwd': (_i, [_i, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'rime_alm2pix_bwd_workspace': (_sz, [_i, _i, _i, _i]),
     'rime_alm2pix_bwd': (_i, [_i, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'rime_alm2pix_packed_bytes': (_sz, [_i, _i, _i]),
+    'rime_alm2pix_pack': (_i, [_vp, _d, _i, _i, _i, _vp, _vp]),
+    'rime_alm2pix_fwd_packed': (_i, [_vp, _vp, _d, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'rime_alm2pix_bwd_packed': (_i, [_vp, _vp, _d, _i, _i, _i, _vp, _vp, _sz, _vp]),
 }
 
 

@@ -749,6 +749,275 @@ alm2pix_bwd_f16_dma_kernel(const uint4* __restrict__ g_hi, const uint4* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// PACKED Ylm (round 3): Ylm x y_scale split ONCE into f16 hi / lo halves and stored in MFMA fragment order -- the
+// same 8 bytes per (coefficient, pixel) as the complex64 matrix, one copy per direction (the forward contracts over
+// coefficients, the backward over pixels: the 16-byte granule a lane feeds to the matrix core holds 8 consecutive K
+// values, so the two directions need transposed granules).  The GEMM kernels then do no arithmetic on the streamed
+// operand at all: a wave's fragment is ONE fully coalesced 1-KB load (forward: into registers; backward: LDS-DMA into
+// the wave's own ring region, read back with linear, conflict-free ds_read_b128).  Callers cache the packed copies per
+// Ylm object (bayeslim_amd/ops.py); a new or modified Ylm is packed again.
+//   forward  Yf: [pixel tile jt of 32][K step s of 8 coefficients][hi | lo][lane][8 x f16]
+//                lane (n = lane & 31 -> pixel 32 jt + n, h = lane >> 5): k = (c, q) = (8 s + 4 h + i, re | im), i = 0..3
+//   backward Yb: [coefficient tile ct of 128][K step s of 16 pixels][wave w][re_hi, re_lo, im_hi, im_lo][lane][8 x f16]
+//                lane (c = 128 ct + 32 w + (lane & 31), h = lane >> 5): pixels 16 s + 8 h + 0..7
+//   rows / pixels / K steps beyond the matrix hold zeros; the K-step count is padded to a whole number of chunks
+// ---------------------------------------------------------------------------------------
+constexpr int PK_FWD_CHUNK = 4;                        // forward: K steps per chunk (32 coefficients)
+constexpr int PK_BWD_KS = 2;                           // backward: K steps per ring chunk (32 pixels)
+
+__host__ __device__ inline int pk_fwd_steps(int Ncoeff) { const int n = (2 * Ncoeff + 15) / 16; return (n + PK_FWD_CHUNK - 1) / PK_FWD_CHUNK * PK_FWD_CHUNK; }
+__host__ __device__ inline int pk_bwd_steps(int Npix) { const int n = (Npix + 15) / 16; return (n + PK_BWD_KS - 1) / PK_BWD_KS * PK_BWD_KS; }
+
+__global__ void __launch_bounds__(256)
+alm_pack_fwd_kernel(const float* __restrict__ Ylm, float y_scale, int Ncoeff, int Npix, int nsteps, size_t ntile,
+                    uint4* __restrict__ Yf)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // (jt, s, lane)
+    const int lane = (int)(i & 63);
+    const size_t js = i >> 6;
+    const int s = (int)(js % nsteps);
+    const size_t jt = js / nsteps;
+    if (jt >= ntile) return;                           // (tiles beyond the map are written too: zeros)
+    const size_t j = jt * 32 + (lane & 31);
+    const int h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = 8 * s + 4 * h + q;
+        float2 y = make_float2(0.f, 0.f);
+        if (c < Ncoeff && j < (size_t)Npix) y = *reinterpret_cast<const float2*>(Ylm + ((size_t)c * Npix + j) * 2);
+        v[2 * q] = y.x * y_scale; v[2 * q + 1] = y.y * y_scale;
+    }
+    uint4 hi, lo;
+    split2h(v[0], v[1], hi.x, lo.x); split2h(v[2], v[3], hi.y, lo.y);
+    split2h(v[4], v[5], hi.z, lo.z); split2h(v[6], v[7], hi.w, lo.w);
+    uint4* dst = Yf + ((jt * nsteps + s) * 2) * 64 + lane;
+    dst[0] = hi;
+    dst[64] = lo;
+}
+
+__global__ void __launch_bounds__(256)
+alm_pack_bwd_kernel(const float* __restrict__ Ylm, float y_scale, int Ncoeff, int Npix, int nsteps, uint4* __restrict__ Yb)
+{
+    // block = (ct, s): thread = (wave w, lane); reads 8 pixels x (re, im) = 64 contiguous bytes of one coefficient row
+    const int s = (int)(blockIdx.x % nsteps), ct = (int)(blockIdx.x / nsteps);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = ct * 128 + w * 32 + (lane & 31);
+    const int j0 = 16 * s + 8 * (lane >> 5);
+    float re[8], im[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float2 y = make_float2(0.f, 0.f);
+        if (c < Ncoeff && j0 + q < Npix) y = *reinterpret_cast<const float2*>(Ylm + ((size_t)c * Npix + j0 + q) * 2);
+        re[q] = y.x * y_scale; im[q] = y.y * y_scale;
+    }
+    uint4 rh, rl, ih, il;
+    split2h(re[0], re[1], rh.x, rl.x); split2h(re[2], re[3], rh.y, rl.y);
+    split2h(re[4], re[5], rh.z, rl.z); split2h(re[6], re[7], rh.w, rl.w);
+    split2h(im[0], im[1], ih.x, il.x); split2h(im[2], im[3], ih.y, il.y);
+    split2h(im[4], im[5], ih.z, il.z); split2h(im[6], im[7], ih.w, il.w);
+    uint4* dst = Yb + ((((size_t)ct * nsteps + s) * 4 + w) * 4) * 64 + lane;
+    dst[0] = rh; dst[64] = rl; dst[128] = ih; dst[192] = il;
+}
+
+// forward on the packed copy: block = 4 waves x 32 pixels, MT row tiles per wave.  A (the pre-split alm granules) goes
+// through LDS, double buffered (one barrier per chunk of 4 K steps); the B fragments are coalesced 16-byte loads per
+// lane from the wave's own contiguous stream: the two registers of a K step are reloaded, right after their MFMAs, with
+// the same K step of the chunk TWO ahead, so a wave keeps 4 to 8 K steps (8 - 16 KB) of its stream in flight.
+template <int MT>
+__global__ void __launch_bounds__(256)
+alm2pix_fwd_packed_kernel(const uint4* __restrict__ a_hi, const uint4* __restrict__ a_lo,
+                          const float* __restrict__ inv_scale, const uint4* __restrict__ Yf, float y_scale,
+                          int R, int Rpad, int Ncoeff, int Npix, int nsteps, float* __restrict__ out)
+{
+    constexpr int ROWS = MT * 32;
+    constexpr int NG = 8 * ROWS;                       // A granules per image and chunk: (ks, h, row)
+    constexpr int PT = NG / 256;
+    __shared__ uint4 lds_hi[2][NG], lds_lo[2][NG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.y * ROWS;
+    const size_t jt = (size_t)blockIdx.x * 4 + wave;
+    const int j0 = (int)(jt * 32);
+    const int asteps = (2 * Ncoeff + 15) / 16;         // K steps the A images hold
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    const uint4* ysrc = Yf + (jt * nsteps * 2) * 64 + lane;            // this wave's stream: 2 KB per K step
+    uint4 b0[8], b1[8];                                // even / odd chunk: [ks * 2 + (hi | lo)]
+    uint4 ahq[PT], alq[PT];
+    auto load_b = [&](int s0, uint4 (&b)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = ysrc[(size_t)(s0 * 2 + u) * 64];
+    };
+    auto fetch_a = [&](int s0) {
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int i = tid + u * 256;
+            const int row = i % ROWS, g = i / ROWS;
+            const int sg = s0 * 2 + g;
+            const bool ok = sg < asteps * 2;
+            ahq[u] = ok ? a_hi[(size_t)sg * Rpad + r0 + row] : make_uint4(0, 0, 0, 0);
+            alq[u] = ok ? a_lo[(size_t)sg * Rpad + r0 + row] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto compute = [&](uint4 (&b)[8], int buf, int s_next) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int gi = (ks * 2 + (lane >> 5)) * ROWS + m * 32 + (lane & 31);
+                const uint4 ah = lds_hi[buf][gi], al = lds_lo[buf][gi];
+                acc[m] = ALM_MFMA(ah, b[2 * ks], acc[m]);
+                acc[m] = ALM_MFMA(ah, b[2 * ks + 1], acc[m]);
+                acc[m] = ALM_MFMA(al, b[2 * ks], acc[m]);
+            }
+            if (s_next >= 0) {                         // uniform
+                b[2 * ks] = ysrc[(size_t)((s_next + ks) * 2) * 64];
+                b[2 * ks + 1] = ysrc[(size_t)((s_next + ks) * 2 + 1) * 64];
+            }
+        }
+    };
+    const int nchunk = nsteps / PK_FWD_CHUNK;
+    load_b(0, b0);
+    if (nchunk > 1) load_b(4, b1);
+    fetch_a(0);
+    for (int ch = 0; ch < nchunk; ch += 2) {
+#pragma unroll
+        for (int u = 0; u < PT; ++u) { lds_hi[0][tid + u * 256] = ahq[u]; lds_lo[0][tid + u * 256] = alq[u]; }
+        __syncthreads();
+        if (ch + 1 < nchunk) fetch_a(4 * (ch + 1));
+        compute(b0, 0, ch + 2 < nchunk ? 4 * (ch + 2) : -1);
+        if (ch + 1 < nchunk) {
+#pragma unroll
+            for (int u = 0; u < PT; ++u) { lds_hi[1][tid + u * 256] = ahq[u]; lds_lo[1][tid + u * 256] = alq[u]; }
+            __syncthreads();
+            if (ch + 2 < nchunk) fetch_a(4 * (ch + 2));
+            compute(b1, 1, ch + 3 < nchunk ? 4 * (ch + 3) : -1);
+        }
+    }
+    RIME_MFMA_SETTLE();
+    const int col = j0 + (lane & 31);
+    if (col < Npix) {
+        const float iy = 1.0f / y_scale;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = r0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < R) out[(size_t)row * Npix + col] = acc[m][e] * inv_scale[row] * iy;
+            }
+    }
+}
+
+// backward on the packed copy: the LDS-DMA ring of alm2pix_bwd_f16_dma_kernel with the chunk's Ylm tile replaced by
+// the wave-private packed fragments (16 wave instructions of 1 KB per K step, contiguous in memory AND in the slot: the
+// chunk is one 32-KB run) -- no swizzle, no split, no multiply; the gout granules are staged as before (shared by the
+// four waves, hence the one barrier per chunk).
+template <int MT, int NSLOT>
+__global__ void __launch_bounds__(256, 1)
+alm2pix_bwd_packed_kernel(const uint4* __restrict__ g_hi, const uint4* __restrict__ g_lo,
+                          const float* __restrict__ inv_scale, const uint4* __restrict__ Yb,
+                          const float* __restrict__ zero16, float y_scale,
+                          int R, int Rpad, int Ncoeff, int Npix, int nsteps, int S, int CT, int RT, float* __restrict__ part)
+{
+    constexpr int KS = PK_BWD_KS;
+    using C = BwdDma<MT, KS, NSLOT>;
+    constexpr int ROWS = C::ROWS, AHEAD = NSLOT - 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int NB = S * CT * RT, per_xcd = (NB + 7) / 8;
+    const int q = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    if ((int)(blockIdx.x / 8) >= per_xcd || q >= NB) return;      // whole block, before any barrier
+    const int split = q / (CT * RT);
+    const int r0 = (q % RT) * ROWS;
+    const int ct = (q / RT) % CT;
+    const int c = ct * 128 + wave * 32 + (lane & 31);
+    const int h = lane >> 5;
+    const int send = (Npix + 15) / 16;                 // K steps the gout images hold
+    const int nchunk = nsteps / KS;
+    const int niter = split < nchunk ? (nchunk - split + S - 1) / S : 0;
+    f32x16 accr[MT], acci[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { accr[m][e] = 0.f; acci[m][e] = 0.f; }
+
+    const uint4* ytile = Yb + (size_t)ct * nsteps * 16 * 64 + lane;
+    auto issue = [&](int it, int slot) {
+        const int s0 = KS * (split + it * S);
+        const unsigned base = smem_addr + (unsigned)(slot * C::SLOT);
+#pragma unroll
+        for (int u = 0; u < C::NPW; ++u) {
+            const int t = wave + 4 * u;                // wave-uniform
+            if (t < 16 * KS) {                         // KB number t of the chunk's 32-KB run: (ks, w, plane) = t
+                glds16(ytile + ((size_t)s0 * 16 + t) * 64, base + t * 1024);
+            } else if (t < C::TI) {
+                const int tg = t - 16 * KS;
+                const int ks = tg / (2 * C::NGW), r = tg % (2 * C::NGW), img = r / C::NGW, k = r % C::NGW;
+                const int i = k * 64 + lane;
+                const int row = i % ROWS, hh = i / ROWS;
+                const int qq = (s0 + ks) * 2 + hh;
+                const uint4* g = img ? g_lo : g_hi;
+                const void* src = s0 + ks < send ? (const void*)&g[(size_t)qq * Rpad + r0 + row] : (const void*)zero16;
+                glds16(src, base + C::YB + (ks * 2 + img) * C::GB + k * 1024);
+            } else {
+                glds16(zero16, smem_addr + NSLOT * C::SLOT);
+            }
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        if (a < niter) issue(a, a);
+    int slot = 0, nslot = AHEAD;
+    for (int it = 0; it < niter; ++it) {
+        wait_chunks<C::NPW, AHEAD - 1>(niter - 1 - it);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + AHEAD < niter) issue(it + AHEAD, nslot);
+        const unsigned char* sl = smem + slot * C::SLOT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint4* lds_hi = reinterpret_cast<const uint4*>(sl + C::YB + ks * 2 * C::GB);
+            const uint4* lds_lo = reinterpret_cast<const uint4*>(sl + C::YB + (ks * 2 + 1) * C::GB);
+            const uint4* yf = reinterpret_cast<const uint4*>(sl + (ks * 16 + wave * 4) * 1024) + lane;
+            const uint4 rh = yf[0], rl = yf[64], ih = yf[128], il = yf[192];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int gi = h * ROWS + m * 32 + (lane & 31);
+                const uint4 ah = lds_hi[gi], al = lds_lo[gi];
+                accr[m] = ALM_MFMA(ah, rh, accr[m]);
+                acci[m] = ALM_MFMA(ah, ih, acci[m]);
+                accr[m] = ALM_MFMA(ah, rl, accr[m]);
+                acci[m] = ALM_MFMA(ah, il, acci[m]);
+                accr[m] = ALM_MFMA(al, rh, accr[m]);
+                acci[m] = ALM_MFMA(al, ih, acci[m]);
+            }
+        }
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        nslot = nslot + 1 == NSLOT ? 0 : nslot + 1;
+    }
+    RIME_MFMA_SETTLE();
+    if (c < Ncoeff) {
+        float* dst = part + (size_t)split * R * Ncoeff * 2;
+        const float iy = 1.0f / y_scale;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = r0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < R) {
+                    const float sc = inv_scale[row] * iy;
+                    *reinterpret_cast<float2*>(dst + ((size_t)row * Ncoeff + c) * 2) =
+                        make_float2(accr[m][e] * sc, -acci[m][e] * sc);
+                }
+            }
+    }
+}
+
 __global__ void alm_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t len, int S)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
@@ -820,8 +1089,9 @@ static long bwd_dma_resident_blocks()
     return cache;
 }
 
-static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward)
+static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward, int dma = -1)      // dma: -1 auto, 1 the ring kernels
 {
+    const bool use_dma = dma < 0 ? bwd_use_dma(K) : dma != 0;
     SplitPlan p{};
     p.MT = R > 64 ? 4 : (R > 32 ? 2 : 1);
     p.Rpad = ((R + p.MT * 32 - 1) / (p.MT * 32)) * p.MT * 32;
@@ -833,11 +1103,11 @@ static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward)
         // streams the same number of chunks, so 4.1 rounds cost 5 (C3: 66 tiles x 32 splits = 2112 blocks over
         // 512 resident ones; 31 splits = 2046 blocks = 4.0 rounds)
         const long blocks = (long)((Ncoeff + 127) / 128) * (p.Rpad / (p.MT * 32));
-        const long resident = bwd_use_dma(K) ? bwd_dma_resident_blocks() : bwd_resident_blocks(p.MT);
+        const long resident = use_dma ? bwd_dma_resident_blocks() : bwd_resident_blocks(p.MT);
         long S = (2048 + blocks - 1) / blocks;                   // measured flat between 1024 and 4096 blocks
         const long maxS = std::max(1, p.nsteps / 32);          // >= 16 chunks of 2 K steps per block
         S = std::max<long>(1, std::min(S, maxS));
-        if (bwd_use_dma(K)) {
+        if (use_dma) {
             // LDS-DMA kernel, one block per CU.  Cost of S splits in units of one chunk (2 K steps) of one block:
             // rounds of the chip x (chunks per block + ~3 for the ring's ramp and the epilogue) + the partial plane
             // each split writes and the reduce kernel reads back (R Ncoeff 16 B at ~4 TB/s against ~2.2 us per
@@ -902,6 +1172,29 @@ static hipError_t launch_bwd_dma(dim3 grid, hipStream_t st, const uint4* hi, con
     return hipSuccess;
 }
 
+template <int MT, int NSLOT>
+static hipError_t launch_bwd_packed(dim3 grid, hipStream_t st, const uint4* hi, const uint4* lo, const float* inv, const uint4* Yb,
+                                    const float* zero16, float ys, int R, int Rpad, int Ncoeff, int Npix, int nsteps, int S, float* part)
+{
+    const int CT = (int)grid.y, RT = (int)grid.z;
+    const int NB = S * CT * RT;
+    grid = dim3(8 * ((NB + 7) / 8));
+    constexpr int LDS = BwdDma<MT, PK_BWD_KS, NSLOT>::LDS;
+    static unsigned long long configured = 0ull;
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) devid = 0;
+    const unsigned long long bit = 1ull << (devid & 63);
+    if (!(configured & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&alm2pix_bwd_packed_kernel<MT, NSLOT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        configured |= bit;
+    }
+    hipLaunchKernelGGL((alm2pix_bwd_packed_kernel<MT, NSLOT>), grid, dim3(256), LDS, st, hi, lo, inv, Yb, zero16, ys, R, Rpad,
+                       Ncoeff, Npix, nsteps, S, CT, RT, part);
+    return hipSuccess;
+}
+
 static size_t split_ws_bytes(const SplitPlan& p)
 {
     return 2 * p.img_bytes + (size_t)p.Rpad * (sizeof(float) + sizeof(unsigned int)) + 64;    // 64: a zero granule
@@ -958,7 +1251,9 @@ extern "C" size_t rime_alm2pix_bwd_workspace(int dtype, int R, int Ncoeff, int N
     const size_t exact = S0 <= 1 ? 0 : (size_t)S0 * R * Ncoeff * 2 * sizeof(float);
     const SplitPlan p = split_plan(R, Npix, Ncoeff, true);
     const size_t fast = split_ws_bytes(p) + (size_t)p.S * R * Ncoeff * 2 * sizeof(float);
-    return std::max(exact, fast);
+    const SplitPlan pp = split_plan(R, Npix, Ncoeff, true, 1);                 // rime_alm2pix_bwd_packed: always the ring
+    const size_t packed = split_ws_bytes(pp) + (size_t)pp.S * R * Ncoeff * 2 * sizeof(float);
+    return std::max(exact, std::max(fast, packed));
 }
 
 extern "C" int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, double y_scale, int R, int Ncoeff,
@@ -1020,5 +1315,83 @@ extern "C" int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, do
     dim3 grid((Ncoeff + CT - 1) / CT, (R + RTB - 1) / RTB);
     hipLaunchKernelGGL((alm2pix_bwd_kernel<double, CT, RTB>), grid, dim3(256), 0, st,
                        (const double*)gout, (const double*)Ylm, R, Ncoeff, Npix, (double*)galm);
+    return check_launch();
+}
+
+
+// ---- packed Ylm (see the kernels): size, packing, and the two transforms on a packed copy ------------------------
+extern "C" size_t rime_alm2pix_packed_bytes(int Ncoeff, int Npix, int direction)
+{
+    if (Ncoeff <= 0 || Npix <= 0 || (direction != 0 && direction != 1)) return 0;
+    if (direction == 0) return (size_t)((Npix + 127) / 128 * 4) * pk_fwd_steps(Ncoeff) * 2048;     // whole 4-wave blocks of pixel tiles
+    return (size_t)((Ncoeff + 127) / 128) * pk_bwd_steps(Npix) * 16384;
+}
+
+extern "C" int rime_alm2pix_pack(const void* Ylm, double y_scale, int Ncoeff, int Npix, int direction, void* packed,
+                                 void* stream)
+{
+    if (!Ylm || !packed || Ncoeff <= 0 || Npix <= 0 || !(y_scale > 0) || (direction != 0 && direction != 1)) return RIME_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (direction == 0) {
+        const int nsteps = pk_fwd_steps(Ncoeff);
+        const size_t ntile = (size_t)(Npix + 127) / 128 * 4;
+        const size_t nthr = ntile * nsteps * 64;
+        if ((nthr + 255) / 256 > 0x7fffffffull) return RIME_EUNSUPPORTED;
+        hipLaunchKernelGGL(alm_pack_fwd_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, (const float*)Ylm, (float)y_scale,
+                           Ncoeff, Npix, nsteps, ntile, (uint4*)packed);
+    } else {
+        const int nsteps = pk_bwd_steps(Npix);
+        const size_t nblk = (size_t)((Ncoeff + 127) / 128) * nsteps;
+        if (nblk > 0x7fffffffull) return RIME_EUNSUPPORTED;
+        hipLaunchKernelGGL(alm_pack_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)Ylm, (float)y_scale,
+                           Ncoeff, Npix, nsteps, (uint4*)packed);
+    }
+    return check_launch();
+}
+
+extern "C" int rime_alm2pix_fwd_packed(const void* alm, const void* packed, double y_scale, int R, int Ncoeff, int Npix,
+                                       void* out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!alm || !packed || !out || R <= 0 || Ncoeff <= 0 || Npix <= 0 || !(y_scale > 0)) return RIME_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const SplitPlan p = split_plan(R, 2 * Ncoeff, Ncoeff, false);
+    if (!workspace || workspace_bytes < split_ws_bytes(p)) return RIME_EWORKSPACE;
+    uint4 *hi, *lo; float* inv;
+    launch_split_rows((const float*)alm, R, 2 * Ncoeff, p, 1, workspace, st, hi, lo, inv);
+    dim3 grid((Npix + 127) / 128, p.Rpad / (p.MT * 32));
+    const float ys = (float)y_scale;
+    const uint4* Y = (const uint4*)packed; float* o = (float*)out;
+    const int nsteps = pk_fwd_steps(Ncoeff);
+    if (p.MT == 4) hipLaunchKernelGGL((alm2pix_fwd_packed_kernel<4>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, nsteps, o);
+    else if (p.MT == 2) hipLaunchKernelGGL((alm2pix_fwd_packed_kernel<2>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, nsteps, o);
+    else hipLaunchKernelGGL((alm2pix_fwd_packed_kernel<1>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, nsteps, o);
+    return check_launch();
+}
+
+extern "C" int rime_alm2pix_bwd_packed(const void* gout, const void* packed, double y_scale, int R, int Ncoeff, int Npix,
+                                       void* galm, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!gout || !packed || !galm || R <= 0 || Ncoeff <= 0 || Npix <= 0 || !(y_scale > 0)) return RIME_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const SplitPlan p = split_plan(R, Npix, Ncoeff, true, 1);
+    const size_t len = (size_t)R * Ncoeff * 2;
+    const size_t need = split_ws_bytes(p) + (size_t)p.S * len * sizeof(float);
+    if (!workspace || workspace_bytes < need) return RIME_EWORKSPACE;
+    uint4 *hi, *lo; float* inv;
+    launch_split_rows((const float*)gout, R, Npix, p, 0, workspace, st, hi, lo, inv);
+    float* part = p.S > 1 ? (float*)((char*)workspace + split_ws_bytes(p)) : (float*)galm;
+    dim3 grid(p.S, (Ncoeff + 127) / 128, p.Rpad / (p.MT * 32));
+    const float* zero16 = (const float*)((char*)workspace + split_ws_bytes(p) - 64);
+    const uint4* Y = (const uint4*)packed;
+    const int nsteps = pk_bwd_steps(Npix);
+    hipError_t e;
+    if (p.MT == 4) e = launch_bwd_packed<4, 3>(grid, st, hi, lo, inv, Y, zero16, (float)y_scale, R, p.Rpad, Ncoeff, Npix, nsteps, p.S, part);
+    else if (p.MT == 2) e = launch_bwd_packed<2, 3>(grid, st, hi, lo, inv, Y, zero16, (float)y_scale, R, p.Rpad, Ncoeff, Npix, nsteps, p.S, part);
+    else e = launch_bwd_packed<1, 3>(grid, st, hi, lo, inv, Y, zero16, (float)y_scale, R, p.Rpad, Ncoeff, Npix, nsteps, p.S, part);
+    if (e != hipSuccess) return RIME_ELAUNCH;
+    if (p.S > 1) {
+        int nb = (int)std::min<size_t>((len + 255) / 256, 2048);
+        hipLaunchKernelGGL(alm_reduce_kernel, dim3(nb), dim3(256), 0, st, part, (float*)galm, len, p.S);
+    }
     return check_launch();
 }

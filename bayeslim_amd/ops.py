@@ -878,6 +878,41 @@ def _ylm_scale(Y):
     return s
 
 
+ALM_PACKED = os.environ.get('RIME_ALM_PACKED', '1') != '0'      # cached pre-split f16 copies of Ylm in fragment order
+ALM_PACKED_MIN_BYTES = 1 << 24                                   # below 16 MB of Ylm the transform is launch-bound anyway
+
+
+def _ylm_packed(Ylm, Y, ys, direction):
+    """
+    The packed copy of Ylm for one direction (0 forward, 1 backward; include/rime_hip.h: rime_alm2pix_pack), built on
+    first use and remembered ON the Ylm tensor object together with its version counter and y_scale -- a different
+    tensor (AlmModel.setup_Ylm replaces it) or an in-place update packs again.  Returns None when packing is switched
+    off, the matrix is small, or the GPU has no room for another copy (the unpacked kernels then run).
+    `Ylm` is the caller's tensor object (the cache lives on it), `Y` its contiguous detached alias.
+    """
+    if not ALM_PACKED or Y.dtype != torch.complex64 or ys <= 0 or Y.numel() * 8 < ALM_PACKED_MIN_BYTES:
+        return None
+    tag = getattr(Ylm, '_rime_packed', None)
+    if tag is None or tag[0] != Ylm._version or tag[1] != ys or tag[2] != Y.data_ptr():
+        tag = (Ylm._version, ys, Y.data_ptr(), {})
+        try:
+            Ylm._rime_packed = tag
+        except Exception:
+            return None
+    buf = tag[3].get(direction)
+    if buf is None:
+        Nc, Npix = Y.shape
+        nbytes = int(lib.rime_alm2pix_packed_bytes(Nc, Npix, direction))
+        free, _ = torch.cuda.mem_get_info(Y.device)
+        if nbytes == 0 or free < nbytes + (1 << 30):
+            tag[3][direction] = False                    # remembered: do not ask the allocator on every call
+            return None
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=Y.device)
+        check(lib.rime_alm2pix_pack(_ptr(torch.view_as_real(Y)), ys, Nc, Npix, direction, _ptr(buf), _stream()), 'rime_alm2pix_pack')
+        tag[3][direction] = buf
+    return buf if buf is not False else None
+
+
 class _Alm2Pix(torch.autograd.Function):
     @staticmethod
     def forward(ctx, alm, Ylm):
@@ -895,10 +930,16 @@ class _Alm2Pix(torch.autograd.Function):
         ys = _ylm_scale(Ylm) if (rdt == torch.float32 and ALM_SPLIT_F16) else 0.0
         nbytes = lib.rime_alm2pix_fwd_workspace(code, R, Nc, Npix) if ys > 0 else 0
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=a.device)
-        rc = lib.rime_alm2pix_fwd(code, _ptr(torch.view_as_real(a)), _ptr(torch.view_as_real(Y)), ys,
-                                  R, Nc, Npix, _ptr(out), _ptr(ws), ws.numel(), _stream())
-        check(rc, 'rime_alm2pix_fwd')
-        ctx.Y, ctx.shape, ctx.dtype, ctx.ys = Y, tuple(alm.shape), alm.dtype, ys
+        packed = _ylm_packed(Ylm, Y, ys, 0) if ys > 0 else None
+        if packed is not None:
+            rc = lib.rime_alm2pix_fwd_packed(_ptr(torch.view_as_real(a)), _ptr(packed), ys, R, Nc, Npix, _ptr(out),
+                                             _ptr(ws), ws.numel(), _stream())
+            check(rc, 'rime_alm2pix_fwd_packed')
+        else:
+            rc = lib.rime_alm2pix_fwd(code, _ptr(torch.view_as_real(a)), _ptr(torch.view_as_real(Y)), ys,
+                                      R, Nc, Npix, _ptr(out), _ptr(ws), ws.numel(), _stream())
+            check(rc, 'rime_alm2pix_fwd')
+        ctx.Y, ctx.shape, ctx.dtype, ctx.ys, ctx.Ylm = Y, tuple(alm.shape), alm.dtype, ys, Ylm
         return out
 
     @staticmethod
@@ -911,9 +952,15 @@ class _Alm2Pix(torch.autograd.Function):
         R = int(np.prod(ctx.shape[:-1])) if len(ctx.shape) > 1 else 1
         nbytes = lib.rime_alm2pix_bwd_workspace(code, R, Nc, Npix)
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=g.device)
-        rc = lib.rime_alm2pix_bwd(code, _ptr(g), _ptr(torch.view_as_real(Y)), ctx.ys, R, Nc, Npix,
-                                  _ptr(torch.view_as_real(ga)), _ptr(ws), ws.numel(), _stream())
-        check(rc, 'rime_alm2pix_bwd')
+        packed = _ylm_packed(ctx.Ylm, Y, ctx.ys, 1) if ctx.ys > 0 else None
+        if packed is not None:
+            rc = lib.rime_alm2pix_bwd_packed(_ptr(g), _ptr(packed), ctx.ys, R, Nc, Npix,
+                                             _ptr(torch.view_as_real(ga)), _ptr(ws), ws.numel(), _stream())
+            check(rc, 'rime_alm2pix_bwd_packed')
+        else:
+            rc = lib.rime_alm2pix_bwd(code, _ptr(g), _ptr(torch.view_as_real(Y)), ctx.ys, R, Nc, Npix,
+                                      _ptr(torch.view_as_real(ga)), _ptr(ws), ws.numel(), _stream())
+            check(rc, 'rime_alm2pix_bwd')
         return ga, None
 
 

@@ -325,7 +325,13 @@ class RIME(utils.Module):
         tel = self.telescope.__class__(self.telescope.location, tloc=getattr(self.telescope, 'tloc', None),
                                        device=self.telescope.device)
         vd.setup_meta(tel, self.array.to_antpos())
-        vd.setup_data(self.data_bls, self.sim_times, self.freqs, pol=pol, data=vis, flags=None,
+        # the baseline integers of this group, converted once (8128 tuples -> numpy costs 1 ms of host time per forward)
+        bn = self.__dict__.setdefault('_blnum_cache', {}).get(self.bl_group_id)
+        if bn is None or bn[0] is not self.data_bls:
+            bn = (self.data_bls, np.asarray(utils.ants2blnum([tuple(b) for b in self.data_bls]), dtype=np.int64)
+                  if len(self.data_bls) else np.array([], dtype=np.int64))
+            self._blnum_cache[self.bl_group_id] = bn
+        vd.setup_data(bn[1].copy(), self.sim_times, self.freqs, pol=pol, data=vis, flags=None,
                       cov=None, history=self.describe())
         return vd
 

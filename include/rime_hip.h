@@ -259,6 +259,21 @@ size_t rime_alm2pix_bwd_workspace(int dtype, int R, int Ncoeff, int Npix);
 int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, double y_scale, int R, int Ncoeff,
                      int Npix, void* galm, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Packed Ylm (float32 f16-split path only): Ylm x y_scale split ONCE into f16 hi / lo halves, stored in the order the
+ * matrix-core fragments are consumed -- 8 bytes per (coefficient, pixel), as the complex64 matrix itself, one copy per
+ * direction (0 = forward: contraction over coefficients; 1 = backward: contraction over pixels).  The transforms on a
+ * packed copy do no arithmetic on the streamed operand and read it as fully coalesced 1-KB fragments; results equal
+ * rime_alm2pix_fwd / _bwd with y_scale > 0 bit for bit in the products (same split, same MFMAs; the summation order over K
+ * is the same, so they are bitwise equal).  The caller owns the packed buffer (rime_alm2pix_packed_bytes) and must pack
+ * again when Ylm or y_scale changes.  Workspaces: rime_alm2pix_fwd_workspace / rime_alm2pix_bwd_workspace bytes.
+ * Same reference lines as above (sph_harm.py:1342-1372); the reference recomputes the einsum on the complex matrix. */
+size_t rime_alm2pix_packed_bytes(int Ncoeff, int Npix, int direction);
+int rime_alm2pix_pack(const void* Ylm, double y_scale, int Ncoeff, int Npix, int direction, void* packed, void* stream);
+int rime_alm2pix_fwd_packed(const void* alm, const void* packed, double y_scale, int R, int Ncoeff, int Npix,
+                            void* out, void* workspace, size_t workspace_bytes, void* stream);
+int rime_alm2pix_bwd_packed(const void* gout, const void* packed, double y_scale, int R, int Ncoeff, int Npix,
+                            void* galm, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Likelihood epilogue:  chi^2 = sum_i icov[i] * |pred[i] - data[i]|^2  over a complex visibility tensor
  * (N complex elements, interleaved), and its backward gpred[i] = 2 g icov[i] (pred[i] - data[i]).

@@ -969,6 +969,72 @@ def test_alm2pix_mfma_shapes(ops, R, lmax, Npix):
     assert torch.equal(g1, x.grad)                      # deterministic
 
 
+@pytest.mark.parametrize('R,lmax,Npix', [(128, 24, 3000), (40, 12, 1111), (3, 40, 5000), (70, 31, 2048), (128, 15, 12289)])
+def test_alm2pix_packed_ylm_equals_unpacked(ops, R, lmax, Npix, monkeypatch):
+    """the cached pre-split copies of Ylm in fragment order (rime_alm2pix_pack / _fwd_packed / _bwd_packed): same
+    split, same products, same summation order as the kernels that split Ylm on the fly -- bitwise equal results for
+    even pixel counts (odd ones: the unpacked backward is another kernel with another pixel split: 2e-6) -- and both
+    against the float64 oracle; row tiles 4 / 2 / 1, ragged coefficient and pixel tails, one-block and many-block grids"""
+    rng = np.random.default_rng(R + Npix)
+    l, m = orc.gen_lm(lmax)
+    th, ph = np.arccos(rng.uniform(-1, 1, Npix)), rng.uniform(0, 2 * np.pi, Npix)
+    Y = torch.as_tensor(orc.sph_Ylm(th, ph, l, m))
+    a = torch.as_tensor(rng.normal(size=(R, len(l))) + 1j * rng.normal(size=(R, len(l))))
+    ar = a.clone().requires_grad_(True)
+    ref = orc.forward_alm(ar, Y)
+    gv = T64(rng.normal(size=tuple(ref.shape)))
+    (ref * gv).sum().backward()
+    Yd = Y.to(torch.complex64).cuda()
+    res = {}
+    for packed in (False, True):
+        monkeypatch.setattr(ops, 'ALM_PACKED', packed)
+        monkeypatch.setattr(ops, 'ALM_PACKED_MIN_BYTES', 0)
+        x = a.to(torch.complex64).cuda().requires_grad_(True)
+        y = ops.alm2pix(x, Yd)
+        (y * gv.float().cuda()).sum().backward()
+        assert (getattr(Yd, '_rime_packed', None) is not None) == packed
+        if packed:
+            assert set(Yd._rime_packed[3]) == {0, 1} and all(b is not False for b in Yd._rime_packed[3].values())
+        res[packed] = (y.detach(), x.grad.detach())
+        assert relmax(y, ref) < 1e-5 and relmax(x.grad, ar.grad) < 1e-5
+    assert torch.equal(res[False][0], res[True][0])
+    if Npix % 2 == 0:
+        assert torch.equal(res[False][1], res[True][1])
+    else:
+        assert relmax(res[True][1], res[False][1]) < 2e-6
+
+
+def test_alm2pix_packed_ylm_is_repacked_when_ylm_changes(ops, monkeypatch):
+    """the packed copies live on the Ylm tensor object with its version counter: an in-place update or another tensor
+    (what AlmModel.setup_Ylm installs) must not be served from a stale copy"""
+    monkeypatch.setattr(ops, 'ALM_PACKED', True)
+    monkeypatch.setattr(ops, 'ALM_PACKED_MIN_BYTES', 0)
+    rng = np.random.default_rng(5)
+    l, m = orc.gen_lm(20)
+    Npix = 4096
+    th, ph = np.arccos(rng.uniform(-1, 1, Npix)), rng.uniform(0, 2 * np.pi, Npix)
+    Y = torch.as_tensor(orc.sph_Ylm(th, ph, l, m)).to(torch.complex64).cuda()
+    a = torch.as_tensor(rng.normal(size=(8, len(l))) + 1j * rng.normal(size=(8, len(l)))).to(torch.complex64).cuda()
+    y1 = ops.alm2pix(a, Y)
+    first = Y._rime_packed[3][0]
+    assert ops.alm2pix(a, Y) is not None and Y._rime_packed[3][0] is first          # second call: the cached copy
+    Y.mul_(2.0)                                                                   # in place: version counter moves
+    y2 = ops.alm2pix(a, Y)
+    assert Y._rime_packed[3][0] is not first
+    assert relmax(y2, 2.0 * y1) < 1e-6
+    Y2 = (Y * 0.25).contiguous()                                                  # another tensor
+    y3 = ops.alm2pix(a, Y2)
+    assert relmax(y3, 0.5 * y1) < 1e-6
+    # through the model: setup_Ylm replaces the matrix
+    from bayeslim_amd import sph_harm
+    A = sph_harm.AlmModel(l, m, real_output=True)
+    A.device = torch.device('cuda', 0)
+    A.setup_Ylm(np.rad2deg(th), np.rad2deg(ph), Ylm=Y2, alm_mult=None)
+    o1 = A(a)
+    A.setup_Ylm(np.rad2deg(th), np.rad2deg(ph), Ylm=(Y2 * 3.0).contiguous(), alm_mult=None)
+    assert relmax(A(a), 3.0 * o1) < 1e-6
+
+
 def test_ops_refuse_cpu_tensors(ops):
     with pytest.raises(RuntimeError):
         ops.alm2pix(torch.zeros(2, 3, dtype=torch.complex64), torch.zeros(3, 4, dtype=torch.complex64))

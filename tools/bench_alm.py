@@ -28,6 +28,11 @@ def run(R, Nc, Npix, reps=5):
         print('  %s R=%d Nc=%d Npix=%d: %.3f ms  %.1f TFLOP/s  %.0f GB/s (Ylm stream)' % (name, R, Nc, Npix, ms, flop / ms * 1e-9, byts / ms * 1e-6), flush=True)
 
 print(ops._lib.version())
-run(128, 8385, 49152)
-run(128, 2145, 196608)
-run(4, 8385, 49152)
+for packed in (False, True):
+    ops.ALM_PACKED = packed
+    print('packed Ylm (cached pre-split f16 copies in fragment order):' if packed else 'Ylm split inside the kernels:', flush=True)
+    run(128, 8385, 49152)
+    run(128, 2145, 196608)
+    run(4, 8385, 49152)
+    if len(sys.argv) > 1:
+        run(128, 8385, 44279)            # the C3 bench's own pixel count class (odd)
