@@ -342,6 +342,51 @@ split_rows_kernel(const float* __restrict__ X, int R, int L, int Rpad, int neg_o
     }
 }
 
+// The same two steps in ONE launch when there are enough rows to fill the chip with one block per row (R >= 64): the
+// block scans its row for the maximum, then reads it again (L2) and splits -- no atomics, no memset, one launch instead
+// of three (round 3: 44 -> ~12 us in front of the C3-shape backward).
+__global__ void __launch_bounds__(256)
+split_rows_fused_kernel(const float* __restrict__ X, int R, int L, int Rpad, int neg_odd, uint4* __restrict__ img_hi,
+                        uint4* __restrict__ img_lo, float* __restrict__ inv_scale)
+{
+    __shared__ float wmax[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int nsteps = (L + 15) / 16;
+    float m = 0.f;
+    if (r < R) {
+        const float* row = X + (size_t)r * L;
+        if ((L & 3) == 0) {
+            for (int i = tid; i < L / 4; i += 256) {
+                const float4 v = reinterpret_cast<const float4*>(row)[i];
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+        } else {
+            for (int i = tid; i < L; i += 256) m = fmaxf(m, fabsf(row[i]));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0) wmax[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    float scale = 1.0f;
+    if (r < R && m > 0.f) scale = exp2f(fminf(fmaxf(floorf(log2f(8192.0f / m)), -100.f), 100.f));
+    if (tid == 0) inv_scale[r] = (r < R) ? 1.0f / scale : 0.f;
+    for (int g = tid; g < nsteps * 2; g += 256) {
+        float v[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int k = g * 8 + jj;
+            float x = (r < R && k < L) ? X[(size_t)r * L + k] * scale : 0.f;
+            v[jj] = (neg_odd && (jj & 1)) ? -x : x;
+        }
+        uint4 hi, lo;
+        split2h(v[0], v[1], hi.x, lo.x); split2h(v[2], v[3], hi.y, lo.y);
+        split2h(v[4], v[5], hi.z, lo.z); split2h(v[6], v[7], hi.w, lo.w);
+        img_hi[(size_t)g * Rpad + r] = hi;
+        img_lo[(size_t)g * Rpad + r] = lo;
+    }
+}
+
 // forward: out[r, j] = sum_k A[r, k] Y[k, j], k = (c, re|im).  Block = 4 waves x 32 pixels, MT row
 // tiles per wave; per chunk of 32 coefficients (4 K steps) the block copies the pre-split A
 // granules to LDS (fetched one chunk ahead into registers) and every lane splits the 16 Ylm values
@@ -829,8 +874,12 @@ template <int MT>
 __global__ void __launch_bounds__(256)
 alm2pix_fwd_packed_kernel(const uint4* __restrict__ a_hi, const uint4* __restrict__ a_lo,
                           const float* __restrict__ inv_scale, const uint4* __restrict__ Yf, float y_scale,
-                          int R, int Rpad, int Ncoeff, int Npix, int nsteps, float* __restrict__ out)
+                          int R, int Rpad, int Ncoeff, int Npix, int nsteps, int chunks_per_split, float* __restrict__ out)
 {
+    // blockIdx.z = K split: chunks [z * chunks_per_split, ...) of the coefficient axis; the split's partial result goes
+    // to plane z of `out` (S > 1: a workspace, summed in a fixed order by alm_reduce_kernel).  A wave owns a pixel tile, so
+    // a map of Npix pixels offers only Npix / 32 waves: small maps are split over K as well (49 152 px: 384 blocks for
+    // 512 resident ones -> 2 splits, - 6 %)
     constexpr int ROWS = MT * 32;
     constexpr int NG = 8 * ROWS;                       // A granules per image and chunk: (ks, h, row)
     constexpr int PT = NG / 256;
@@ -880,11 +929,12 @@ alm2pix_fwd_packed_kernel(const uint4* __restrict__ a_hi, const uint4* __restric
             }
         }
     };
-    const int nchunk = nsteps / PK_FWD_CHUNK;
-    load_b(0, b0);
-    if (nchunk > 1) load_b(4, b1);
-    fetch_a(0);
-    for (int ch = 0; ch < nchunk; ch += 2) {
+    const int ch0 = blockIdx.z * chunks_per_split;
+    const int nchunk = min(nsteps / PK_FWD_CHUNK, ch0 + chunks_per_split);
+    if (ch0 < nchunk) load_b(4 * ch0, b0);
+    if (ch0 + 1 < nchunk) load_b(4 * (ch0 + 1), b1);
+    fetch_a(4 * ch0);
+    for (int ch = ch0; ch < nchunk; ch += 2) {
 #pragma unroll
         for (int u = 0; u < PT; ++u) { lds_hi[0][tid + u * 256] = ahq[u]; lds_lo[0][tid + u * 256] = alq[u]; }
         __syncthreads();
@@ -907,9 +957,28 @@ alm2pix_fwd_packed_kernel(const uint4* __restrict__ a_hi, const uint4* __restric
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = r0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (row < R) out[(size_t)row * Npix + col] = acc[m][e] * inv_scale[row] * iy;
+                if (row < R) out[((size_t)blockIdx.z * R + row) * Npix + col] = acc[m][e] * inv_scale[row] * iy;
             }
     }
+}
+
+// K splits of the packed forward (two 4-wave blocks per CU are resident), each split >= 16 chunks
+static int fwd_packed_splits(int R, int Ncoeff, int Npix, int MT)
+{
+    static long resident = 0;
+    if (resident == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        resident = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? 2L * prop.multiProcessorCount : 512;
+        (void)hipGetLastError();
+    }
+    const long blocks = (long)((Npix + 127) / 128) * ((R + MT * 32 - 1) / (MT * 32));
+    const int nchunk = pk_fwd_steps(Ncoeff) / PK_FWD_CHUNK;
+    // measured at the C3 shape (384 blocks of 263 chunks, 512 resident): S 1 / 2 / 3 / 4 / 6 -> 0.911 / 0.853 / 0.890 /
+    // 0.871 / 0.898 ms including the reduction of the partial planes: enough blocks for 1.5 resident grids, no more
+    int best = (int)std::min<long>(4, std::max<long>(1, (3 * resident / 2 + blocks - 1) / blocks));
+    while (best > 1 && nchunk / best < 16) --best;
+    if (const char* e = getenv("RIME_ALM_FWD_SPLITS")) { const int v = atoi(e); if (v >= 1 && v <= 8 && nchunk / v >= 1) best = v; }   // lab
+    return best;
 }
 
 // backward on the packed copy: the LDS-DMA ring of alm2pix_bwd_f16_dma_kernel with the chunk's Ylm tile replaced by
@@ -1142,6 +1211,11 @@ static void launch_split_rows(const float* X, int R, int L, const SplitPlan& p, 
     inv = (float*)((char*)workspace + 2 * p.img_bytes);
     unsigned int* rowmax = (unsigned int*)(inv + p.Rpad);
     const int nseg = (2 * p.nsteps * 8 + SPLIT_SEG - 1) / SPLIT_SEG;
+    if (R >= 64) {
+        (void)hipMemsetAsync((char*)rowmax + (size_t)p.Rpad * sizeof(unsigned int), 0, 64, st);     // the zero granule
+        hipLaunchKernelGGL(split_rows_fused_kernel, dim3(p.Rpad), dim3(256), 0, st, X, R, L, p.Rpad, neg_odd, hi, lo, inv);
+        return;
+    }
     (void)hipMemsetAsync(rowmax, 0, (size_t)p.Rpad * sizeof(unsigned int) + 64, st);     // + the zero granule behind it
     hipLaunchKernelGGL(row_absmax_kernel, dim3(R, (L + SPLIT_SEG - 1) / SPLIT_SEG), dim3(256), 0, st, X, R, L, rowmax);
     hipLaunchKernelGGL(split_rows_kernel, dim3(p.Rpad, std::max(1, nseg)), dim3(256), 0, st, X, R, L, p.Rpad,
@@ -1208,7 +1282,9 @@ extern "C" size_t rime_alm2pix_fwd_workspace(int dtype, int R, int Ncoeff, int N
 {
     if (dtype != RIME_F32 || R <= 0 || Ncoeff <= 0) return 0;
     const SplitPlan p = split_plan(R, 2 * Ncoeff, Ncoeff, false);
-    return split_ws_bytes(p);
+    if (Npix <= 0) return split_ws_bytes(p);
+    const int S = fwd_packed_splits(R, Ncoeff, Npix, p.MT);                   // rime_alm2pix_fwd_packed: K-split partial planes
+    return split_ws_bytes(p) + (S > 1 ? (size_t)S * R * Npix * sizeof(float) : 0);
 }
 
 extern "C" int rime_alm2pix_fwd(int dtype, const void* alm, const void* Ylm, double y_scale, int R, int Ncoeff,
@@ -1358,13 +1434,22 @@ extern "C" int rime_alm2pix_fwd_packed(const void* alm, const void* packed, doub
     if (!workspace || workspace_bytes < split_ws_bytes(p)) return RIME_EWORKSPACE;
     uint4 *hi, *lo; float* inv;
     launch_split_rows((const float*)alm, R, 2 * Ncoeff, p, 1, workspace, st, hi, lo, inv);
-    dim3 grid((Npix + 127) / 128, p.Rpad / (p.MT * 32));
+    const int S = fwd_packed_splits(R, Ncoeff, Npix, p.MT);
+    const size_t len = (size_t)R * Npix;
+    if (S > 1 && workspace_bytes < split_ws_bytes(p) + (size_t)S * len * sizeof(float)) return RIME_EWORKSPACE;
+    dim3 grid((Npix + 127) / 128, p.Rpad / (p.MT * 32), S);
     const float ys = (float)y_scale;
-    const uint4* Y = (const uint4*)packed; float* o = (float*)out;
+    const uint4* Y = (const uint4*)packed;
+    float* o = S > 1 ? (float*)((char*)workspace + split_ws_bytes(p)) : (float*)out;
     const int nsteps = pk_fwd_steps(Ncoeff);
-    if (p.MT == 4) hipLaunchKernelGGL((alm2pix_fwd_packed_kernel<4>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, nsteps, o);
-    else if (p.MT == 2) hipLaunchKernelGGL((alm2pix_fwd_packed_kernel<2>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, nsteps, o);
-    else hipLaunchKernelGGL((alm2pix_fwd_packed_kernel<1>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, nsteps, o);
+    const int cps = (nsteps / PK_FWD_CHUNK + S - 1) / S;
+    if (p.MT == 4) hipLaunchKernelGGL((alm2pix_fwd_packed_kernel<4>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, nsteps, cps, o);
+    else if (p.MT == 2) hipLaunchKernelGGL((alm2pix_fwd_packed_kernel<2>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, nsteps, cps, o);
+    else hipLaunchKernelGGL((alm2pix_fwd_packed_kernel<1>), grid, dim3(256), 0, st, hi, lo, inv, Y, ys, R, p.Rpad, Ncoeff, Npix, nsteps, cps, o);
+    if (S > 1) {
+        int nb = (int)std::min<size_t>((len + 255) / 256, 2048);
+        hipLaunchKernelGGL(alm_reduce_kernel, dim3(nb), dim3(256), 0, st, o, (float*)out, len, S);
+    }
     return check_launch();
 }
 

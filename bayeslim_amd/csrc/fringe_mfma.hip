@@ -1402,6 +1402,43 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
     }
 }
 
+// Power-of-two pre-scale (and minimum) of the rows the matrix-core kernels contract: scale = 2^floor(log2(2^14 / max|x|))
+// (1 for an all-zero row), rowmin = min x.  One block per row; rows are enumerated (d0, d1, d2, d3) in OUTPUT order and
+// found through four element strides, so a strided psky view needs no copy.  Replaces a dozen elementwise / reduction
+// launches per fringe call (aminmax, maximum, log2, floor, clamp, exp2, where, permute + contiguous) -- host time, not
+// device time, is what it saves (a rank's share at 8 GPUs spends a sixth of its step enqueueing).
+__global__ void __launch_bounds__(256)
+row_scale_kernel(const float* __restrict__ x, int d1, int d2, int d3, long long s0, long long s1, long long s2, long long s3,
+                 int L, float* __restrict__ scale, float* __restrict__ rowmin)
+{
+    __shared__ float wlo[4], whi[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int i3 = r % d3, i2 = (r / d3) % d2, i1 = (r / (d3 * d2)) % d1, i0 = r / (d3 * d2 * d1);
+    const float* row = x + i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3;
+    float lo = INFINITY, hi = -INFINITY;
+    if ((L & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+        for (int i = tid; i < L / 4; i += 256) {
+            const float4 v = reinterpret_cast<const float4*>(row)[i];
+            lo = fminf(fminf(lo, fminf(v.x, v.y)), fminf(v.z, v.w));
+            hi = fmaxf(fmaxf(hi, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        }
+    } else {
+        for (int i = tid; i < L; i += 256) { const float v = row[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    if ((tid & 63) == 0) { wlo[tid >> 6] = lo; whi[tid >> 6] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+        lo = fminf(fminf(wlo[0], wlo[1]), fminf(wlo[2], wlo[3]));
+        hi = fmaxf(fmaxf(whi[0], whi[1]), fmaxf(whi[2], whi[3]));
+        const float amax = fmaxf(hi, -lo);
+        float sc = 1.0f;
+        if (amax > 0.f && amax < INFINITY) sc = exp2f(fminf(fmaxf(floorf(log2f(16384.0f / amax)), -100.f), 100.f));
+        scale[r] = sc;
+        if (rowmin) rowmin[r] = lo;
+    }
+}
+
 // vis[bl][t][f][c] = sum_s ws[s][t][f][c][bl]: block = (32 baselines, 32 channels, one time); reads are
 // coalesced along bl, the 32x32 tile is turned through LDS, writes are 256-B runs along f.
 __global__ void __launch_bounds__(256)
@@ -1590,6 +1627,17 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
             break;
     }
 #undef RIME_FWD_PAIR
+    return check_launch();
+}
+
+extern "C" int rime_fringe_row_scale(const float* x, int d0, int d1, int d2, int d3, long long s0, long long s1,
+                                     long long s2, long long s3, int L, float* scale, float* rowmin, void* stream)
+{
+    if (!x || !scale || d0 <= 0 || d1 <= 0 || d2 <= 0 || d3 <= 0 || L <= 0) return RIME_EINVAL;
+    const long long rows = (long long)d0 * d1 * d2 * d3;
+    if (rows > 0x7fffffffLL) return RIME_EUNSUPPORTED;
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       x, d1, d2, d3, s0, s1, s2, s3, L, scale, rowmin);
     return check_launch();
 }
 

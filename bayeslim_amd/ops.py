@@ -276,11 +276,19 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
             amax = inp.abs().amax(dim=(-1, -2))                                    # (Nt, Nmp, Npp, Nf)
             lo = inp.amin(dim=-2)                                                  # (Nt, Nmp, Npp, Nf, 2): per plane
             rowmin = [lo[..., c].permute(1, 2, 0, 3).contiguous() for c in range(2)]
+        elif inp.stride(-1) == 1:
+            # one launch: power-of-two scale and minimum of every (mp, pp, t, f) row, through the view's strides
+            scale = torch.empty((Nmp, Npp, Nt, Nf), dtype=torch.float32, device=dev)
+            rowmin = [torch.empty_like(scale)]
+            check(lib.rime_fringe_row_scale(_ptr(inp), Nmp, Npp, Nt, Nf, inp.stride(1), inp.stride(2), inp.stride(0),
+                                            inp.stride(3), inp.shape[-1], _ptr(scale), _ptr(rowmin[0]), _stream()),
+                  'rime_fringe_row_scale')
         else:
             lo, hi = torch.aminmax(inp, dim=-1)                                    # one pass, no |psky| temporary
             amax = torch.maximum(hi, -lo)
             rowmin = [lo.permute(1, 2, 0, 3).contiguous()]
-        scale = _pow2_scale(amax.permute(1, 2, 0, 3)).contiguous()                 # (Nmp, Npp, Nt, Nf)
+        if cplx or inp.stride(-1) != 1:
+            scale = _pow2_scale(amax.permute(1, 2, 0, 3)).contiguous()             # (Nmp, Npp, Nt, Nf)
         nbytes = lib.rime_fringe_ant_workspace(Nbl, Nt, Nf, geom.Pstride)
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
         two_pass = [blk for blk in blocks if cplx and blk['fwd_cpass'] == 0]
@@ -333,8 +341,9 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
                 if c == 0:
                     # max |gvis| per (t, f) from the transposed copy: a contiguous row reduction (the same
                     # reduction over the (Nbl, Nt, Nf, 2) layout is strided and 4x slower); -i g has the same maxima
-                    lo, hi = torch.aminmax(gvt, dim=-1)
-                    scale_pp = _pow2_scale(torch.maximum(hi, -lo)).contiguous()    # (Nt * Nf)
+                    scale_pp = torch.empty(Nt * Nf, dtype=torch.float32, device=dev)
+                    check(lib.rime_fringe_row_scale(_ptr(gvt), 1, 1, 1, Nt * Nf, 0, 0, 0, 2 * Nbl, 2 * Nbl, _ptr(scale_pp),
+                                                    None, _stream()), 'rime_fringe_row_scale')
                 # single-pass blocks first: they initialise BOTH planes of their psky slice, the two-pass
                 # blocks then accumulate plane by plane
                 todo = sorted(blocks, key=lambda b: not (cplx and b['cpass'] != 0)) if c == 0 else two_pass

@@ -164,6 +164,14 @@ int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, const 
                               const float* rowmin, const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf,
                               int Pstride, long long st_t, long long st_f, long long st_p, int sign,
                               int psky_complex, void* workspace, size_t workspace_bytes, void* stream);
+/* Row pre-scales of the matrix-core kernels in one launch: for every row (i0, i1, i2, i3) of a 4-D arrangement of
+ * contiguous float32 rows of length L at x + i0 s0 + i1 s1 + i2 s2 + i3 s3 (element strides):
+ *   scale[row]  = 2^floor(log2(2^14 / max|x|)) (1 for an all-zero row)   -- the `scale` / `gscale` inputs above
+ *   rowmin[row] = min x (or NULL)                                          -- the `rowmin` input of the forward
+ * rows numbered ((i0 d1 + i1) d2 + i2) d3 + i3.  Host-side convenience (what the shipped binding computes these two
+ * inputs with); the reference has no counterpart. */
+int rime_fringe_row_scale(const float* x, int d0, int d1, int d2, int d3, long long s0, long long s1,
+                          long long s2, long long s3, int L, float* scale, float* rowmin, void* stream);
 int rime_fringe_ant_fwd_finish(const void* workspace, size_t workspace_bytes, float* vis,
                                int Nbl, int Nt, int Nf, int Pstride, void* stream);
 int rime_fringe_ant_bwd_prepare(const float* gvis, int Nbl, int Nt, int Nf,
