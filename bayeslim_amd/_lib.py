@@ -51,6 +51,8 @@ SIGNATURES = {
     'rime_interp_scatter_bwd': (_i, [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'rime_beam_sky_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rime_beam_sky_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'rime_jones_apply_fwd': (_i, [_i, _i, _vp, _vp, _vp, _ll, _ll, _vp, _vp]),
+    'rime_jones_apply_bwd': (_i, [_i, _i, _vp, _vp, _vp, _vp, _ll, _ll, _vp, _vp, _vp, _vp]),
     'rime_chisq_workspace': (_sz, []),
     'rime_chisq_fwd': (_i, [_i, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     'rime_chisq_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),

@@ -13,8 +13,12 @@ import math
 import numpy as np
 import torch
 
-from . import utils, sph_harm
+import os
+
+from . import utils, sph_harm, ops
 from .utils import _float, _cfloat, D2R
+
+FUSED_JONES = os.environ.get('RIME_FUSED_JONES', '1') != '0'       # 4-pol beam x sky product in one pass (csrc/jones.hip)
 
 
 class PixelBeam(utils.Module):
@@ -212,6 +216,10 @@ class PixelBeam(utils.Module):
             assert tuple(sky.shape[:2]) == (1, 1)
             return beam1[:, :1] * sky[0:1, 0:1]                       # (2, 1, Nmp, Nf, P)
         assert tuple(sky.shape[:2]) == (2, 2)
+        if (sky.is_complex() and sky.is_cuda and FUSED_JONES and sky.shape[2] in (1, beam1.shape[2])
+                and beam1.dtype in (sky.dtype, sky.real.dtype)):
+            # J_p S J_q^dagger in one pass (csrc/jones.hip) instead of two broadcast products with 8x temporaries
+            return ops.jones_apply(beam1, beam1 if (beam2 is beam1) else beam2, sky)
         dt = torch.promote_types(beam1.dtype, sky.dtype)
         b1, b2c, sk = beam1.to(dt), beam2.conj().to(dt), sky.to(dt)
         # out[a,d] = sum_{b,c} b1[a,b] sky[b,c] conj(b2[d,c])   (J_p B J_q^dagger)

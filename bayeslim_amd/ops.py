@@ -631,6 +631,61 @@ def eq2top(ra, dec, M, vbary, vdiurnal):
 
 
 # ---------------------------------------------------------------------------------------
+class _JonesApply(torch.autograd.Function):
+    """psky[a, d] = sum_bc J1[a, b] S[b, c] conj(J2[d, c]) in one pass (csrc/jones.hip); J2 is J1 when `same`"""
+    @staticmethod
+    def forward(ctx, J1, J2, S, same):
+        _require_cuda(J1, J2, S)
+        j1 = J1.detach().contiguous()
+        j2 = j1 if same else J2.detach().contiguous()
+        sk = S.detach().contiguous()
+        assert sk.is_complex() and tuple(j1.shape[:2]) == (2, 2) and tuple(sk.shape[:2]) == (2, 2) and j1.shape == j2.shape
+        code, rdt = _real_dtype(sk)
+        bc = j1.is_complex()
+        assert (j1.dtype == sk.dtype) if bc else (j1.dtype == rdt), 'beam %s vs sky %s' % (j1.dtype, sk.dtype)
+        N, Ns = j1[0, 0].numel(), sk[0, 0].numel()
+        assert N % Ns == 0 and tuple(j1.shape[-2:]) == tuple(sk.shape[-2:])
+        out = torch.empty(j1.shape, dtype=sk.dtype, device=sk.device)
+        vr = torch.view_as_real
+        rc = lib.rime_jones_apply_fwd(code, int(bc), _ptr(vr(j1) if bc else j1), _ptr(vr(j2) if bc else j2), _ptr(vr(sk)),
+                                      N, Ns, _ptr(vr(out)), _stream())
+        check(rc, 'rime_jones_apply_fwd')
+        ctx.save_for_backward(j1, j2, sk)
+        ctx.same, ctx.sky_shape = same, tuple(S.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        j1, j2, sk = ctx.saved_tensors
+        g = g.contiguous()
+        code, _ = _real_dtype(sk)
+        bc = j1.is_complex()
+        N, Ns = j1[0, 0].numel(), sk[0, 0].numel()
+        g1, g2 = torch.empty_like(j1), torch.empty_like(j1)
+        gs = torch.empty(j1.shape, dtype=sk.dtype, device=sk.device)
+        vr = torch.view_as_real
+        rc = lib.rime_jones_apply_bwd(code, int(bc), _ptr(vr(j1) if bc else j1), _ptr(vr(j2) if bc else j2), _ptr(vr(sk)),
+                                      _ptr(vr(g)), N, Ns, _ptr(vr(g1) if bc else g1), _ptr(vr(g2) if bc else g2),
+                                      _ptr(vr(gs)), _stream())
+        check(rc, 'rime_jones_apply_bwd')
+        if N != Ns:                                       # one sky for several model pairs: sum their contributions
+            gs = gs.reshape(2, 2, N // Ns, Ns).sum(2)
+        gs = gs.reshape(ctx.sky_shape)
+        if ctx.same:
+            return g1 + g2, None, gs, None
+        return g1, g2, gs, None
+
+
+def jones_apply(J1, J2, S):
+    """
+    Full-polarisation beam x sky product J1 S J2^dagger per pixel, channel and beam-model pair (the 4-pol branch of
+    PixelBeam.apply_beam, beam_model.py:345-363).  J1, J2 (2, 2, Nmp, Nf, P) real or complex (J2 may be J1 itself),
+    S (2, 2, 1 | Nmp, Nf, P) complex -> (2, 2, Nmp, Nf, P) complex.
+    """
+    return _JonesApply.apply(J1, J2, S, J2 is J1)
+
+
+# ---------------------------------------------------------------------------------------
 class InterpStencil:
     """(inds, wgts) of PixInterp plus the CSR inverse index the deterministic adjoint uses."""
     def __init__(self, inds, wgts, Npb):

@@ -245,6 +245,22 @@ int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmapT, const voi
                       int Nt, int Ps, int Nnn, void* T1, void* gsky, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Full-polarisation beam x sky product, elementwise:  psky[a, d] = sum_{b, c} J1[a, b] S[b, c] conj(J2[d, c])
+ * Replaces the 4-pol branch of PixelBeam.apply_beam (beam_model.py:345-363, einsum "ab...,bc...,dc...->ad...") and
+ * its autograd backward in one pass each (the torch composition materialises two temporaries of 8 x psky).
+ *   J1, J2 : T [2, 2, N] (beam_complex = 0) or complex<T> [2, 2, N];  J2 may be the same pointer as J1
+ *   S      : complex<T> [2, 2, Ns], Ns dividing N (one sky for all Nmp model pairs: element n reads n % Ns)
+ *   out, G : complex<T> [2, 2, N]  (N = Nmp * Nf * P)
+ * Backward: gS [2, 2, N] = J1^H G J2 (the caller sums over model pairs when Ns < N), gJ1 = G (S J2^H)^H,
+ * gJ2 = G^H (J1 S) -- real parts for a real beam -- each [2, 2, N] in the beam's type.  The caller adds gJ1 + gJ2 when
+ * J2 is J1.
+ * ------------------------------------------------------------------------------------- */
+int rime_jones_apply_fwd(int dtype, int beam_complex, const void* J1, const void* J2, const void* S,
+                         long long N, long long Ns, void* out, void* stream);
+int rime_jones_apply_bwd(int dtype, int beam_complex, const void* J1, const void* J2, const void* S,
+                         const void* G, long long N, long long Ns, void* gJ1, void* gJ2, void* gS, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * a_lm -> pixel transform:  out[r, j] = sum_c ( are[r,c] * Yre[c,j] - aim[r,c] * Yim[c,j] )
  *   = Re( (a * alm_mult) @ Ylm ), with alm_mult already folded into `alm` by the caller
  *   (an elementwise torch op, kept in autograd).

@@ -1035,6 +1035,46 @@ def test_alm2pix_packed_ylm_is_repacked_when_ylm_changes(ops, monkeypatch):
     assert relmax(A(a), 3.0 * o1) < 1e-6
 
 
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+@pytest.mark.parametrize('beam_complex,Nmp,same', [(False, 1, True), (True, 1, True), (False, 3, False), (True, 2, False)])
+def test_jones_apply_against_the_einsum(ops, dtype, beam_complex, Nmp, same):
+    """fused J1 S J2^dagger (csrc/jones.hip) against the einsum of the reference's 4-pol apply_beam branch
+    (beam_model.py:345-363, "ab...,bc...,dc...->ad...") in float64 on the CPU: values and the gradients with respect
+    to both beams and the sky, real and complex (Jones) beams, one sky shared by several beam-model pairs"""
+    rng = np.random.default_rng(17 + Nmp)
+    Nf, P = 5, 333
+    rdt, cdt = (torch.float64, torch.complex128) if dtype == 'f64' else (torch.float32, torch.complex64)
+    tol = 1e-12 if dtype == 'f64' else 2e-6
+
+    def beam():
+        b = rng.normal(size=(2, 2, Nmp, Nf, P))
+        return torch.as_tensor(b + 1j * rng.normal(size=b.shape)) if beam_complex else torch.as_tensor(b)
+
+    b1 = beam()
+    b2 = b1 if same else beam()
+    sk = torch.as_tensor(rng.normal(size=(2, 2, 1, Nf, P)) + 1j * rng.normal(size=(2, 2, 1, Nf, P)))
+    g = torch.as_tensor(rng.normal(size=(2, 2, Nmp, Nf, P)) + 1j * rng.normal(size=(2, 2, Nmp, Nf, P)))
+    # reference (float64, CPU)
+    r1 = b1.clone().requires_grad_(True)
+    r2 = r1 if same else b2.clone().requires_grad_(True)
+    rs = sk.clone().requires_grad_(True)
+    ref = torch.einsum('ab...,bc...,dc...->ad...', r1.to(torch.complex128), rs.expand(2, 2, Nmp, Nf, P), r2.conj().to(torch.complex128))
+    (ref * g.conj()).real.sum().backward()
+    # device
+    bdt = cdt if beam_complex else rdt
+    d1 = b1.to(bdt).cuda().requires_grad_(True)
+    d2 = d1 if same else b2.to(bdt).cuda().requires_grad_(True)
+    ds = sk.to(cdt).cuda().requires_grad_(True)
+    out = ops.jones_apply(d1, d2, ds)
+    assert out.shape == (2, 2, Nmp, Nf, P) and out.dtype == cdt
+    (out * g.to(cdt).cuda().conj()).real.sum().backward()
+    assert relmax(out, ref) < tol
+    assert relmax(d1.grad, r1.grad) < tol and relmax(ds.grad, rs.grad) < tol
+    if not same:
+        assert relmax(d2.grad, r2.grad) < tol
+    assert d1.grad.dtype == bdt and ds.grad.shape == ds.shape
+
+
 def test_ops_refuse_cpu_tensors(ops):
     with pytest.raises(RuntimeError):
         ops.alm2pix(torch.zeros(2, 3, dtype=torch.complex64), torch.zeros(3, 4, dtype=torch.complex64))

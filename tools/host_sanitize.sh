@@ -7,7 +7,7 @@ out=${1:-/tmp/rime_asan}
 mkdir -p $out
 FLAGS="-O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -Wno-unused-function"
 objs=""
-for f in fringe.hip fringe_mfma.hip interp.hip alm.hip chisq.hip cal.hip eq2top.hip capi.cpp comm.cpp; do
+for f in fringe.hip fringe_mfma.hip interp.hip alm.hip chisq.hip cal.hip eq2top.hip jones.hip capi.cpp comm.cpp; do
   o=$out/$(basename ${f%.*}).o
   case $f in *.cpp) x="-x hip";; *) x="";; esac
   /opt/rocm/bin/hipcc $FLAGS $x -c bayeslim_amd/csrc/$f -o $o &

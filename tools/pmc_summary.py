@@ -59,6 +59,17 @@ def main():
                 entry['valu_issue_frac_of_simd_cycles'] = (entry['SQ_ACTIVE_INST_VALU'] - entry['SQ_INSTS_MFMA']) * 4 / simd_cycles
         res[k] = entry
     json.dump(res, open(out, 'w'), indent=1)
+    # traffic.json beside it: HBM bytes per launch per kernel NAME (what bench.py quotes as roofline.traffic, with
+    # traffic_source), instantiations of one kernel template listed and summed in proportion to their launches
+    traffic = {}
+    for k, e in res.items():
+        if 'hbm_bytes_per_launch' not in e:
+            continue
+        base = k.split('<')[0]
+        t = traffic.setdefault(base, dict(hbm_bytes_per_launch=0.0, instantiations={}))
+        t['instantiations'][k] = dict(hbm_bytes_per_launch=e['hbm_bytes_per_launch'], duration_ms_larger_half=e['duration_ms'])
+        t['hbm_bytes_per_launch'] += e['hbm_bytes_per_launch']
+    json.dump(traffic, open(os.path.join(os.path.dirname(os.path.abspath(out)), 'traffic.json'), 'w'), indent=1)
     for k, e in res.items():
         print(k, {c: (round(v, 4) if isinstance(v, float) else v) for c, v in e.items()})
 
