@@ -1098,6 +1098,24 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                 const int bc = A.pair_conj[i * MF_NA + j0 + q];
                 if (bc >= 0) { gr[q] += gre[bc]; gi[q] -= gim[bc]; }
             }
+            if constexpr (!CPLX) {
+                if (ti == tj) {
+                    // diagonal tile, real psky: Re(E^H conj(G) E) = 1/2 E^H H E with H = conj(G) + conj(G)^H Hermitian
+                    //   = Er^T S Er + Ei^T S Ei + Ei^T A Er,   S = (Gr + Gr^T) / 2 (symmetric),  A = Gi^T - Gi (antisymmetric)
+                    // i.e. accR = S Er, accI = S Ei + A Er: three real products instead of four (9 MFMAs, not 12).  The
+                    // planes hold S in place of Gr and A in place of -Gi; the Gi planes of these tiles are not read.
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float tr = 0.f, ti_ = 0.f;               // G[j, i]
+                        const int bd = A.pair_direct[(j0 + q) * MF_NA + i];
+                        if (bd >= 0) { tr += gre[bd]; ti_ += gim[bd]; }
+                        const int bc = A.pair_conj[(j0 + q) * MF_NA + i];
+                        if (bc >= 0) { tr += gre[bc]; ti_ -= gim[bc]; }
+                        const float s_ = 0.5f * (gr[q] + tr), a_ = ti_ - gi[q];
+                        gr[q] = s_; gi[q] = -a_;                 // the "-Gi" plane (ih ^ sign) then holds +A
+                    }
+                }
+            }
         }
         uint32_t rh, rl, ih, il;
         split2(gr[0] * gs, gr[1] * gs, rh, rl);
@@ -1184,6 +1202,24 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                             // two lane bases + 16-bit immediates reach all six planes (left alone, the compiler
                             // keeps 19 per-tile bases and adds the plane offsets: 62 v_add per pixel tile)
                             const int tk = (tri_index(ti, tj) * 2 + ks) * 1024;
+                            if constexpr (!CPLX) {
+                                if (ti == tj) {              // (compile-time after unrolling) symmetric form: 9 MFMAs
+                                    const uint4 Gnh = *reinterpret_cast<const uint4*>(g_img + gl0 + 2 * MB_PLANE + tk);
+                                    const uint4 Gnl = *reinterpret_cast<const uint4*>(g_img + gl1 + 2 * MB_PLANE + tk);
+                                    const uint4 Grh = *reinterpret_cast<const uint4*>(g_img + gl0 + 0 * MB_PLANE + tk);
+                                    const uint4 Grl = *reinterpret_cast<const uint4*>(g_img + gl1 + 0 * MB_PLANE + tk);
+                                    accR[ti] = RIME_MFMA(Grh, Erh, accR[ti]);
+                                    accI[ti] = RIME_MFMA(Grh, Eih, accI[ti]);
+                                    accI[ti] = RIME_MFMA(Gnh, Erh, accI[ti]);
+                                    accR[ti] = RIME_MFMA(Grh, Erl, accR[ti]);
+                                    accI[ti] = RIME_MFMA(Grh, Eil, accI[ti]);
+                                    accI[ti] = RIME_MFMA(Gnh, Erl, accI[ti]);
+                                    accR[ti] = RIME_MFMA(Grl, Erh, accR[ti]);
+                                    accI[ti] = RIME_MFMA(Grl, Eih, accI[ti]);
+                                    accI[ti] = RIME_MFMA(Gnl, Erh, accI[ti]);
+                                    continue;
+                                }
+                            }
                             const uint4 Grh = *reinterpret_cast<const uint4*>(g_img + gl0 + 0 * MB_PLANE + tk);
                             const uint4 Gih = *reinterpret_cast<const uint4*>(g_img + gl0 + 1 * MB_PLANE + tk);
                             const uint4 Gnh = *reinterpret_cast<const uint4*>(g_img + gl0 + 2 * MB_PLANE + tk);

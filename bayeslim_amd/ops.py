@@ -360,7 +360,7 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
                                                        *shape, blk['cpass'] if single else 0, acc, dst,
                                                        _ptr(ws), ws.numel(), _stream())
                     check(rc, 'rime_fringe_ant_bwd_block')
-                    flops += blk['mf_bwd']
+                    flops += blk['mf_bwd'] if single else blk['mf_bwd_real']
             assert len(written) == Nmp * m, 'every psky plane must be written by a block'
     return flops * per16
 
@@ -410,6 +410,7 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
             rows, TA = pi.contiguous(), (pi.shape[0] + 31) // 32
             mf_fwd = 12 * (TA * (TA - 1) // 2) + 7 * TA      # diagonal tiles: symmetric products folded
             mf_bwd = 12 * (TA * (TA + 1) // 2)
+            mf_bwd_real = 12 * (TA * (TA - 1) // 2) + 9 * TA   # real psky: symmetric form on the diagonal tiles (round 3)
             cross, fwd_cpass = 0, 0                          # forward diagonal blocks: one real plane per call ...
             self_pos, mf_self = None, 0
             if SELF_BLOCKS and blk['cpass'] != 0:
@@ -426,18 +427,18 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
             rows = torch.zeros(blk['rows_i'] + blk['rows_j'], 3, dtype=torch.float64, device=dev)
             rows[:pi.shape[0]] = pi
             rows[blk['rows_i']:blk['rows_i'] + pj.shape[0]] = pj
-            mf_fwd = mf_bwd = 12 * (blk['rows_i'] // 32) * (blk['rows_j'] // 32)
+            mf_fwd = mf_bwd = mf_bwd_real = 12 * (blk['rows_i'] // 32) * (blk['rows_j'] // 32)
             cross, fwd_cpass = blk['rows_i'], blk['cpass']
         if fwd_cpass == 0:
             slots = np.concatenate([blk['direct'][blk['direct'] >= 0], blk['conj'][blk['conj'] >= 0]])
             two_pass_mask[torch.as_tensor(slots, dtype=torch.int64, device=dev)] = 1.0
         blocks.append(dict(pos=rows, nrows=int(rows.shape[0]), cross=int(cross), mp=blk['mp'],
-                           cpass=blk['cpass'], fwd_cpass=fwd_cpass, mf_fwd=mf_fwd, mf_bwd=mf_bwd,
+                           cpass=blk['cpass'], fwd_cpass=fwd_cpass, mf_fwd=mf_fwd, mf_bwd=mf_bwd, mf_bwd_real=mf_bwd_real,
                            self_pos=self_pos, mf_self=mf_self,
                            direct=torch.as_tensor(blk['direct'].reshape(-1), device=dev),
                            conj=torch.as_tensor(blk['conj'].reshape(-1), device=dev)))
         mfma_fwd += mf_fwd
-        mfma_bwd += mf_bwd
+        mfma_bwd += mf_bwd_real
     # executed matrix-core work per pass: per 16 pixels, 12 MFMAs of 2*32*32*16 flop on each 32x32
     # antenna tile of every block (3 hi/lo products x 4 real products); the forward runs 7 on the
     # diagonal tiles of a diagonal block
