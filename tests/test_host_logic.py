@@ -602,3 +602,29 @@ def test_astrometry_host_chain_against_the_independent_oracle():
     zen, az = telescope_model.eq2top((21.42827, -30.72148), 2459861.37, ra, dec)
     z2, _ = E.eq2top((21.42827, -30.72148, 0.0), 2459861.37, ra, dec)
     assert np.abs(np.asarray(zen) - z2).max() > 0.1
+
+
+def test_rime_zenaz_cache_follows_the_conv_cache_entry_not_its_address():
+    """RIME's per-key (zen, az) cache was validated by id() of the telescope's conv_cache entry; after
+    clear_cache() + repopulate CPython can hand the same address to the new entry and the stale angles were served.
+    The cache now holds the entry itself and compares with `is`: 200 clear / repopulate rounds never return a stale
+    value (the old check failed this within a few rounds)."""
+    import types
+    import numpy as np
+    import torch
+    from bayeslim_amd import rime_model, telescope_model
+    tel = telescope_model.TelescopeModel((21.42827, -30.72148))
+    fake = types.SimpleNamespace(telescope=tel, _zenaz_cache={}, cache_eq2top=True)
+    key = ('sky', 5, 2459861.0)
+    ra = torch.linspace(0, 300, 5, dtype=torch.float64)
+    dec = torch.linspace(-60, 20, 5, dtype=torch.float64)
+    dev = torch.device('cpu')
+    for k in range(200):
+        tel.clear_cache()
+        entry = torch.stack([torch.full((5,), float(k)), torch.full((5,), 2.0 * k)]).double()
+        tel.conv_cache[key] = entry
+        del entry
+        zen, az = rime_model.RIME._zenaz(fake, key, 2459861.0, ra, dec, dev)
+        assert float(zen[0]) == float(k) and float(az[0]) == 2.0 * k, k
+        zen2, _ = rime_model.RIME._zenaz(fake, key, 2459861.0, ra, dec, dev)      # second call: the cached pair
+        assert zen2 is zen
