@@ -24,7 +24,8 @@ int main()
         acc += rime_alm2pix_fwd_workspace(dt, R, Nc, Npix);
         acc += rime_alm2pix_bwd_workspace(dt, R, Nc, Npix);
         acc += rime_chisq_workspace();
-        calls += 7;
+        acc += rime_alm2pix_packed_bytes(Nc, Npix, 0) + rime_alm2pix_packed_bytes(Nc, Npix, 1);
+        calls += 9;
     }
     // argument validation: null pointers, bad shapes, bad flags must come back as error codes, never touch memory
     std::vector<double> d(64, 0.0);
@@ -45,6 +46,13 @@ int main()
     bad += rime_eq2top(d.data(), d.data(), 0, d.data(), d.data(), 0.0, d.data(), d.data(), nullptr) != RIME_OK;
     bad += rime_interp_gather_fwd(0, 0, nullptr, nullptr, nullptr, 1, 1, 1, 1, nullptr, 1, nullptr) == RIME_OK;
     bad += rime_alm2pix_fwd(0, nullptr, nullptr, 1.0, 1, 1, 1, nullptr, nullptr, 0, nullptr) != RIME_EINVAL;
+    bad += rime_alm2pix_pack(f.data(), 0.0, 8, 8, 0, f.data(), nullptr) != RIME_EINVAL;                  // y_scale must be > 0
+    bad += rime_alm2pix_pack(f.data(), 1.0, 8, 8, 2, f.data(), nullptr) != RIME_EINVAL;                  // direction 0 | 1
+    bad += rime_alm2pix_fwd_packed(f.data(), f.data(), 1.0, 4, 8, 8, f.data(), nullptr, 0, nullptr) != RIME_EWORKSPACE;
+    bad += rime_alm2pix_bwd_packed(f.data(), f.data(), 1.0, 4, 8, 8, f.data(), nullptr, 0, nullptr) != RIME_EWORKSPACE;
+    bad += rime_jones_apply_fwd(0, 0, f.data(), f.data(), f.data(), 10, 3, f.data(), nullptr) != RIME_EINVAL;        // Ns must divide N
+    bad += rime_jones_apply_bwd(0, 0, f.data(), f.data(), f.data(), f.data(), 8, 4, nullptr, f.data(), f.data(), nullptr) != RIME_EINVAL;
+    bad += rime_fringe_row_scale(f.data(), 1, 1, 1, 0, 0, 0, 0, 0, 8, f.data(), nullptr, nullptr) != RIME_EINVAL;
     bad += rime_comm_init(nullptr, 1, 0, nullptr) != RIME_EINVAL;
     bad += rime_comm_allgather_vis(nullptr, 0, nullptr, nullptr, 1, nullptr) != RIME_EINVAL;
     std::printf("host sanitizer sweep: %ld planning calls (checksum %zu), %d unexpected return codes, version %s\n",
