@@ -299,6 +299,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     const uint32_t lo_s = 16u * pp, lo_a0 = 8u * pp * (uint32_t)st_p, lo_a1 = lo_a0 + 4u * (uint32_t)st_p;
     const double* sdy = sd + A.Pstride;
     const double* sdz = sd + 2 * (size_t)A.Pstride;
+#if defined(RIME_FWD_GLOBAL_LOADS)     /* lab: the flat-load form (6 v_lshl_add_u64 per half panel for the addresses) */
     auto fetch = [&](int panel, int hf) {
         const int p0 = panel * MF_KP + 16 * hf;      // uniform
         sx[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sd + p0) + lo_s);
@@ -309,6 +310,29 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
         if constexpr (CPLX)
             aw[hf] = make_float2(*reinterpret_cast<const float*>(ab + lo_a0 + 4), *reinterpret_cast<const float*>(ab + lo_a1 + 4));
     };
+#else
+    // buffer loads: descriptor (SGPRs, wave-uniform: built from kernel arguments and the block index) + constant per-lane
+    // offset + scalar panel offset -- no vector address arithmetic in the generation phase, whose cost is its
+    // instruction count (profiles/r03/lab_forward_experiments.txt); out-of-range reads return 0 instead of faulting
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(sd), 0, (int)min((long long)3 * A.Pstride * 8, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(arow), 0, (int)min((long long)A.Pstride * st_p * 4, 0x7fffffffLL), 0x00020000);
+    (void)sdy; (void)sdz;
+    auto fetch = [&](int panel, int hf) {
+        const int p0 = panel * MF_KP + 16 * hf;      // uniform
+        sx[hf] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, p0 * 8, 0));
+        sy[hf] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (A.Pstride + p0) * 8, 0));
+        sz[hf] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (2 * A.Pstride + p0) * 8, 0));
+        const int so = p0 * st_p * 4;
+        av[hf] = make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a0, so, 0)),
+                             __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a1, so, 0)));
+        if constexpr (CPLX)
+            aw[hf] = make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a0 + 4, so, 0)),
+                                 __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a1 + 4, so, 0)));
+    };
+#endif
     auto generate = [&](unsigned char* buf, int next_panel) {
         if constexpr (OCT) {
             constexpr int hf = W & 1;
