@@ -1087,6 +1087,119 @@ alm2pix_bwd_packed_kernel(const uint4* __restrict__ g_hi, const uint4* __restric
     }
 }
 
+// Backward on the packed copy, 8-wave form (MT = 4): one block = 256 coefficients (two packed coefficient tiles) x 128 rows.
+// The gout granules a chunk needs are the same for every coefficient tile, so doubling the coefficients per block halves
+// their share of the LDS-DMA intake (16 px: Ylm 32 KB + gout 8 KB instead of 16 + 8) -- and that intake, ~21-23 GB/s per
+// CU whatever it carries, is what bounds the ring kernels.  Chunks of ONE K step in a ring of four 40-KB
+// slots (exactly the 160 KB of a CU: 40 wave instructions per chunk = 5 per wave, no padding loads, no scratch).
+struct BwdDma8 {
+    static constexpr int ROWS = 128, NW = 8, NSLOT = 4;
+    static constexpr int YB = NW * 4 * 1024;           // 8 waves x (re_hi, re_lo, im_hi, im_lo) x 1 KB
+    static constexpr int GB = 2 * ROWS * 16;           // one gout image (hi or lo) of the K step: 4 KB
+    static constexpr int SLOT = YB + 2 * GB;           // 40 KB
+    static constexpr int NGW = GB / 1024;              // 4
+    static constexpr int TI = 4 * NW + 2 * NGW;        // 40
+    static constexpr int NPW = TI / NW;                // 5
+    static constexpr int LDS = NSLOT * SLOT;
+    static_assert(TI % NW == 0 && LDS <= 160 * 1024 && NPW * (NSLOT - 2) < 64, "ring shape");
+};
+
+__global__ void __launch_bounds__(512, 1)
+alm2pix_bwd_packed8_kernel(const uint4* __restrict__ g_hi, const uint4* __restrict__ g_lo,
+                           const float* __restrict__ inv_scale, const uint4* __restrict__ Yb,
+                           const float* __restrict__ zero16, float y_scale,
+                           int R, int Rpad, int Ncoeff, int Npix, int nsteps, int S, int CT2, int RT, float* __restrict__ part)
+{
+    using C = BwdDma8;
+    constexpr int MT = 4, ROWS = C::ROWS, AHEAD = C::NSLOT - 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int NB = S * CT2 * RT, per_xcd = (NB + 7) / 8;
+    const int q = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    if ((int)(blockIdx.x / 8) >= per_xcd || q >= NB) return;
+    const int split = q / (CT2 * RT);
+    const int r0 = (q % RT) * ROWS;
+    const int ct0 = 2 * ((q / RT) % CT2);              // first of this block's two packed coefficient tiles
+    const int c = ct0 * 128 + wave * 32 + (lane & 31);
+    const int h = lane >> 5;
+    const int send = (Npix + 15) / 16;
+    const int nchunk = nsteps;                         // one K step per chunk
+    const int niter = split < nchunk ? (nchunk - split + S - 1) / S : 0;
+    f32x16 accr[MT], acci[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { accr[m][e] = 0.f; acci[m][e] = 0.f; }
+
+    const uint4* ytile = Yb + (size_t)ct0 * nsteps * 16 * 64 + lane;
+    const size_t ct_stride = (size_t)nsteps * 16 * 64;                 // uint4 elements between packed coefficient tiles
+    auto issue = [&](int it, int slot) {
+        const int s0 = split + it * S;
+        const unsigned base = smem_addr + (unsigned)(slot * C::SLOT);
+#pragma unroll
+        for (int u = 0; u < C::NPW; ++u) {
+            const int t = wave + C::NW * u;            // wave-uniform, 0 .. 39
+            if (t < 4 * C::NW) {                       // KB number t of the chunk's Ylm: (tile half, wave, plane)
+                glds16(ytile + (size_t)(t >> 4) * ct_stride + ((size_t)s0 * 16 + (t & 15)) * 64, base + t * 1024);
+            } else {
+                const int tg = t - 4 * C::NW;
+                const int img = tg / C::NGW, k = tg % C::NGW;
+                const int i = k * 64 + lane;
+                const int row = i % ROWS, hh = i / ROWS;
+                const int qq = s0 * 2 + hh;
+                const uint4* g = img ? g_lo : g_hi;
+                const void* src = s0 < send ? (const void*)&g[(size_t)qq * Rpad + r0 + row] : (const void*)zero16;
+                glds16(src, base + C::YB + img * C::GB + k * 1024);
+            }
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        if (a < niter) issue(a, a);
+    int slot = 0, nslot = AHEAD;
+    for (int it = 0; it < niter; ++it) {
+        wait_chunks<C::NPW, AHEAD - 1>(niter - 1 - it);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + AHEAD < niter) issue(it + AHEAD, nslot);
+        const unsigned char* sl = smem + slot * C::SLOT;
+        const uint4* lds_hi = reinterpret_cast<const uint4*>(sl + C::YB);
+        const uint4* lds_lo = reinterpret_cast<const uint4*>(sl + C::YB + C::GB);
+        const uint4* yf = reinterpret_cast<const uint4*>(sl + (wave * 4) * 1024) + lane;
+        const uint4 rh = yf[0], rl = yf[64], ih = yf[128], il = yf[192];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int gi = h * ROWS + m * 32 + (lane & 31);
+            const uint4 ah = lds_hi[gi], al = lds_lo[gi];
+            accr[m] = ALM_MFMA(ah, rh, accr[m]);
+            acci[m] = ALM_MFMA(ah, ih, acci[m]);
+            accr[m] = ALM_MFMA(ah, rl, accr[m]);
+            acci[m] = ALM_MFMA(ah, il, acci[m]);
+            accr[m] = ALM_MFMA(al, rh, accr[m]);
+            acci[m] = ALM_MFMA(al, ih, acci[m]);
+        }
+        slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
+        nslot = nslot + 1 == C::NSLOT ? 0 : nslot + 1;
+    }
+    RIME_MFMA_SETTLE();
+    if (c < Ncoeff) {
+        float* dst = part + (size_t)split * R * Ncoeff * 2;
+        const float iy = 1.0f / y_scale;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = r0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < R) {
+                    const float sc = inv_scale[row] * iy;
+                    *reinterpret_cast<float2*>(dst + ((size_t)row * Ncoeff + c) * 2) =
+                        make_float2(accr[m][e] * sc, -acci[m][e] * sc);
+                }
+            }
+    }
+}
+
 __global__ void alm_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t len, int S)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
@@ -1161,6 +1274,7 @@ static long bwd_dma_resident_blocks()
 static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward, int dma = -1)      // dma: -1 auto, 1 the ring kernels
 {
     const bool use_dma = dma < 0 ? bwd_use_dma(K) : dma != 0;
+    const bool wide = dma == 2 && R > 64;                          // 8-wave blocks of 256 coefficients, one K step per chunk
     SplitPlan p{};
     p.MT = R > 64 ? 4 : (R > 32 ? 2 : 1);
     p.Rpad = ((R + p.MT * 32 - 1) / (p.MT * 32)) * p.MT * 32;
@@ -1171,7 +1285,7 @@ static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward, int dma = -
         // ~2048 blocks of 128 coefficients x MT row tiles, as WHOLE rounds of the resident grid: every block
         // streams the same number of chunks, so 4.1 rounds cost 5 (C3: 66 tiles x 32 splits = 2112 blocks over
         // 512 resident ones; 31 splits = 2046 blocks = 4.0 rounds)
-        const long blocks = (long)((Ncoeff + 127) / 128) * (p.Rpad / (p.MT * 32));
+        const long blocks = (long)(wide ? (Ncoeff + 255) / 256 : (Ncoeff + 127) / 128) * (p.Rpad / (p.MT * 32));
         const long resident = use_dma ? bwd_dma_resident_blocks() : bwd_resident_blocks(p.MT);
         long S = (2048 + blocks - 1) / blocks;                   // measured flat between 1024 and 4096 blocks
         const long maxS = std::max(1, p.nsteps / 32);          // >= 16 chunks of 2 K steps per block
@@ -1182,7 +1296,7 @@ static SplitPlan split_plan(int R, int K, int Ncoeff, bool backward, int dma = -
             // each split writes and the reduce kernel reads back (R Ncoeff 16 B at ~4 TB/s against ~2.2 us per
             // chunk).  Measured (C3 shape, 66 tiles): S 11 / 15 / 19 / 23 / 31 -> 1.09 / 1.08 / 1.10 / 1.17 / 1.21 ms,
             // S 8 (2.06 rounds) 1.31 ms; 17 tiles x 196608 px: S 15 / 30 / 45 / 60 -> 1.12 / 1.16 / 1.17 / 1.25 ms.
-            const long nchunk = (p.nsteps + 1) / 2;
+            const long nchunk = wide ? p.nsteps : (p.nsteps + 1) / 2;
             const double c1 = (double)R * Ncoeff * 1.8e-6;
             double best = 1e300;
             const long top = std::min<long>(maxS, 8 * resident / blocks + 1);
@@ -1327,8 +1441,9 @@ extern "C" size_t rime_alm2pix_bwd_workspace(int dtype, int R, int Ncoeff, int N
     const size_t exact = S0 <= 1 ? 0 : (size_t)S0 * R * Ncoeff * 2 * sizeof(float);
     const SplitPlan p = split_plan(R, Npix, Ncoeff, true);
     const size_t fast = split_ws_bytes(p) + (size_t)p.S * R * Ncoeff * 2 * sizeof(float);
-    const SplitPlan pp = split_plan(R, Npix, Ncoeff, true, 1);                 // rime_alm2pix_bwd_packed: always the ring
-    const size_t packed = split_ws_bytes(pp) + (size_t)pp.S * R * Ncoeff * 2 * sizeof(float);
+    const SplitPlan pp = split_plan(R, Npix, Ncoeff, true, 1);                 // rime_alm2pix_bwd_packed: always a ring
+    const SplitPlan pw = split_plan(R, Npix, Ncoeff, true, 2);
+    const size_t packed = split_ws_bytes(pp) + (size_t)std::max(pp.S, pw.S) * R * Ncoeff * 2 * sizeof(float);
     return std::max(exact, std::max(fast, packed));
 }
 
@@ -1400,7 +1515,7 @@ extern "C" size_t rime_alm2pix_packed_bytes(int Ncoeff, int Npix, int direction)
 {
     if (Ncoeff <= 0 || Npix <= 0 || (direction != 0 && direction != 1)) return 0;
     if (direction == 0) return (size_t)((Npix + 127) / 128 * 4) * pk_fwd_steps(Ncoeff) * 2048;     // whole 4-wave blocks of pixel tiles
-    return (size_t)((Ncoeff + 127) / 128) * pk_bwd_steps(Npix) * 16384;
+    return (size_t)((Ncoeff + 255) / 256 * 2) * pk_bwd_steps(Npix) * 16384;      // whole 256-coefficient (8-wave) blocks
 }
 
 extern "C" int rime_alm2pix_pack(const void* Ylm, double y_scale, int Ncoeff, int Npix, int direction, void* packed,
@@ -1417,7 +1532,7 @@ extern "C" int rime_alm2pix_pack(const void* Ylm, double y_scale, int Ncoeff, in
                            Ncoeff, Npix, nsteps, ntile, (uint4*)packed);
     } else {
         const int nsteps = pk_bwd_steps(Npix);
-        const size_t nblk = (size_t)((Ncoeff + 127) / 128) * nsteps;
+        const size_t nblk = (size_t)((Ncoeff + 255) / 256 * 2) * nsteps;
         if (nblk > 0x7fffffffull) return RIME_EUNSUPPORTED;
         hipLaunchKernelGGL(alm_pack_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)Ylm, (float)y_scale,
                            Ncoeff, Npix, nsteps, (uint4*)packed);
@@ -1458,7 +1573,10 @@ extern "C" int rime_alm2pix_bwd_packed(const void* gout, const void* packed, dou
 {
     if (!gout || !packed || !galm || R <= 0 || Ncoeff <= 0 || Npix <= 0 || !(y_scale > 0)) return RIME_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const SplitPlan p = split_plan(R, Npix, Ncoeff, true, 1);
+    static int wide_env = -1;
+    if (wide_env < 0) { const char* ev = getenv("RIME_ALM_BWD_WIDE"); wide_env = (ev && ev[0] == '0') ? 0 : 1; }
+    const bool wide = wide_env == 1 && R > 64;
+    const SplitPlan p = split_plan(R, Npix, Ncoeff, true, wide ? 2 : 1);
     const size_t len = (size_t)R * Ncoeff * 2;
     const size_t need = split_ws_bytes(p) + (size_t)p.S * len * sizeof(float);
     if (!workspace || workspace_bytes < need) return RIME_EWORKSPACE;
@@ -1470,7 +1588,23 @@ extern "C" int rime_alm2pix_bwd_packed(const void* gout, const void* packed, dou
     const uint4* Y = (const uint4*)packed;
     const int nsteps = pk_bwd_steps(Npix);
     hipError_t e;
-    if (p.MT == 4) e = launch_bwd_packed<4, 3>(grid, st, hi, lo, inv, Y, zero16, (float)y_scale, R, p.Rpad, Ncoeff, Npix, nsteps, p.S, part);
+    if (wide) {
+        const int CT2 = (Ncoeff + 255) / 256, RT = p.Rpad / 128, NB = p.S * CT2 * RT;
+        static unsigned long long configured = 0ull;
+        int devid = 0;
+        if (hipGetDevice(&devid) != hipSuccess) devid = 0;
+        const unsigned long long bit = 1ull << (devid & 63);
+        e = hipSuccess;
+        if (!(configured & bit)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&alm2pix_bwd_packed8_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, BwdDma8::LDS);
+            if (e == hipSuccess) configured |= bit;
+        }
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(alm2pix_bwd_packed8_kernel, dim3(8 * ((NB + 7) / 8)), dim3(512), BwdDma8::LDS, st, hi, lo, inv, Y,
+                               zero16, (float)y_scale, R, p.Rpad, Ncoeff, Npix, nsteps, p.S, CT2, RT, part);
+    }
+    else if (p.MT == 4) e = launch_bwd_packed<4, 3>(grid, st, hi, lo, inv, Y, zero16, (float)y_scale, R, p.Rpad, Ncoeff, Npix, nsteps, p.S, part);
     else if (p.MT == 2) e = launch_bwd_packed<2, 3>(grid, st, hi, lo, inv, Y, zero16, (float)y_scale, R, p.Rpad, Ncoeff, Npix, nsteps, p.S, part);
     else e = launch_bwd_packed<1, 3>(grid, st, hi, lo, inv, Y, zero16, (float)y_scale, R, p.Rpad, Ncoeff, Npix, nsteps, p.S, part);
     if (e != hipSuccess) return RIME_ELAUNCH;

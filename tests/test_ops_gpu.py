@@ -972,9 +972,8 @@ def test_alm2pix_mfma_shapes(ops, R, lmax, Npix):
 @pytest.mark.parametrize('R,lmax,Npix', [(128, 24, 3000), (40, 12, 1111), (3, 40, 5000), (70, 31, 2048), (128, 15, 12289)])
 def test_alm2pix_packed_ylm_equals_unpacked(ops, R, lmax, Npix, monkeypatch):
     """the cached pre-split copies of Ylm in fragment order (rime_alm2pix_pack / _fwd_packed / _bwd_packed): same
-    split, same products, same summation order as the kernels that split Ylm on the fly -- bitwise equal results for
-    even pixel counts (odd ones: the unpacked backward is another kernel with another pixel split: 2e-6) -- and both
-    against the float64 oracle; row tiles 4 / 2 / 1, ragged coefficient and pixel tails, one-block and many-block grids"""
+    split and the same products as the kernels that split Ylm on the fly -- forward bitwise equal (same summation order),
+    backward to 2e-6 (another deal of the pixel chunks) -- and both against the float64 oracle; row tiles 4 / 2 / 1, ragged coefficient and pixel tails, one-block and many-block grids"""
     rng = np.random.default_rng(R + Npix)
     l, m = orc.gen_lm(lmax)
     th, ph = np.arccos(rng.uniform(-1, 1, Npix)), rng.uniform(0, 2 * np.pi, Npix)
@@ -998,10 +997,10 @@ def test_alm2pix_packed_ylm_equals_unpacked(ops, R, lmax, Npix, monkeypatch):
         res[packed] = (y.detach(), x.grad.detach())
         assert relmax(y, ref) < 1e-5 and relmax(x.grad, ar.grad) < 1e-5
     assert torch.equal(res[False][0], res[True][0])
-    if Npix % 2 == 0:
-        assert torch.equal(res[False][1], res[True][1])
-    else:
-        assert relmax(res[True][1], res[False][1]) < 2e-6
+    # backward: the packed kernels deal the pixel chunks to their blocks differently (256-coefficient blocks, one K step
+    # per chunk; odd pixel counts: the unpacked path is another kernel altogether): same products, another order of the
+    # float32 partial sums
+    assert relmax(res[True][1], res[False][1]) < 2e-6
 
 
 def test_alm2pix_packed_ylm_is_repacked_when_ylm_changes(ops, monkeypatch):
