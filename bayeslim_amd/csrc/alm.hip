@@ -342,20 +342,20 @@ split_rows_kernel(const float* __restrict__ X, int R, int L, int Rpad, int neg_o
     }
 }
 
-// The same two steps in ONE launch when there are enough rows to fill the chip with one block per row (R >= 64): the
-// block scans its row for the maximum, then reads it again (L2) and splits -- no atomics, no memset, one launch instead
-// of three (round 3: 44 -> ~12 us in front of the C3-shape backward).
+// Long rows (round 3; gout: 128 rows of 49 152 values in front of every C3-shape backward): the two kernels above cost 64 us
+// there, mostly because every 16-byte granule store of split_rows_kernel lands 2 KB from the next (granule-major images,
+// one block per row).  Two launches without atomics or memset instead: the scale of every row by one block per row
+// (coalesced float4 reads), then a TILED split -- a block reads 64 rows x 32 granules along the rows (a wave reads 2 KB
+// contiguous pieces), turns the tile through LDS and writes it granule-major, 64 rows x 16 B = 1 KB contiguous per store.
 __global__ void __launch_bounds__(256)
-split_rows_fused_kernel(const float* __restrict__ X, int R, int L, int Rpad, int neg_odd, uint4* __restrict__ img_hi,
-                        uint4* __restrict__ img_lo, float* __restrict__ inv_scale)
+row_scale_alm_kernel(const float* __restrict__ X, int R, int L, float* __restrict__ scale, float* __restrict__ inv_scale)
 {
     __shared__ float wmax[4];
     const int r = blockIdx.x, tid = threadIdx.x;
-    const int nsteps = (L + 15) / 16;
     float m = 0.f;
     if (r < R) {
         const float* row = X + (size_t)r * L;
-        if ((L & 3) == 0) {
+        if ((L & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
             for (int i = tid; i < L / 4; i += 256) {
                 const float4 v = reinterpret_cast<const float4*>(row)[i];
                 m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -367,23 +367,54 @@ split_rows_fused_kernel(const float* __restrict__ X, int R, int L, int Rpad, int
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((tid & 63) == 0) wmax[tid >> 6] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-    float scale = 1.0f;
-    if (r < R && m > 0.f) scale = exp2f(fminf(fmaxf(floorf(log2f(8192.0f / m)), -100.f), 100.f));
-    if (tid == 0) inv_scale[r] = (r < R) ? 1.0f / scale : 0.f;
-    for (int g = tid; g < nsteps * 2; g += 256) {
-        float v[8];
+    if (tid == 0) {
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        float sc = 1.0f;
+        if (r < R && m > 0.f) sc = exp2f(fminf(fmaxf(floorf(log2f(8192.0f / m)), -100.f), 100.f));   // max|x| * scale in [2^12, 2^13]
+        scale[r] = sc;
+        inv_scale[r] = (r < R) ? 1.0f / sc : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+split_rows_tiled_kernel(const float* __restrict__ X, int R, int L, int Rpad, int neg_odd, const float* __restrict__ scale,
+                        uint4* __restrict__ img_hi, uint4* __restrict__ img_lo)
+{
+    __shared__ uint4 t_hi[32 * 65], t_lo[32 * 65];     // [granule][row], rows padded to 65: the turn is (nearly) conflict-free
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * 32, r0 = blockIdx.y * 64;
+    const int ngran = ((L + 15) / 16) * 2;
+    const int gl = tid & 31;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int k = g * 8 + jj;
-            float x = (r < R && k < L) ? X[(size_t)r * L + k] * scale : 0.f;
-            v[jj] = (neg_odd && (jj & 1)) ? -x : x;
+    for (int it = 0; it < 8; ++it) {
+        const int rr = (tid >> 5) + 8 * it, r = r0 + rr, g = g0 + gl;
+        float v[8];
+        const float sc = r < R ? scale[r] : 0.f;
+        const size_t base = (size_t)r * L + (size_t)g * 8;
+        if (r < R && g * 8 + 7 < L && ((base & 3) == 0)) {
+            const float4 a = *reinterpret_cast<const float4*>(X + base), b = *reinterpret_cast<const float4*>(X + base + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) v[jj] = (r < R && g * 8 + jj < L) ? X[base + jj] : 0.f;
         }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) { v[jj] *= sc; if (neg_odd && (jj & 1)) v[jj] = -v[jj]; }
         uint4 hi, lo;
         split2h(v[0], v[1], hi.x, lo.x); split2h(v[2], v[3], hi.y, lo.y);
         split2h(v[4], v[5], hi.z, lo.z); split2h(v[6], v[7], hi.w, lo.w);
-        img_hi[(size_t)g * Rpad + r] = hi;
-        img_lo[(size_t)g * Rpad + r] = lo;
+        t_hi[gl * 65 + rr] = hi;
+        t_lo[gl * 65 + rr] = lo;
+    }
+    __syncthreads();
+    const int rr = tid & 63;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int gq = (tid >> 6) + 4 * it, g = g0 + gq;
+        if (g < ngran) {
+            img_hi[(size_t)g * Rpad + r0 + rr] = t_hi[gq * 65 + rr];
+            img_lo[(size_t)g * Rpad + r0 + rr] = t_lo[gq * 65 + rr];
+        }
     }
 }
 
@@ -1325,9 +1356,13 @@ static void launch_split_rows(const float* X, int R, int L, const SplitPlan& p, 
     inv = (float*)((char*)workspace + 2 * p.img_bytes);
     unsigned int* rowmax = (unsigned int*)(inv + p.Rpad);
     const int nseg = (2 * p.nsteps * 8 + SPLIT_SEG - 1) / SPLIT_SEG;
-    if (R >= 64) {
+    if (p.Rpad % 64 == 0 && (long)R * L >= (1L << 20)) {
+        // long rows: scale per row (one block each), then the tiled transposing split; `rowmax` doubles as the scale array
+        float* scale = reinterpret_cast<float*>(rowmax);
         (void)hipMemsetAsync((char*)rowmax + (size_t)p.Rpad * sizeof(unsigned int), 0, 64, st);     // the zero granule
-        hipLaunchKernelGGL(split_rows_fused_kernel, dim3(p.Rpad), dim3(256), 0, st, X, R, L, p.Rpad, neg_odd, hi, lo, inv);
+        hipLaunchKernelGGL(row_scale_alm_kernel, dim3(p.Rpad), dim3(256), 0, st, X, R, L, scale, inv);
+        hipLaunchKernelGGL(split_rows_tiled_kernel, dim3((2 * p.nsteps + 31) / 32, p.Rpad / 64), dim3(256), 0, st, X, R, L,
+                           p.Rpad, neg_odd, scale, hi, lo);
         return;
     }
     (void)hipMemsetAsync(rowmax, 0, (size_t)p.Rpad * sizeof(unsigned int) + 64, st);     // + the zero granule behind it
