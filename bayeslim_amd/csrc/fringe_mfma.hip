@@ -314,11 +314,17 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // buffer loads: descriptor (SGPRs, wave-uniform: built from kernel arguments and the block index) + constant per-lane
     // offset + scalar panel offset -- no vector address arithmetic in the generation phase, whose cost is its
     // instruction count (profiles/r03/lab_forward_experiments.txt); out-of-range reads return 0 instead of faulting
-    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    // (the descriptor inputs go through readfirstlane: a base pointer the compiler cannot PROVE wave-uniform makes it wrap
+    // every buffer load in a waterfall loop of ~14 instructions -- seen here on the psky descriptor, guide T20)
+    auto uniform_ptr = [](const void* q) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    };
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double*>(sd), 0, (int)min((long long)3 * A.Pstride * 8, 0x7fffffffLL), 0x00020000);
+        uniform_ptr(sd), 0, __builtin_amdgcn_readfirstlane((int)min((long long)3 * A.Pstride * 8, 0x7fffffffLL)), 0x00020000);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(arow), 0, (int)min((long long)A.Pstride * st_p * 4, 0x7fffffffLL), 0x00020000);
+        uniform_ptr(arow), 0, __builtin_amdgcn_readfirstlane((int)min((long long)A.Pstride * st_p * 4, 0x7fffffffLL)), 0x00020000);
     (void)sdy; (void)sdz;
     auto fetch = [&](int panel, int hf) {
         const int p0 = panel * MF_KP + 16 * hf;      // uniform
