@@ -15,6 +15,29 @@ namespace rime {
 
 constexpr int RT = 8;     // map rows per block
 
+// Workgroups go to the 8 XCDs round-robin in launch order (x fastest), and every XCD has its own L2.  The kernels below
+// gather from a beam map (or from the rows of the points around a beam node) that neighbouring tiles share: dealt
+// round-robin, every L2 ends up fetching the whole map (measured at C4: 3.4 GB fetched by the fused psky builder for 1.1 GB of
+// algorithmic traffic).  xcd_tile() hands XCD k a CONTIGUOUS range of the launch-order tile numbers instead, so tiles that share
+// map lines meet in one L2.  Bijective for any grid size; a no-op on a single-XCD partition only in effect, not in result.
+__device__ __forceinline__ void xcd_tile(int remap, int& bx, int& by)
+{
+    bx = blockIdx.x; by = blockIdx.y;
+    if (!remap) return;
+    const unsigned gx = gridDim.x, N = gx * gridDim.y;
+    const unsigned L = blockIdx.x + blockIdx.y * gx;
+    const unsigned k = L & 7u, chunk = N >> 3, rem = N & 7u;
+    const unsigned Lp = k * chunk + (k < rem ? k : rem) + (L >> 3);
+    bx = (int)(Lp % gx); by = (int)(Lp / gx);
+}
+
+static int xcd_remap_enabled()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("RIME_XCD_REMAP"); v = (e && e[0] == '0') ? 0 : 1; }     // lab switch
+    return v;
+}
+
 template <typename T, int NC, int NNN>
 __global__ void __launch_bounds__(256)
 interp_gather_kernel(const T* __restrict__ m, const int* __restrict__ inds,
@@ -72,17 +95,19 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 interp_scatter_kernel(const T* __restrict__ goutT, const int* __restrict__ csr_ptr,
                       const int* __restrict__ csr_src, const T* __restrict__ wgts,
-                      int RN, int Npb, int Nnn, T* __restrict__ gmT)
+                      int RN, int Npb, int Nnn, T* __restrict__ gmT, int remap)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int es = lane >> 4, rq = lane & 15;
-    const int j = blockIdx.x * 4 + wave;
+    int bx, by;
+    xcd_tile(remap, bx, by);
+    const int j = bx * 4 + wave;
     if (j >= Npb) return;
     const int e0 = csr_ptr[j], e1 = csr_ptr[j + 1];
     const bool pow2 = (Nnn & (Nnn - 1)) == 0;
     const int sh = __ffs(Nnn) - 1;
     const bool vec_rows = (RN & 3) == 0;
-    for (int rb = blockIdx.y * 64; rb < RN; rb += gridDim.y * 64) {
+    for (int rb = by * 64; rb < RN; rb += gridDim.y * 64) {
         const int r = rb + 4 * rq;
         T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
 #pragma unroll 2
@@ -161,7 +186,7 @@ static int scatter_launch(const void* goutT, const int* csr_ptr, const int* csr_
     dim3 grid((Npb + 3) / 4, ny), block(256);
     hipLaunchKernelGGL((interp_scatter_kernel<T>), grid, block, 0, st, reinterpret_cast<const T*>(goutT),
                        csr_ptr, csr_src, reinterpret_cast<const T*>(wgts), RN, Npb, Nnn,
-                       reinterpret_cast<T*>(gmT));
+                       reinterpret_cast<T*>(gmT), xcd_remap_enabled());
     return check_launch();
 }
 
@@ -199,7 +224,31 @@ namespace rime {
 // to the product phase, whose lanes run along the points: psky / gpsky / gs rows are contiguous there.
 template <typename T> struct vec4 { T x, y, z, w; };
 
-// points of the tile: q0 + ql (valid when inside Q and not a padding slot of the cut), or qlist[ql] (< 0: none)
+// the NNN node indices and weights of point q; four-node stencils are two 16-byte loads
+template <typename T, int NNN>
+__device__ __forceinline__ void load_stencil(const int* __restrict__ inds, const T* __restrict__ wgts, size_t q,
+                                             int (&id)[NNN], T (&wk)[NNN])
+{
+    if constexpr (NNN == 4) {
+        const int4 i4 = *reinterpret_cast<const int4*>(inds + q * 4);
+        id[0] = i4.x; id[1] = i4.y; id[2] = i4.z; id[3] = i4.w;
+        if constexpr (sizeof(T) == 4) {
+            const vec4<T> w4 = *reinterpret_cast<const vec4<T>*>(wgts + q * 4);
+            wk[0] = w4.x; wk[1] = w4.y; wk[2] = w4.z; wk[3] = w4.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wk[k] = wgts[q * 4 + k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NNN; ++k) { id[k] = inds[q * NNN + k]; wk[k] = wgts[q * NNN + k]; }
+    }
+}
+
+// points of the tile: q0 + ql (valid when inside Q and not a padding slot of the cut), or qlist[ql] (< 0: none).
+// The block's time goes into a chain of dependent memory phases (cut -> stencil -> beam nodes), so everything is loaded
+// UNCONDITIONALLY (points without a value read the stencil of point 0 and are zeroed afterwards): no branch stands between the
+// loads and the compiler issues the four points' stencils together and then all their node gathers.
 template <typename T, int NNN>
 __device__ __forceinline__ void interp_tile(const T* __restrict__ bmapT, const int* __restrict__ inds,
                                             const T* __restrict__ wgts, const int* __restrict__ cut, int R, int Npix,
@@ -209,13 +258,40 @@ __device__ __forceinline__ void interp_tile(const T* __restrict__ bmapT, const i
     const int qs = lane >> 4, rq = lane & 15;
     const int r = r0 + 4 * rq;
     const bool vec_ok = (R & 3) == 0 && r + 3 < R;
+    if constexpr (NNN > 0) {
+        if (vec_ok) {
+            int qc[4]; bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ql = 16 * w + 4 * j + qs, q = qlist ? qlist[ql] : q0 + ql;
+                ok[j] = qlist ? q >= 0 : (q < Q && cut[min(q, Q - 1)] < Npix);
+                qc[j] = ok[j] ? q : 0;
+            }
+            int id[4][NNN]; T wk[4][NNN];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_stencil<T, NNN>(inds, wgts, (size_t)qc[j], id[j], wk[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                T b0 = T(0), b1 = T(0), b2 = T(0), b3 = T(0);
+#pragma unroll
+                for (int k = 0; k < NNN; ++k) {
+                    const vec4<T> v = *reinterpret_cast<const vec4<T>*>(bmapT + (size_t)id[j][k] * R + r);
+                    b0 = tfma<T>(wk[j][k], v.x, b0); b1 = tfma<T>(wk[j][k], v.y, b1);
+                    b2 = tfma<T>(wk[j][k], v.z, b2); b3 = tfma<T>(wk[j][k], v.w, b3);
+                }
+                const int ql = 16 * w + 4 * j + qs;
+                tile[ql][4 * rq] = ok[j] ? b0 : T(0); tile[ql][4 * rq + 1] = ok[j] ? b1 : T(0);
+                tile[ql][4 * rq + 2] = ok[j] ? b2 : T(0); tile[ql][4 * rq + 3] = ok[j] ? b3 : T(0);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ql = 16 * w + 4 * j + qs, q = qlist ? qlist[ql] : q0 + ql;
         T b0 = T(0), b1 = T(0), b2 = T(0), b3 = T(0);
         if (qlist ? q >= 0 : (q < Q && cut[q] < Npix)) {
             const int nn = NNN > 0 ? NNN : Nnn;
-#pragma unroll
             for (int k = 0; k < nn; ++k) {
                 const T wk = wgts[(size_t)q * nn + k];
                 const T* src = bmapT + (size_t)inds[(size_t)q * nn + k] * R + r;
@@ -234,24 +310,36 @@ __device__ __forceinline__ void interp_tile(const T* __restrict__ bmapT, const i
     }
 }
 
+#ifndef RIME_BSFWD_BLOCKS
+#define RIME_BSFWD_BLOCKS 8
+#endif
 template <typename T, int NNN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (NNN > 0 && NNN <= 4 && sizeof(T) == 4) ? RIME_BSFWD_BLOCKS : 1)
 beam_sky_fwd_kernel(const T* __restrict__ bmapT, const T* __restrict__ sky, const int* __restrict__ inds,
                     const T* __restrict__ wgts, const int* __restrict__ cut, int R, int Npb, int Npix,
-                    int Q, int Nnn, T* __restrict__ out)
+                    int Q, int Nnn, T* __restrict__ out, int remap)
 {
     __shared__ T tile[64][65];
-    const int q0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-    interp_tile<T, NNN>(bmapT, inds, wgts, cut, R, Npix, Q, Nnn, q0, r0, tile);
-    __syncthreads();
+    int bx, by;
+    xcd_tile(remap, bx, by);
+    const int q0 = bx * 64, r0 = by * 64;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int q = q0 + lx;
+    // the sky values of the product phase are fetched first: their latency runs under the interpolation phase's
+    const int c = q < Q ? cut[q] : Npix;
+    T sv[16];
+#pragma unroll
+    for (int k16 = 0; k16 < 16; ++k16) {
+        const int r = r0 + ly + 4 * k16;
+        sv[k16] = (c < Npix && r < R) ? sky[(size_t)r * Npix + c] : T(0);
+    }
+    interp_tile<T, NNN>(bmapT, inds, wgts, cut, R, Npix, Q, Nnn, q0, r0, tile);
+    __syncthreads();
     if (q >= Q) return;
-    const int c = cut[q];
-#pragma unroll 4
+#pragma unroll
     for (int k16 = 0; k16 < 16; ++k16) {
         const int rl = ly + 4 * k16, r = r0 + rl;
-        if (r < R) out[(size_t)r * Q + q] = c < Npix ? tile[lx][rl] * sky[(size_t)r * Npix + c] : T(0);
+        if (r < R) out[(size_t)r * Q + q] = c < Npix ? tile[lx][rl] * sv[k16] : T(0);
     }
 }
 
@@ -283,21 +371,107 @@ beam_sky_bwd_kernel(const T* __restrict__ gps, const T* __restrict__ sky, const 
 // pixels x 64 channels walks the time steps, re-interpolating the beam for the pixels visible at t (the
 // (Nf x Nt P) product gpsky * beam is never written: it would be one more write and one more read of the largest
 // tensor of the step)
+#ifndef RIME_SKYGRAD_BLOCKS
+#define RIME_SKYGRAD_BLOCKS 4
+#endif
 template <typename T, int NNN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (NNN > 0 && NNN <= 4 && sizeof(T) == 4) ? RIME_SKYGRAD_BLOCKS : 1)
 sky_grad_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const int* __restrict__ inds,
                 const T* __restrict__ wgts, const int* __restrict__ pos, int R, int Npix, int Nt, int Ps, int Nnn,
-                T* __restrict__ gsky)
+                T* __restrict__ gsky, int remap)
 {
     __shared__ T tile[64][65];
     __shared__ int qsel[64];
-    const int j0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    int bx, by;
+    xcd_tile(remap, bx, by);
+    const int j0 = bx * 64, r0 = by * 64;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int j = j0 + lx;
     const size_t Q = (size_t)Nt * Ps;
     T acc[16];
 #pragma unroll
     for (int k16 = 0; k16 < 16; ++k16) acc[k16] = T(0);
+    if constexpr (NNN == 4) {
+        if ((R & 3) == 0 && r0 + 64 <= R) {            // uniform: every lane's 4 channels are one vector load
+            // Software pipeline over the time steps: the chain pos -> stencil -> beam nodes of step t+1 is walked while step
+            // t is contracted.  The stencils of the tile's 64 pixels (256 indices + 256 weights: one of each per thread) go
+            // through LDS, double buffered: thread (pixel pl, node k) loads its entry for step t+1 during step t (from the
+            // position it loaded during t-1) and stores it before the step's barrier; the interpolation phase reads
+            // its four pixels' stencils with two ds_read_b128 each.  Only the node gathers + the gpsky column of the step
+            // itself are waited for, and a lane carries 3 registers of pipeline state.  (Two other forms were slower at
+            // C4: the stencils prefetched into registers -- 220 registers, two blocks per CU, 32 scalar stencil loads per
+            // lane and step: 0.56 ms; a wave-autonomous form without LDS and barriers, each lane interpolating exactly the
+            // 4 pixels x 4 channels whose gpsky values it multiplies: 1.17 ms, its gpsky loads touch 16 rows per
+            // instruction instead of one.)
+            __shared__ int sten_i[2][64][4];
+            __shared__ T sten_w[2][64][4];
+            __shared__ int sten_q[2][64];
+            const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+            const int qs = lane >> 4, rq = lane & 15;
+            const int r = r0 + 4 * rq;
+            const int pl = threadIdx.x >> 2, pk = threadIdx.x & 3, jp = j0 + pl;
+            auto q_of = [&](int t) {
+                const int pp = (t < Nt && jp < Npix) ? pos[(size_t)t * Npix + jp] : -1;
+                return pp >= 0 ? t * Ps + pp : -1;
+            };
+            {
+                const int q0 = q_of(0);
+                const size_t qc = q0 >= 0 ? (size_t)q0 : 0;
+                sten_i[0][pl][pk] = inds[qc * 4 + pk];
+                sten_w[0][pl][pk] = wgts[qc * 4 + pk];
+                if (pk == 0) sten_q[0][pl] = q0;
+            }
+            int q1 = q_of(1);
+            int pprod = j < Npix ? pos[j] : -1;
+            for (int t = 0; t < Nt; ++t) {
+                const int q = pprod >= 0 ? t * Ps + pprod : -1;
+                if (t + 1 < Nt) pprod = j < Npix ? pos[(size_t)(t + 1) * Npix + j] : -1;
+                const size_t qc1 = q1 >= 0 ? (size_t)q1 : 0;
+                const int nid = inds[qc1 * 4 + pk];
+                const T nw = wgts[qc1 * 4 + pk];
+                const int q2 = q_of(t + 2);
+                const int cur = t & 1;
+                const bool any = __syncthreads_or(q >= 0);       // some pixel of the tile is above the horizon at t (uniform)
+                T g[16];
+                if (any) {
+#pragma unroll
+                    for (int k16 = 0; k16 < 16; ++k16)
+                        g[k16] = q >= 0 ? gps[(size_t)(r0 + ly + 4 * k16) * Q + q] : T(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ql = 16 * w + 4 * u + qs;
+                        const int4 id = *reinterpret_cast<const int4*>(&sten_i[cur][ql][0]);
+                        const vec4<T> wk = *reinterpret_cast<const vec4<T>*>(&sten_w[cur][ql][0]);
+                        const bool ok = sten_q[cur][ql] >= 0;
+                        const vec4<T> v0 = *reinterpret_cast<const vec4<T>*>(bmapT + (size_t)id.x * R + r);
+                        const vec4<T> v1 = *reinterpret_cast<const vec4<T>*>(bmapT + (size_t)id.y * R + r);
+                        const vec4<T> v2 = *reinterpret_cast<const vec4<T>*>(bmapT + (size_t)id.z * R + r);
+                        const vec4<T> v3 = *reinterpret_cast<const vec4<T>*>(bmapT + (size_t)id.w * R + r);
+                        T b0 = tfma<T>(wk.x, v0.x, T(0)), b1 = tfma<T>(wk.x, v0.y, T(0)), b2 = tfma<T>(wk.x, v0.z, T(0)), b3 = tfma<T>(wk.x, v0.w, T(0));
+                        b0 = tfma<T>(wk.y, v1.x, b0); b1 = tfma<T>(wk.y, v1.y, b1); b2 = tfma<T>(wk.y, v1.z, b2); b3 = tfma<T>(wk.y, v1.w, b3);
+                        b0 = tfma<T>(wk.z, v2.x, b0); b1 = tfma<T>(wk.z, v2.y, b1); b2 = tfma<T>(wk.z, v2.z, b2); b3 = tfma<T>(wk.z, v2.w, b3);
+                        b0 = tfma<T>(wk.w, v3.x, b0); b1 = tfma<T>(wk.w, v3.y, b1); b2 = tfma<T>(wk.w, v3.z, b2); b3 = tfma<T>(wk.w, v3.w, b3);
+                        tile[ql][4 * rq] = ok ? b0 : T(0); tile[ql][4 * rq + 1] = ok ? b1 : T(0);
+                        tile[ql][4 * rq + 2] = ok ? b2 : T(0); tile[ql][4 * rq + 3] = ok ? b3 : T(0);
+                    }
+                }
+                sten_i[cur ^ 1][pl][pk] = nid;
+                sten_w[cur ^ 1][pl][pk] = nw;
+                if (pk == 0) sten_q[cur ^ 1][pl] = q1;
+                q1 = q2;
+                if (any) {
+                    __syncthreads();
+#pragma unroll
+                    for (int k16 = 0; k16 < 16; ++k16) acc[k16] = tfma<T>(g[k16], tile[lx][ly + 4 * k16], acc[k16]);
+                }
+            }
+            if (j < Npix) {
+#pragma unroll
+                for (int k16 = 0; k16 < 16; ++k16) gsky[(size_t)(r0 + ly + 4 * k16) * Npix + j] = acc[k16];
+            }
+            return;
+        }
+    }
     // the block is a chain of dependent memory phases per time step (pos -> stencil -> beam nodes -> gpsky);
     // pos of the next step and the gpsky column of this one are fetched ahead of the interpolation phase
     int pnext = j < Npix ? pos[j] : -1;
@@ -334,7 +508,8 @@ static int beam_sky_fwd_launch(const void* bmap, const void* sky, const int* ind
     dim3 grid((Q + 63) / 64, (R + 63) / 64), block(256);
     const T* b_ = reinterpret_cast<const T*>(bmap); const T* s_ = reinterpret_cast<const T*>(sky);
     const T* w_ = reinterpret_cast<const T*>(wgts); T* o_ = reinterpret_cast<T*>(out);
-#define RIME_BS(N) hipLaunchKernelGGL((beam_sky_fwd_kernel<T, N>), grid, block, 0, st, b_, s_, inds, w_, cut, R, Npb, Npix, Q, Nnn, o_)
+    const int remap = xcd_remap_enabled();
+#define RIME_BS(N) hipLaunchKernelGGL((beam_sky_fwd_kernel<T, N>), grid, block, 0, st, b_, s_, inds, w_, cut, R, Npb, Npix, Q, Nnn, o_, remap)
     switch (Nnn) {
         case 1: RIME_BS(1); break;
         case 4: RIME_BS(4); break;
@@ -367,9 +542,10 @@ extern "C" int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmapT
     if (R <= 0 || Npb <= 0 || Npix <= 0 || Nt <= 0 || Ps <= 0 || Nnn <= 0) return RIME_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int Q = Nt * Ps;
+    const int remap = xcd_remap_enabled();
     dim3 g1((Q + 63) / 64, (R + 63) / 64), g2((Npix + 63) / 64, (R + 63) / 64);
 #define RIME_SG(TT, N) hipLaunchKernelGGL((sky_grad_kernel<TT, N>), g2, dim3(256), 0, st, (const TT*)gpsky, (const TT*)bmapT, \
-        inds, (const TT*)wgts, pos, R, Npix, Nt, Ps, Nnn, (TT*)gsky)
+        inds, (const TT*)wgts, pos, R, Npix, Nt, Ps, Nnn, (TT*)gsky, remap)
 #define RIME_SG_ALL(TT) switch (Nnn) { case 1: RIME_SG(TT, 1); break; case 4: RIME_SG(TT, 4); break; \
         case 9: RIME_SG(TT, 9); break; case 16: RIME_SG(TT, 16); break; default: RIME_SG(TT, 0); break; }
     if (dtype == RIME_F32) {
