@@ -20,22 +20,47 @@ constexpr int RT = 8;     // map rows per block
 // round-robin, every L2 ends up fetching the whole map (measured at C4: 3.4 GB fetched by the fused psky builder for 1.1 GB of
 // algorithmic traffic).  xcd_tile() hands XCD k a CONTIGUOUS range of the launch-order tile numbers instead, so tiles that share
 // map lines meet in one L2.  Bijective for any grid size; a no-op on a single-XCD partition only in effect, not in result.
+// remap == 1: one contiguous range per XCD; remap = C > 1: chunk-cyclic -- of every 8 C consecutive tile numbers XCD k takes
+// [k C, (k + 1) C): locality within C tiles, the XCDs' shares interleaved along the tile axis (for tile axes along which
+// the work per tile varies); the tail that does not fill 8 C tiles keeps the launch order.
 __device__ __forceinline__ void xcd_tile(int remap, int& bx, int& by)
 {
     bx = blockIdx.x; by = blockIdx.y;
     if (!remap) return;
     const unsigned gx = gridDim.x, N = gx * gridDim.y;
     const unsigned L = blockIdx.x + blockIdx.y * gx;
-    const unsigned k = L & 7u, chunk = N >> 3, rem = N & 7u;
-    const unsigned Lp = k * chunk + (k < rem ? k : rem) + (L >> 3);
+    unsigned Lp;
+    if (remap == 1) {
+        const unsigned k = L & 7u, chunk = N >> 3, rem = N & 7u;
+        Lp = k * chunk + (k < rem ? k : rem) + (L >> 3);
+    } else {
+        const unsigned C = (unsigned)remap, super = 8u * C;
+        if (L >= N / super * super) return;
+        const unsigned i = L >> 3;
+        Lp = (i / C) * super + (L & 7u) * C + i % C;
+    }
     bx = (int)(Lp % gx); by = (int)(Lp / gx);
 }
 
-static int xcd_remap_enabled()
+// which kernels use it (lab switch RIME_XCD_REMAP = bit mask): 1 psky forward, 2 transposing product of the adjoint,
+// 4 sky gradient, 8 CSR scatter.  Measured at C4 (diffuse call, tools/bench_beam_sky.py): forward 0.545 -> 0.489 ms, sky
+// gradient - 0.045 ms; the transposing product does not care (+ 0.01) and the CSR scatter is 0.1 ms SLOWER although it
+// fetches less (contiguous node ranges are zenith-angle bands with very different list lengths: the XCDs finish at
+// different times; it takes the chunk-cyclic form below instead) -- so the default is forward + sky gradient.
+enum { XCD_FWD = 1, XCD_BWD = 2, XCD_SKYGRAD = 4, XCD_SCATTER = 8 };
+static int xcd_scatter_chunk()
 {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("RIME_XCD_REMAP"); v = (e && e[0] == '0') ? 0 : 1; }     // lab switch
+    // C4 diffuse adjoint, whole chain: launch order 1.245 ms, one contiguous range per XCD 1.344, chunks of 8 ... 64 1.205, 256
+    // 1.238, 512 1.274
+    if (v < 0) { const char* e = getenv("RIME_XCD_SCATTER_CHUNK"); v = e ? atoi(e) : 32; }     // lab switch
     return v;
+}
+static int xcd_remap_enabled(int which)
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("RIME_XCD_REMAP"); v = e ? atoi(e) : (XCD_FWD | XCD_SKYGRAD); }
+    return (v & which) ? 1 : 0;
 }
 
 template <typename T, int NC, int NNN>
@@ -110,6 +135,35 @@ interp_scatter_kernel(const T* __restrict__ goutT, const int* __restrict__ csr_p
     for (int rb = by * 64; rb < RN; rb += gridDim.y * 64) {
         const int r = rb + 4 * rq;
         T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+        if (vec_rows && rb + 64 <= RN) {                // uniform
+            // a node's list is a chain entry -> source index -> (weight, row of the source point): the indices of the NEXT
+            // four entries of the lane's slot are fetched while the rows of these four are in flight (the list is walked in
+            // the same order as by the plain loop below: same sums)
+            constexpr int U = 4;
+            int sn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int e = e0 + es + 4 * u; sn[u] = e < e1 ? csr_src[e] : -1; }
+            for (int eb = e0; eb < e1; eb += 4 * U) {   // uniform
+                int sc[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) sc[u] = sn[u];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const int e = eb + 4 * U + es + 4 * u; sn[u] = e < e1 ? csr_src[e] : -1; }
+                T w[U]; svec4<T> v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int src = sc[u] >= 0 ? sc[u] : 0;
+                    w[u] = sc[u] >= 0 ? wgts[src] : T(0);
+                    v[u] = *reinterpret_cast<const svec4<T>*>(goutT + (size_t)(pow2 ? src >> sh : src / Nnn) * RN + r);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (sc[u] >= 0) {
+                        a0 = tfma<T>(w[u], v[u].x, a0); a1 = tfma<T>(w[u], v[u].y, a1);
+                        a2 = tfma<T>(w[u], v[u].z, a2); a3 = tfma<T>(w[u], v[u].w, a3);
+                    }
+            }
+        } else {
 #pragma unroll 2
         for (int e = e0 + es; e < e1; e += 4) {
             const int src = csr_src[e];
@@ -124,6 +178,7 @@ interp_scatter_kernel(const T* __restrict__ goutT, const int* __restrict__ csr_p
                 if (r + 2 < RN) a2 = tfma<T>(w, p[2], a2);
                 if (r + 3 < RN) a3 = tfma<T>(w, p[3], a3);
             }
+        }
         }
         a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64); a3 += __shfl_xor(a3, 16, 64);
         a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64); a3 += __shfl_xor(a3, 32, 64);
@@ -186,7 +241,7 @@ static int scatter_launch(const void* goutT, const int* csr_ptr, const int* csr_
     dim3 grid((Npb + 3) / 4, ny), block(256);
     hipLaunchKernelGGL((interp_scatter_kernel<T>), grid, block, 0, st, reinterpret_cast<const T*>(goutT),
                        csr_ptr, csr_src, reinterpret_cast<const T*>(wgts), RN, Npb, Nnn,
-                       reinterpret_cast<T*>(gmT), xcd_remap_enabled());
+                       reinterpret_cast<T*>(gmT), xcd_scatter_chunk());
     return check_launch();
 }
 
@@ -347,10 +402,12 @@ beam_sky_fwd_kernel(const T* __restrict__ bmapT, const T* __restrict__ sky, cons
 template <typename T>
 __global__ void __launch_bounds__(256)
 beam_sky_bwd_kernel(const T* __restrict__ gps, const T* __restrict__ sky, const int* __restrict__ cut,
-                    int R, int Npix, int Q, T* __restrict__ T1)
+                    int R, int Npix, int Q, T* __restrict__ T1, int remap)
 {
     __shared__ T tile[64][65];
-    const int q0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    int bx, by;
+    xcd_tile(remap, bx, by);                           // neighbouring point tiles share the sky lines their cuts straddle
+    const int q0 = bx * 64, r0 = by * 64;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int q = q0 + lx;
     const int c = q < Q ? cut[q] : Npix;
@@ -508,7 +565,7 @@ static int beam_sky_fwd_launch(const void* bmap, const void* sky, const int* ind
     dim3 grid((Q + 63) / 64, (R + 63) / 64), block(256);
     const T* b_ = reinterpret_cast<const T*>(bmap); const T* s_ = reinterpret_cast<const T*>(sky);
     const T* w_ = reinterpret_cast<const T*>(wgts); T* o_ = reinterpret_cast<T*>(out);
-    const int remap = xcd_remap_enabled();
+    const int remap = xcd_remap_enabled(XCD_FWD);
 #define RIME_BS(N) hipLaunchKernelGGL((beam_sky_fwd_kernel<T, N>), grid, block, 0, st, b_, s_, inds, w_, cut, R, Npb, Npix, Q, Nnn, o_, remap)
     switch (Nnn) {
         case 1: RIME_BS(1); break;
@@ -542,7 +599,7 @@ extern "C" int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmapT
     if (R <= 0 || Npb <= 0 || Npix <= 0 || Nt <= 0 || Ps <= 0 || Nnn <= 0) return RIME_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int Q = Nt * Ps;
-    const int remap = xcd_remap_enabled();
+    const int remap = xcd_remap_enabled(XCD_SKYGRAD), remap_b = xcd_remap_enabled(XCD_BWD);
     dim3 g1((Q + 63) / 64, (R + 63) / 64), g2((Npix + 63) / 64, (R + 63) / 64);
 #define RIME_SG(TT, N) hipLaunchKernelGGL((sky_grad_kernel<TT, N>), g2, dim3(256), 0, st, (const TT*)gpsky, (const TT*)bmapT, \
         inds, (const TT*)wgts, pos, R, Npix, Nt, Ps, Nnn, (TT*)gsky, remap)
@@ -550,11 +607,11 @@ extern "C" int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmapT
         case 9: RIME_SG(TT, 9); break; case 16: RIME_SG(TT, 16); break; default: RIME_SG(TT, 0); break; }
     if (dtype == RIME_F32) {
         hipLaunchKernelGGL((beam_sky_bwd_kernel<float>), g1, dim3(256), 0, st, (const float*)gpsky, (const float*)sky, cut,
-                           R, Npix, Q, (float*)T1);
+                           R, Npix, Q, (float*)T1, remap_b);
         RIME_SG_ALL(float)
     } else if (dtype == RIME_F64) {
         hipLaunchKernelGGL((beam_sky_bwd_kernel<double>), g1, dim3(256), 0, st, (const double*)gpsky, (const double*)sky, cut,
-                           R, Npix, Q, (double*)T1);
+                           R, Npix, Q, (double*)T1, remap_b);
         RIME_SG_ALL(double)
     } else return RIME_EINVAL;
 #undef RIME_SG_ALL
