@@ -298,7 +298,10 @@ class RIME(utils.Module):
             if fused is not None:
                 # 1-pol power beam: interpolation, FoV cut and beam x sky in one pass (ops.beam_sky_product)
                 bc, st = fused
-                ps = ops.beam_sky_product(bc[0, 0, 0], sky[0, 0], st, bg['cut32'], bg['pos'], Nt, Ps)
+                # leading axes of length 1 are dropped by reshape (a view in the backward too: indexing them away
+                # costs a zero-fill + copy of the whole map / sky gradient per axis, 0.5 ms per C4 step)
+                b2 = bc.reshape(bc.shape[-2:]) if bc.numel() == bc.shape[-2] * bc.shape[-1] else bc[0, 0, 0]
+                ps = ops.beam_sky_product(b2, sky.reshape(sky.shape[-2:]), st, bg['cut32'], bg['pos'], Nt, Ps)
                 ps = ps.reshape(1, 1, 1, ps.shape[0], Nt * Ps)
             else:
                 # beam at the FoV-cut angles of ALL time steps: one response evaluation / gather launch
