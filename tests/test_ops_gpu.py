@@ -847,6 +847,46 @@ def test_beam_sky_product(ops, dtype, Nnn):
     assert float(out.detach().reshape(R, Nt, Ps)[:, 0, 150:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('Nt,R', [(1, 64), (2, 128), (5, 192), (9, 68)])
+def test_beam_sky_product_time_pipeline_edges(ops, Nt, R):
+    """the sky gradient's software pipeline over the time steps (stencils of step t+1 staged through LDS while step t is
+    contracted, positions two steps ahead) at its edges: a single step, two steps, an odd count, whole 64-channel tiles and
+    a partial one, sky pixels never visible / visible at every step, a time step with NO visible pixel in whole tiles"""
+    rng = np.random.default_rng(100 * Nt + R)
+    Npb, Npix, Ps, Nnn = 257, 700, 256, 4
+    cut = np.full((Nt, Ps), Npix, dtype=np.int64)
+    pos = np.full((Nt, Npix), -1, dtype=np.int64)
+    for t in range(Nt):
+        if Nt > 2 and t == 1:
+            c = np.arange(640, 700)                       # only the last tile of sky pixels sees this step
+        else:
+            c = np.sort(rng.choice(Npix - 64, int(rng.integers(100, Ps)), replace=False)) + (0 if t % 2 else 32)
+        cut[t, :len(c)] = c
+        pos[t, c] = np.arange(len(c))
+    inds = torch.as_tensor(rng.integers(0, Npb, (Nt * Ps, Nnn)))
+    wgts = T64(rng.normal(size=(Nt * Ps, Nnn)))
+    bmap, sky = T64(rng.normal(size=(R, Npb))), T64(rng.normal(size=(R, Npix)))
+    b_ref, s_ref = bmap.clone().requires_grad_(True), sky.clone().requires_grad_(True)
+    sky_ext = torch.cat([s_ref, torch.zeros(R, 1, dtype=torch.float64)], dim=1)
+    ref = orc.interp(b_ref, inds, wgts) * sky_ext[:, torch.as_tensor(cut.reshape(-1))]
+    gv = T64(rng.normal(size=tuple(ref.shape)))
+    (ref * gv).sum().backward()
+    for rdt, tol in ((torch.float64, 1e-12), (torch.float32, 3e-6)):
+        st = ops.InterpStencil(inds.cuda(), wgts.to(rdt).cuda(), Npb)
+        b, s_ = bmap.to(rdt).cuda().requires_grad_(True), sky.to(rdt).cuda().requires_grad_(True)
+        out = ops.beam_sky_product(b, s_, st, torch.as_tensor(cut.reshape(-1), dtype=torch.int32).cuda(),
+                                   torch.as_tensor(pos, dtype=torch.int32).cuda(), Nt, Ps)
+        assert relmax(out, ref) < tol
+        (out * gv.to(rdt).cuda()).sum().backward()
+        assert relmax(b.grad, b_ref.grad) < tol and relmax(s_.grad, s_ref.grad) < tol
+        # twice the same bits
+        b2, s2 = bmap.to(rdt).cuda().requires_grad_(True), sky.to(rdt).cuda().requires_grad_(True)
+        out2 = ops.beam_sky_product(b2, s2, st, torch.as_tensor(cut.reshape(-1), dtype=torch.int32).cuda(),
+                                    torch.as_tensor(pos, dtype=torch.int32).cuda(), Nt, Ps)
+        (out2 * gv.to(rdt).cuda()).sum().backward()
+        assert torch.equal(out, out2) and torch.equal(b.grad, b2.grad) and torch.equal(s_.grad, s2.grad)
+
+
 def test_side_kernels_at_c4_size(ops):
     """the HBM-bound kernels either side of the fringe sum at BASELINE config 4's sizes, float32 against the same
     kernels in float64 (themselves pinned to the oracle at small sizes) and against torch compositions: the fused
