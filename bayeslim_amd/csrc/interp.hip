@@ -83,10 +83,15 @@ interp_gather_kernel(const T* __restrict__ m, const int* __restrict__ inds,
             T acc[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[c] = T(0);
+            // a node of weight 0 contributes nothing even when the map holds a NaN / inf there (RIME's FoV cut is a one-node
+            // gather whose padding slots carry weight 0)
 #pragma unroll
             for (int k = 0; k < NNN; ++k)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) acc[c] = tfma<T>(w[k], row[(size_t)id[k] * NC + c], acc[c]);
+                for (int c = 0; c < NC; ++c) {
+                    const T v = row[(size_t)id[k] * NC + c];
+                    acc[c] = w[k] != T(0) ? tfma<T>(w[k], v, acc[c]) : acc[c];
+                }
 #pragma unroll
             for (int c = 0; c < NC; ++c) out[((size_t)r * out_stride + p) * NC + c] = acc[c];
         }

@@ -306,9 +306,17 @@ class RIME(utils.Module):
             else:
                 # beam at the FoV-cut angles of ALL time steps: one response evaluation / gather launch
                 beam = self.beam.eval_response(bg['zen'], bg['az'], prior_cache=prior_cache)
-                # sky with one trailing zero column: padded cut indices point at it
-                sky_ext = torch.cat([sky, sky.new_zeros(sky.shape[:-1] + (1,))], dim=-1)
-                cut_sky = sky_ext.index_select(-1, bg['cut'])        # beam_model.cut_sky_fov, all times
+                # beam_model.cut_sky_fov for all times at once, as a one-node gather (index = the cut, weight 1, 0 for the
+                # padding of a time step): no zero-extended copy of the sky, and its adjoint is the CSR gather of the
+                # interpolation kernels -- a sky pixel seen at several time steps is summed in a fixed order (the
+                # scatter-add of index_select's backward uses atomics: the sky gradient differed in the last bits from run
+                # to run)
+                st = bg.get('cut_stencil')
+                if st is None:
+                    cut = bg['cut']
+                    st = bg['cut_stencil'] = ops.InterpStencil(cut.clamp(max=Npix - 1).reshape(-1, 1),
+                                                               (cut < Npix).to(torch.float64).reshape(-1, 1), Npix)
+                cut_sky = ops.interp_gather(sky, st)
                 ps = self.beam.apply_beam_mp(beam, cut_sky, pairs)   # (n1, n2, Nmp, Nf, Nt*Ps)
             n1, n2, Nmp, Nf = ps.shape[:4]
             # -> (Nt, Nmp, Npp, Nf, Ps) as a strided VIEW: the fringe kernels take the strides
