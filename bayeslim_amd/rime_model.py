@@ -327,8 +327,21 @@ class RIME(utils.Module):
             vis = v if vis is None else vis + v
 
         idx = self._sim2data[self.bl_group_id]
-        if idx is not None:
-            vis = vis.index_select(2, idx.to(vis.device))           # rime_model.py:436-437
+        if idx is not None:                                          # rime_model.py:436-437
+            idx = idx.to(vis.device)
+            st = self.__dict__.setdefault('_inflate_cache', {}).get(self.bl_group_id)
+            if st is None or st[0] is not self._sim2data[self.bl_group_id]:
+                dup = bool(idx.numel() > torch.unique(idx).numel())
+                st = (self._sim2data[self.bl_group_id],
+                      ops.InterpStencil(idx.reshape(-1, 1), torch.ones(idx.numel(), 1, dtype=torch.float64, device=idx.device),
+                                        vis.shape[2]) if dup and vis.is_cuda else None)
+                self._inflate_cache[self.bl_group_id] = st
+            if st[1] is not None:
+                # redundant inflation (one simulated baseline feeds several data baselines): a one-node gather whose adjoint
+                # sums the copies in a fixed order (index_select's scatter-add backward uses atomics)
+                vis = ops.interp_gather(vis.movedim(2, -1), st[1]).movedim(-1, 2).contiguous()
+            else:
+                vis = vis.index_select(2, idx)
         if self.device is not None and not utils.check_devices(vis.device, self.device):
             vis = vis.to(self.device)
 
