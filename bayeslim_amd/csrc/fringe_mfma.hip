@@ -267,7 +267,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // 16 k + (W >> 1) + 2 ag, k = 0..3, and skips the k whose 8 rows are all padding: 37 antennas cost
     // 3 sweeps per wave instead of 4 (padding rows of the images are never written: they only reach
     // the result rows / columns of padding antennas, which have no baseline slot)
-    constexpr bool OCT = !SH::CROSS && SH::TA == 2;
+    constexpr bool OCT = !SH::CROSS && SH::TA <= 2;
     constexpr int NGEN = OCT ? SH::ROWS / 16 : (SH::SELF ? SH::GEN_I : SH::GEN);
     const int nk = OCT ? min(NGEN, (A.Nant - (W >> 1) + 15) / 16) : NGEN;     // uniform
     double ax[NGEN], ay[NGEN], az[NGEN];

@@ -122,7 +122,7 @@ class FringeGeometry:
             self.bl_order = torch.as_tensor(order, dtype=torch.int32, device=dev)
 
 
-MFMA_MIN_ANTS = int(os.environ.get('RIME_MFMA_MIN_ANTS', '33'))   # 'auto' threshold (see _setup_antenna_path)
+MFMA_MIN_ANTS = int(os.environ.get('RIME_MFMA_MIN_ANTS', '16'))   # 'auto' threshold (see _setup_antenna_path)
 MFMA_GROUP = 128          # antennas per group of the matrix-core path (4 x 4 tiles of 32)
 MFMA_MAX_ANTS = 2048      # table memory only: 136 blocks x 128 KB at 2048 antennas
 # complex psky, forward: diagonal blocks whose baselines all have one orientation run as
