@@ -1213,12 +1213,24 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                     }
 #else
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int an = 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
-                        const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
-                        const float rr = (float)__builtin_amdgcn_fract(ph);
-                        ec[8 * ks + jj] = __builtin_amdgcn_cosf(rr);
-                        es[8 * ks + jj] = __builtin_amdgcn_sinf(rr);
+                    for (int jq = 0; jq < 2; ++jq) {
+                        // the 8 antennas of this half K step (4 per half wave) are all padding: uniform skip -- 19 antennas
+                        // generate 24 phasors per pixel instead of 32, 37 generate 40 instead of 48 (their G rows and columns
+                        // are zero, so E = 0 gives the same bits)
+                        if (32 * tj + 16 * ks + 8 * jq >= A.Nant) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { ec[8 * ks + 4 * jq + u] = 0.f; es[8 * ks + 4 * jq + u] = 0.f; }
+                            continue;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int jj = 4 * jq + u;
+                            const int an = 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
+                            const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
+                            const float rr = (float)__builtin_amdgcn_fract(ph);
+                            ec[8 * ks + jj] = __builtin_amdgcn_cosf(rr);
+                            es[8 * ks + jj] = __builtin_amdgcn_sinf(rr);
+                        }
                     }
 #endif
 #pragma unroll
