@@ -31,6 +31,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int MF_NA = 128;                   // antennas per block (4 x 4 tiles)
+#ifndef RIME_OCT_MAX_TA
+#define RIME_OCT_MAX_TA 2      /* lab: 3 adds the three-row-tile blocks to the half-panel generation (measured + 0.5 %) */
+#endif
 #ifndef RIME_MF_SPLIT_PIX
 #define RIME_MF_SPLIT_PIX 8192
 #endif
@@ -267,7 +270,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // 16 k + (W >> 1) + 2 ag, k = 0..3, and skips the k whose 8 rows are all padding: 37 antennas cost
     // 3 sweeps per wave instead of 4 (padding rows of the images are never written: they only reach
     // the result rows / columns of padding antennas, which have no baseline slot)
-    constexpr bool OCT = !SH::CROSS && SH::TA <= 2;
+    constexpr bool OCT = !SH::CROSS && (SH::TA <= 2 || SH::TA == 4 || SH::TA <= RIME_OCT_MAX_TA);
     constexpr int NGEN = OCT ? SH::ROWS / 16 : (SH::SELF ? SH::GEN_I : SH::GEN);
     const int nk = OCT ? min(NGEN, (A.Nant - (W >> 1) + 15) / 16) : NGEN;     // uniform
     double ax[NGEN], ay[NGEN], az[NGEN];
