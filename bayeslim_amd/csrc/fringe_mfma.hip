@@ -271,12 +271,20 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // 3 sweeps per wave instead of 4 (padding rows of the images are never written: they only reach
     // the result rows / columns of padding antennas, which have no baseline slot)
     constexpr bool OCT = !SH::CROSS && (SH::TA <= 2 || SH::TA == 4 || SH::TA <= RIME_OCT_MAX_TA);
-    constexpr int NGEN = OCT ? SH::ROWS / 16 : (SH::SELF ? SH::GEN_I : SH::GEN);
+    // the same idea for the 8-wave complex-psky blocks (128 x 128 cross blocks, 128-antenna self blocks; C5): a wave generates
+    // one half of the panel for twice as many antennas per lane -- sweeps of 32 rows, rows 32 u + 2 ag + 16 ((W >> 1) & 1) + (W >> 2)
+#if defined(RIME_NO_OCTX)          /* lab: the two-half mapping */
+    constexpr bool OCTX = false;
+#else
+    constexpr bool OCTX = SH::CROSS && CPLX && SH::NW == 8;
+#endif
+    constexpr int NGEN = OCT ? SH::ROWS / 16 : (OCTX ? 2 : 1) * (SH::SELF ? SH::GEN_I : SH::GEN);
     const int nk = OCT ? min(NGEN, (A.Nant - (W >> 1) + 15) / 16) : NGEN;     // uniform
+    const int growx = 2 * ag + 16 * ((W >> 1) & 1) + (W >> 2);
     double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
     for (int u = 0; u < NGEN; ++u) {
-        const int an = OCT ? 16 * u + (W >> 1) + 2 * ag : SH::GROWS * u + grow;
+        const int an = OCT ? 16 * u + (W >> 1) + 2 * ag : (OCTX ? 32 * u + growx : SH::GROWS * u + grow);
         const bool ok = an < A.Nant;
         ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
         ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
@@ -372,8 +380,10 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
         }
         if constexpr (CPLX) {
             const float sb = scl * (1.0f / 128.0f), si = sb * A.imsign;
+            constexpr int HF0 = OCTX ? (W & 1) : 0, HF1 = OCTX ? (W & 1) + 1 : MF_NH;
+            constexpr int NI = (OCTX ? 2 : 1) * SH::GEN_I;      // sweeps that belong to group I
 #pragma unroll
-            for (int hf = 0; hf < MF_NH; ++hf) {
+            for (int hf = HF0; hf < HF1; ++hf) {
                 const float ar0 = av[hf].x * sb, ar1 = av[hf].y * sb, ai0 = aw[hf].x * si, ai1 = aw[hf].y * si;
 #pragma unroll
                 for (int u = 0; u < NGEN; ++u) {
@@ -383,8 +393,9 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                     const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                     const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
                     uint32_t rh, rl, ih, il;
-                    unsigned char* o = buf + goff + u * SH::GROWS * MF_ROWB + 32 * hf;
-                    if (SH::SELF || u < SH::GEN_I) { // group I: L = 2^7 E
+                    unsigned char* o = OCTX ? buf + (32 * u + growx) * MF_ROWB + pp * 4 + 32 * hf
+                                            : buf + goff + u * SH::GROWS * MF_ROWB + 32 * hf;
+                    if (SH::SELF || u < NI) { // group I: L = 2^7 E
                         split2(128.0f * c0, 128.0f * c1, rh, rl);
                         split2(128.0f * s0, 128.0f * s1, ih, il);
                         *reinterpret_cast<uint32_t*>(o) = rh;
@@ -393,7 +404,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                         *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
                         if constexpr (SH::SELF) o += SH::GEN_I * SH::GROWS * MF_ROWB;     // the same antenna's B row
                     }
-                    if (SH::SELF || u >= SH::GEN_I) { // group J: B = psky E (complex product)
+                    if (SH::SELF || u >= NI) { // group J: B = psky E (complex product)
                         split2(fmaf(ar0, c0, -ai0 * s0), fmaf(ar1, c1, -ai1 * s1), rh, rl);
                         split2(fmaf(ar0, s0, ai0 * c0), fmaf(ar1, s1, ai1 * c1), ih, il);
                         *reinterpret_cast<uint32_t*>(o) = rh;
@@ -560,7 +571,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // two panels per trip: buffer addresses are compile-time offsets
     unsigned char* const buf0 = smem;
     unsigned char* const buf1 = smem + MF_BUF;
-    if constexpr (OCT) fetch(pbeg, W & 1);
+    if constexpr (OCT || OCTX) fetch(pbeg, W & 1);
     else {
 #pragma unroll
         for (int hf = 0; hf < MF_NH; ++hf) fetch(pbeg, hf);
