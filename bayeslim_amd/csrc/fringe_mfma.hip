@@ -270,7 +270,13 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // 16 k + (W >> 1) + 2 ag, k = 0..3, and skips the k whose 8 rows are all padding: 37 antennas cost
     // 3 sweeps per wave instead of 4 (padding rows of the images are never written: they only reach
     // the result rows / columns of padding antennas, which have no baseline slot)
-    constexpr bool OCT = !SH::CROSS && (SH::TA <= 2 || SH::TA == 4 || SH::TA <= RIME_OCT_MAX_TA);
+    // OCT8: the 8-wave real-psky cross blocks (arrays of more than 128 antennas, 1-pol): sweeps of 32 rows as OCTX below
+#if defined(RIME_NO_OCT8)          /* lab */
+    constexpr bool OCT8 = false;
+#else
+    constexpr bool OCT8 = SH::CROSS && !SH::SELF && !CPLX && SH::NW == 8;
+#endif
+    constexpr bool OCT = OCT8 || (!SH::CROSS && (SH::TA <= 2 || SH::TA == 4 || SH::TA <= RIME_OCT_MAX_TA));
     // the same idea for the 8-wave complex-psky blocks (128 x 128 cross blocks, 128-antenna self blocks; C5): a wave generates
     // one half of the panel for twice as many antennas per lane -- sweeps of 32 rows, rows 32 u + 2 ag + 16 ((W >> 1) & 1) + (W >> 2)
 #if defined(RIME_NO_OCTX)          /* lab: the two-half mapping */
@@ -278,13 +284,13 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
 #else
     constexpr bool OCTX = SH::CROSS && CPLX && SH::NW == 8;
 #endif
-    constexpr int NGEN = OCT ? SH::ROWS / 16 : (OCTX ? 2 : 1) * (SH::SELF ? SH::GEN_I : SH::GEN);
-    const int nk = OCT ? min(NGEN, (A.Nant - (W >> 1) + 15) / 16) : NGEN;     // uniform
+    constexpr int NGEN = OCT8 ? SH::ROWS / 32 : OCT ? SH::ROWS / 16 : (OCTX ? 2 : 1) * (SH::SELF ? SH::GEN_I : SH::GEN);
+    const int nk = (OCT && !OCT8) ? min(NGEN, (A.Nant - (W >> 1) + 15) / 16) : NGEN;     // uniform
     const int growx = 2 * ag + 16 * ((W >> 1) & 1) + (W >> 2);
     double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
     for (int u = 0; u < NGEN; ++u) {
-        const int an = OCT ? 16 * u + (W >> 1) + 2 * ag : (OCTX ? 32 * u + growx : SH::GROWS * u + grow);
+        const int an = OCT8 ? 32 * u + growx : OCT ? 16 * u + (W >> 1) + 2 * ag : (OCTX ? 32 * u + growx : SH::GROWS * u + grow);
         const bool ok = an < A.Nant;
         ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
         ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
@@ -368,7 +374,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                     uint32_t rh, rl, ih, il;
                     split2(w0 * c0, w1 * c1, rh, rl);
                     split2(w0 * s0, w1 * s1, ih, il);
-                    unsigned char* o = buf + (16 * u + (W >> 1) + 2 * ag) * MF_ROWB + pp * 4 + 32 * hf;
+                    unsigned char* o = buf + (OCT8 ? 32 * u + growx : 16 * u + (W >> 1) + 2 * ag) * MF_ROWB + pp * 4 + 32 * hf;
                     *reinterpret_cast<uint32_t*>(o) = rh;
                     *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
                     *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
