@@ -50,7 +50,8 @@ SIGNATURES = {
     'rime_interp_gather_fwd': (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'rime_interp_scatter_bwd': (_i, [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'rime_beam_sky_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    'rime_beam_sky_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'rime_beam_sky_bwd_workspace': (_sz, [_i, _i, _i, _i]),
+    'rime_beam_sky_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'rime_jones_apply_fwd': (_i, [_i, _i, _vp, _vp, _vp, _ll, _ll, _vp, _vp]),
     'rime_jones_apply_bwd': (_i, [_i, _i, _vp, _vp, _vp, _vp, _ll, _ll, _vp, _vp, _vp, _vp]),
     'rime_chisq_workspace': (_sz, []),

@@ -440,8 +440,15 @@ template <typename T, int NNN>
 __global__ void __launch_bounds__(256, (NNN > 0 && NNN <= 4 && sizeof(T) == 4) ? RIME_SKYGRAD_BLOCKS : 1)
 sky_grad_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const int* __restrict__ inds,
                 const T* __restrict__ wgts, const int* __restrict__ pos, int R, int Npix, int Nt, int Ps, int Nnn,
-                T* __restrict__ gsky, int remap)
+                T* __restrict__ gsky, int remap, int Tc)
 {
+    // blockIdx.z = time split: steps [z Tc, min(Nt, (z + 1) Tc)) into plane z of gsky (a workspace when there are several: workloads
+    // of many time steps and few sky pixels -- C2: 192 tiles for 256 CUs, each walking 30 steps -- are split over time and the
+    // planes summed in a fixed order by plane_sum_kernel)
+    const int tz0 = blockIdx.z * Tc;
+    const size_t Q = (size_t)Nt * Ps;                  // row length of gpsky: ALL time steps
+    Nt = min(Nt, tz0 + Tc);
+    gsky += (size_t)blockIdx.z * R * Npix;
     __shared__ T tile[64][65];
     __shared__ int qsel[64];
     int bx, by;
@@ -449,7 +456,6 @@ sky_grad_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const in
     const int j0 = bx * 64, r0 = by * 64;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int j = j0 + lx;
-    const size_t Q = (size_t)Nt * Ps;
     T acc[16];
 #pragma unroll
     for (int k16 = 0; k16 < 16; ++k16) acc[k16] = T(0);
@@ -477,22 +483,22 @@ sky_grad_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const in
                 return pp >= 0 ? t * Ps + pp : -1;
             };
             {
-                const int q0 = q_of(0);
+                const int q0 = q_of(tz0);
                 const size_t qc = q0 >= 0 ? (size_t)q0 : 0;
                 sten_i[0][pl][pk] = inds[qc * 4 + pk];
                 sten_w[0][pl][pk] = wgts[qc * 4 + pk];
                 if (pk == 0) sten_q[0][pl] = q0;
             }
-            int q1 = q_of(1);
-            int pprod = j < Npix ? pos[j] : -1;
-            for (int t = 0; t < Nt; ++t) {
+            int q1 = q_of(tz0 + 1);
+            int pprod = (j < Npix && tz0 < Nt) ? pos[(size_t)tz0 * Npix + j] : -1;
+            for (int t = tz0; t < Nt; ++t) {
                 const int q = pprod >= 0 ? t * Ps + pprod : -1;
                 if (t + 1 < Nt) pprod = j < Npix ? pos[(size_t)(t + 1) * Npix + j] : -1;
                 const size_t qc1 = q1 >= 0 ? (size_t)q1 : 0;
                 const int nid = inds[qc1 * 4 + pk];
                 const T nw = wgts[qc1 * 4 + pk];
                 const int q2 = q_of(t + 2);
-                const int cur = t & 1;
+                const int cur = (t - tz0) & 1;
                 const bool any = __syncthreads_or(q >= 0);       // some pixel of the tile is above the horizon at t (uniform)
                 T g[16];
                 if (any) {
@@ -536,8 +542,8 @@ sky_grad_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const in
     }
     // the block is a chain of dependent memory phases per time step (pos -> stencil -> beam nodes -> gpsky);
     // pos of the next step and the gpsky column of this one are fetched ahead of the interpolation phase
-    int pnext = j < Npix ? pos[j] : -1;
-    for (int t = 0; t < Nt; ++t) {
+    int pnext = (j < Npix && tz0 < Nt) ? pos[(size_t)tz0 * Npix + j] : -1;
+    for (int t = tz0; t < Nt; ++t) {
         const int q = pnext >= 0 ? t * Ps + pnext : -1;
         if (threadIdx.x < 64) qsel[threadIdx.x] = q;
         if (t + 1 < Nt) pnext = j < Npix ? pos[(size_t)(t + 1) * Npix + j] : -1;
@@ -561,6 +567,27 @@ sky_grad_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const in
             if (r < R) gsky[(size_t)r * Npix + j] = acc[k16];
         }
     }
+}
+
+// sums the S time-split planes of the sky gradient in plane order (fixed: bitwise reproducible)
+template <typename T>
+__global__ void __launch_bounds__(256)
+plane_sum_kernel(const T* __restrict__ part, T* __restrict__ out, size_t len, int S)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (size_t)gridDim.x * 256) {
+        T v = part[i];
+        for (int z = 1; z < S; ++z) v += part[(size_t)z * len + i];
+        out[i] = v;
+    }
+}
+
+// time splits of the sky gradient: enough blocks for ~8 per CU, at least 4 time steps per split
+static int sky_grad_splits(int R, int Npix, int Nt)
+{
+    const long blocks = (long)((Npix + 63) / 64) * ((R + 63) / 64);
+    long S = std::min<long>((Nt + 3) / 4, (2048 + blocks - 1) / blocks);
+    if (const char* e = getenv("RIME_SKYGRAD_SPLITS")) { const long v = atol(e); if (v >= 1 && v <= Nt) S = v; }     // lab
+    return (int)std::max<long>(1, std::min<long>(S, 64));
 }
 
 template <typename T>
@@ -596,28 +623,49 @@ extern "C" int rime_beam_sky_fwd(int dtype, const void* bmap, const void* sky, c
     return RIME_EINVAL;
 }
 
+extern "C" size_t rime_beam_sky_bwd_workspace(int dtype, int R, int Npix, int Nt)
+{
+    if ((dtype != RIME_F32 && dtype != RIME_F64) || R <= 0 || Npix <= 0 || Nt <= 0) return 0;
+    const int S = sky_grad_splits(R, Npix, Nt);
+    return S > 1 ? (size_t)S * R * Npix * (dtype == RIME_F64 ? 8 : 4) : 0;
+}
+
 extern "C" int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmapT, const void* sky, const int* inds,
                                  const void* wgts, const int* cut, const int* pos, int R, int Npb, int Npix,
-                                 int Nt, int Ps, int Nnn, void* T1, void* gsky, void* stream)
+                                 int Nt, int Ps, int Nnn, void* T1, void* gsky, void* workspace, size_t workspace_bytes,
+                                 void* stream)
 {
     if (!gpsky || !bmapT || !sky || !inds || !wgts || !cut || !pos || !T1 || !gsky) return RIME_EINVAL;
     if (R <= 0 || Npb <= 0 || Npix <= 0 || Nt <= 0 || Ps <= 0 || Nnn <= 0) return RIME_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int Q = Nt * Ps;
     const int remap = xcd_remap_enabled(XCD_SKYGRAD), remap_b = xcd_remap_enabled(XCD_BWD);
-    dim3 g1((Q + 63) / 64, (R + 63) / 64), g2((Npix + 63) / 64, (R + 63) / 64);
+    // time splits of the sky gradient (their partial planes live in the workspace; without one the steps are walked in one go)
+    int S = sky_grad_splits(R, Npix, Nt);
+    if (S > 1 && (!workspace || workspace_bytes < rime_beam_sky_bwd_workspace(dtype, R, Npix, Nt))) {
+        if (workspace) return RIME_EWORKSPACE;
+        S = 1;
+    }
+    const int Tc = (Nt + S - 1) / S;
+    S = (Nt + Tc - 1) / Tc;
+    void* sg_out = S > 1 ? workspace : gsky;
+    dim3 g1((Q + 63) / 64, (R + 63) / 64), g2((Npix + 63) / 64, (R + 63) / 64, S);
 #define RIME_SG(TT, N) hipLaunchKernelGGL((sky_grad_kernel<TT, N>), g2, dim3(256), 0, st, (const TT*)gpsky, (const TT*)bmapT, \
-        inds, (const TT*)wgts, pos, R, Npix, Nt, Ps, Nnn, (TT*)gsky, remap)
+        inds, (const TT*)wgts, pos, R, Npix, Nt, Ps, Nnn, (TT*)sg_out, remap, Tc)
 #define RIME_SG_ALL(TT) switch (Nnn) { case 1: RIME_SG(TT, 1); break; case 4: RIME_SG(TT, 4); break; \
         case 9: RIME_SG(TT, 9); break; case 16: RIME_SG(TT, 16); break; default: RIME_SG(TT, 0); break; }
+    const size_t len = (size_t)R * Npix;
+    const int nb = (int)std::min<size_t>((len + 255) / 256, 4096);
     if (dtype == RIME_F32) {
         hipLaunchKernelGGL((beam_sky_bwd_kernel<float>), g1, dim3(256), 0, st, (const float*)gpsky, (const float*)sky, cut,
                            R, Npix, Q, (float*)T1, remap_b);
         RIME_SG_ALL(float)
+        if (S > 1) hipLaunchKernelGGL((plane_sum_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)workspace, (float*)gsky, len, S);
     } else if (dtype == RIME_F64) {
         hipLaunchKernelGGL((beam_sky_bwd_kernel<double>), g1, dim3(256), 0, st, (const double*)gpsky, (const double*)sky, cut,
                            R, Npix, Q, (double*)T1, remap_b);
         RIME_SG_ALL(double)
+        if (S > 1) hipLaunchKernelGGL((plane_sum_kernel<double>), dim3(nb), dim3(256), 0, st, (const double*)workspace, (double*)gsky, len, S);
     } else return RIME_EINVAL;
 #undef RIME_SG_ALL
 #undef RIME_SG

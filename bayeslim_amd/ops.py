@@ -782,8 +782,11 @@ class _BeamSkyProduct(torch.autograd.Function):
         g = g.contiguous()
         T1 = torch.empty((Q, R), dtype=b.dtype, device=b.device)
         gsky = torch.empty((R, Npix), dtype=b.dtype, device=b.device)
+        nws = int(lib.rime_beam_sky_bwd_workspace(code, R, Npix, Nt))
+        ws = torch.empty(nws, dtype=torch.uint8, device=b.device) if nws else None
         rc = lib.rime_beam_sky_bwd(code, _ptr(g), _ptr(b), _ptr(k), _ptr(st.inds), _ptr(st.weights(rdt)), _ptr(cut),
-                                   _ptr(pos), R, Npb, Npix, Nt, Ps, st.Nnn, _ptr(T1), _ptr(gsky), _stream())
+                                   _ptr(pos), R, Npb, Npix, Nt, Ps, st.Nnn, _ptr(T1), _ptr(gsky),
+                                   _ptr(ws) if ws is not None else None, nws, _stream())
         check(rc, 'rime_beam_sky_bwd')
         gmT = torch.empty((Npb, R), dtype=b.dtype, device=b.device)
         rc = lib.rime_interp_scatter_bwd(code, 0, _ptr(T1), _ptr(st.csr_ptr), _ptr(st.csr_src), _ptr(st.weights(rdt)),

@@ -240,9 +240,13 @@ int rime_interp_scatter_bwd(int dtype, int is_complex, const void* goutT,
  * ------------------------------------------------------------------------------------- */
 int rime_beam_sky_fwd(int dtype, const void* bmapT, const void* sky, const int* inds, const void* wgts,
                       const int* cut, int R, int Npb, int Npix, int Q, int Nnn, void* psky, void* stream);
+/* workspace: partial planes of the sky gradient when its time steps are split over blocks (workloads of many time steps and
+ * few sky pixels; 0 bytes when one block walks all steps).  NULL = no split. */
+size_t rime_beam_sky_bwd_workspace(int dtype, int R, int Npix, int Nt);
 int rime_beam_sky_bwd(int dtype, const void* gpsky, const void* bmapT, const void* sky, const int* inds,
                       const void* wgts, const int* cut, const int* pos, int R, int Npb, int Npix,
-                      int Nt, int Ps, int Nnn, void* T1, void* gsky, void* stream);
+                      int Nt, int Ps, int Nnn, void* T1, void* gsky, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Full-polarisation beam x sky product, elementwise:  psky[a, d] = sum_{b, c} J1[a, b] S[b, c] conj(J2[d, c])
