@@ -1130,7 +1130,10 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
     // stage G: fragment element (tile, ks, h, row, jj) <-> pair (i = 32 ti + row,
     // j = 32 tj + (jj & 3) + 8 (2 ks + (jj >> 2)) + 4 h); a thread packs the (jj, jj + 1) pair
     const float gs = A.gscale[t * A.Nf + f];
-    for (int e = tid; e < MB_TILES * 2 * 2 * 32 * 4; e += 512) {
+    // tiles (ti, tj) with ti <= tj < TA are the ones the contraction reads: in the 4 x 4 upper-triangular numbering they end at
+    // index 0 / 4 / 7 / 9 for TA = 1 .. 4, so small arrays stage 1 / 5 / 8 tiles instead of 10
+    const int ntl = TA == 1 ? 1 : TA == 2 ? 5 : TA == 3 ? 8 : MB_TILES;
+    for (int e = tid; e < ntl * 2 * 2 * 32 * 4; e += 512) {
         const int jp = e & 3, row = (e >> 2) & 31, h = (e >> 7) & 1, ks = (e >> 8) & 1, tile = e >> 9;
         int ti = 0, rem = tile;
         while (rem >= 4 - ti) { rem -= 4 - ti; ++ti; }
