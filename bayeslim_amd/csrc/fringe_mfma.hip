@@ -34,6 +34,9 @@ constexpr int MF_NA = 128;                   // antennas per block (4 x 4 tiles)
 #ifndef RIME_OCT_MAX_TA
 #define RIME_OCT_MAX_TA 2      /* lab: 3 adds the three-row-tile blocks to the half-panel generation (measured + 0.5 %) */
 #endif
+#ifndef RIME_OCTX_NW4
+#define RIME_OCTX_NW4 1         /* 0: the 4-wave complex-psky blocks keep the two-half generation mapping (lab) */
+#endif
 #ifndef RIME_MF_SPLIT_PIX
 #define RIME_MF_SPLIT_PIX 8192
 #endif
@@ -282,15 +285,16 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
 #if defined(RIME_NO_OCTX)          /* lab: the two-half mapping */
     constexpr bool OCTX = false;
 #else
-    constexpr bool OCTX = SH::CROSS && CPLX && SH::NW == 8;
+    constexpr bool OCTX = SH::CROSS && CPLX && (SH::NW == 8 || RIME_OCTX_NW4);
 #endif
+    constexpr int SWX = SH::NW * 4;                    // rows of an OCTX sweep: 32 (8 waves) or 16 (4 waves)
     constexpr int NGEN = OCT8 ? SH::ROWS / 32 : OCT ? SH::ROWS / 16 : (OCTX ? 2 : 1) * (SH::SELF ? SH::GEN_I : SH::GEN);
     const int nk = (OCT && !OCT8) ? min(NGEN, (A.Nant - (W >> 1) + 15) / 16) : NGEN;     // uniform
-    const int growx = 2 * ag + 16 * ((W >> 1) & 1) + (W >> 2);
+    const int growx = SH::NW == 8 ? 2 * ag + 16 * ((W >> 1) & 1) + (W >> 2) : 2 * ag + (W >> 1);
     double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
     for (int u = 0; u < NGEN; ++u) {
-        const int an = OCT8 ? 32 * u + growx : OCT ? 16 * u + (W >> 1) + 2 * ag : (OCTX ? 32 * u + growx : SH::GROWS * u + grow);
+        const int an = OCT8 ? 32 * u + growx : OCT ? 16 * u + (W >> 1) + 2 * ag : (OCTX ? SWX * u + growx : SH::GROWS * u + grow);
         const bool ok = an < A.Nant;
         ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
         ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
@@ -399,7 +403,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                     const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                     const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
                     uint32_t rh, rl, ih, il;
-                    unsigned char* o = OCTX ? buf + (32 * u + growx) * MF_ROWB + pp * 4 + 32 * hf
+                    unsigned char* o = OCTX ? buf + (SWX * u + growx) * MF_ROWB + pp * 4 + 32 * hf
                                             : buf + goff + u * SH::GROWS * MF_ROWB + 32 * hf;
                     if (SH::SELF || u < NI) { // group I: L = 2^7 E
                         split2(128.0f * c0, 128.0f * c1, rh, rl);

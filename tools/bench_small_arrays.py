@@ -52,6 +52,36 @@ def run(Nant, Nt, Nf, P):
         Nant, len(pairs), Nt, Nf, P, out[0][0], out[0][1], out[1][0], out[1][1], out[0][0] + out[0][1], out[1][0] + out[1][1], err))
 
 
+def run_fullpol(Nant, Nt, Nf, P):
+    """4-pol complex psky (the full-polarisation layout) on the matrix-core kernels: forward and backward times"""
+    dev = 'cuda'
+    rng = np.random.default_rng(Nant)
+    antpos = torch.as_tensor(rng.normal(0, 60.0, (Nant, 3)) * [1, 1, 0.01], device=dev)
+    pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
+    blv = torch.stack([antpos[j] - antpos[i] for i, j in pairs])
+    Ps = ops.pad_to_tile(P)
+    cz = torch.rand(Nt, Ps, device=dev, dtype=torch.float64)
+    az = torch.rand(Nt, Ps, device=dev, dtype=torch.float64) * 2 * np.pi
+    sz = torch.sqrt(1 - cz ** 2)
+    sdir = torch.stack([sz * torch.sin(az), sz * torch.cos(az), cz], dim=1)
+    freqs = torch.linspace(120e6, 180e6, Nf, dtype=torch.float64)
+    geom = ops.FringeGeometry(blv, sdir, freqs, antpos=antpos, bl_ants=pairs, mfma=True)
+    psky = torch.complex(torch.randn(Nt, 1, 4, Nf, Ps, device=dev), torch.randn(Nt, 1, 4, Nf, Ps, device=dev)).requires_grad_(True)
+    vis = ops.fringe_sum(psky, geom)
+    g = torch.randn_like(vis)
+    tf = timeit(lambda: ops.fringe_sum(psky.detach(), geom))
+
+    def fb():
+        psky.grad = None
+        ops.fringe_sum(psky, geom).backward(g)
+    print('4-pol complex psky, Nant %3d (%4d bl) Nt %d Nf %d P %6d:  forward %.3f ms  backward %.3f ms' % (
+        Nant, len(pairs), Nt, Nf, P, tf, timeit(fb) - tf))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'fullpol':
+    for Nant in (37, 64, 96, 128):
+        run_fullpol(Nant, 2, 64, 49152)
+    sys.exit(0)
 for Nant in (7, 10, 13, 16, 19, 24, 28, 32):
     run(Nant, 8, 64, 6144)
 for Nant in (10, 16, 24):
