@@ -451,6 +451,12 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
 FringeGeometry._setup_antenna_path = _setup_antenna_path
 
 
+def _fringe_algorithmic_bytes(geom, a, b):
+    """HBM bytes a fused fringe sum cannot avoid: psky (or gpsky) once, the visibilities (or their
+    gradient) once, the pointing vectors once -- both directions move the same tensors"""
+    return int(a.numel() * a.element_size() + b.numel() * b.element_size() + geom.sdir.numel() * geom.sdir.element_size())
+
+
 def _fringe_call(geom, backward, inp, out, Npp, cplx, strides=None):
     if geom.ant is not None and inp.dtype == torch.float32 and strides is not None:
         prof = PROFILE
@@ -460,7 +466,8 @@ def _fringe_call(geom, backward, inp, out, Npp, cplx, strides=None):
         flops = _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx)
         if prof is not None:
             e1.record()
-            prof.append(('fringe_ant_bwd_kernel' if backward else 'fringe_ant_fwd_kernel', e0, e1, geom.elements, flops))
+            prof.append(('fringe_ant_bwd_kernel' if backward else 'fringe_ant_fwd_kernel', e0, e1, geom.elements, flops,
+                         _fringe_algorithmic_bytes(geom, inp, out)))
         return
     code, rdt = _real_dtype(inp)
     fn = lib.rime_fringe_sum_bwd if backward else lib.rime_fringe_sum_fwd
@@ -478,7 +485,8 @@ def _fringe_call(geom, backward, inp, out, Npp, cplx, strides=None):
     check(rc, 'rime_fringe_sum_bwd' if backward else 'rime_fringe_sum_fwd')
     if prof is not None:
         e1.record()
-        prof.append(('fringe_bwd_kernel' if backward else 'fringe_fwd_kernel', e0, e1, geom.elements, 0))
+        prof.append(('fringe_bwd_kernel' if backward else 'fringe_fwd_kernel', e0, e1, geom.elements, 0,
+                     _fringe_algorithmic_bytes(geom, inp, out)))
 
 
 def _npp_chunks(Npp, cplx):

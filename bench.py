@@ -14,8 +14,10 @@ HEALPix diffuse sky + 1e4 point sources, 256 channels, interpolated Airy PixelBe
 A "step" = one RIME forward + backward over a minibatch of NT time steps.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): visibilities are independent
-across baselines and across channels.  Two partitions, BOTH measured in one invocation (the faster
-one is `value`, the other is reported under `alt`):
+across baselines and across channels.  Two partitions, BOTH measured (the faster one is `value`, the
+other is reported under `alt`), each by a FRESH worker process per rank: the rank process the launcher
+started only supervises (supervise_modes) and never touches the GPU, so a crash, hang or failed
+self-check of one partition cannot lose the other's finished result:
   --shard bl   the north-star partition.  Arrays served by the antenna-factored matrix-core kernels
                are cut by whole 32 x 32 antenna-pair tile blocks (dist.plan_tile_shards: the MFMA work
                is sharded, every rank regenerates the E operands of the antennas its tiles touch);
@@ -25,8 +27,12 @@ one is `value`, the other is reported under `alt`):
 Visibilities are all-gathered (RCCL) per time chunk, asynchronously, overlapping the next chunk's
 kernels; gradients of replicated parameters are summed in place (shared) or all-gathered by block
 (per-channel) from autograd hooks inside the last chunk's backward.  Total work is fixed, so scaling
-is "strong".  BENCH_FORCE_DIST=1 runs the same code path on ONE rank (RCCL initialised, every
-collective executed with world size 1) to rehearse it on a one-GPU box.
+is "strong".  After the timed region every N > 1 worker runs a VALUE SELF-CHECK (`dist.selfcheck`):
+one more step of the sharded model with the loss restricted to 64 sampled baselines x the first time
+of every chunk, whose gathered visibilities and exchanged gradients rank 0 compares with the
+unsharded float64 model (1e-5 / 1e-4; a worker that fails it exits non-zero).
+BENCH_FORCE_DIST=1 runs the same code path on ONE rank (RCCL initialised, every collective executed
+with world size 1, supervisor + workers + self-check) to rehearse it on a one-GPU box.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields), including
   roofline     -- dominant kernel (fused fringe sum): algorithmic flops / measured kernel time
@@ -420,6 +426,194 @@ def launch_ranks(nproc, script_argv, env=None, timeout=None, out=None):
 
 
 # ---------------------------------------------------------------------------------------------
+# N > 1: one fresh WORKER process per shard mode under every rank (the rank process itself only supervises)
+# ---------------------------------------------------------------------------------------------
+SHARD_MODES = ('freq', 'bl')
+
+
+def merge_mode_results(results):
+    """
+    results: [(shard, exit code, parsed JSON line or None)] in the order the modes ran.  The fastest mode whose worker
+    exited 0 is the line; every other mode is listed under `alt` -- with its numbers when it finished, with
+    `failed: <exit code>` when it did not (a mode that failed after printing a line, e.g. on its self-check, keeps the
+    line's `selfcheck` beside the code).  Returns (line dict or None, exit code): 0 as soon as ONE mode is good.
+    """
+    good = [(m, o) for m, rc, o in results if rc == 0 and o is not None]
+    if not good:
+        # nothing usable: hand back the first line that exists (its numbers are NOT to be trusted) and fail
+        first = next((o for _, _, o in results if o is not None), None)
+        rc = next((rc for _, rc, _ in results if rc != 0), 4)
+        if first is not None:
+            first = dict(first, failed=[dict(shard=m, failed=rc) for m, rc, _ in results])
+        return first, (rc or 4)
+    best_mode, best = min(good, key=lambda mo: mo[1]['ms_per_step'])
+    out = dict(best)
+    alt = []
+    for m, rc, o in results:
+        if m == best_mode:
+            continue
+        if rc == 0 and o is not None:
+            alt.append(dict(shard=m, parallelism=o.get('config', {}).get('parallelism'), ms_per_step=o['ms_per_step'],
+                            value=o['value'], tile_plan_load=o.get('dist', {}).get('tile_plan_load'),
+                            selfcheck=o.get('dist', {}).get('selfcheck')))
+        else:
+            e = dict(shard=m, failed=rc)
+            if o is not None and o.get('dist', {}).get('selfcheck') is not None:
+                e['selfcheck'] = o['dist']['selfcheck']
+            alt.append(e)
+    if alt:
+        out['alt'] = alt
+    return out, 0
+
+
+def supervise_modes(modes, worker_argv, rank, world, timeout, out=None, env=None):
+    """
+    Run by EVERY rank process of an N > 1 job before anything touches the GPU: for each shard mode in turn start a
+    fresh worker process (`worker_argv + ['--shard', mode, '--worker']`) that joins the other ranks' workers of the same
+    mode in a process group of its own (BENCH_PG_TAG: a PrefixStore on the launcher's store, or a port of its own), wait
+    for it with `timeout` seconds (the worker's process group is killed at the limit) and go on to the next mode
+    WHATEVER happened to this one: a crash or hang of the second mode cannot lose the first mode's finished result.
+    Rank 0 collects its workers' JSON lines, merges them (merge_mode_results) and writes ONE line to `out`.
+    Returns the exit code: 0 when at least one mode finished on this rank.
+    """
+    import signal
+    import subprocess
+    base_env = dict(os.environ if env is None else env)
+    agent_store = base_env.get('TORCHELASTIC_USE_AGENT_STORE') == 'True'
+    base_port = int(base_env.get('MASTER_PORT', '29533'))
+    if not agent_store and world == 1:
+        base_port = _free_port()
+    current = {}
+
+    def forward(signum, frame):
+        # the launcher ends its ranks with SIGTERM: take this rank's worker group along
+        p = current.get('p')
+        if p is not None and p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+            except ProcessLookupError:
+                pass
+        raise SystemExit(128 + signum)
+
+    old = {}
+    try:
+        for sg in (signal.SIGTERM, signal.SIGINT):
+            old[sg] = signal.signal(sg, forward)
+    except ValueError:                      # not the main thread (tests): no forwarding
+        old = {}
+    results = []
+    try:
+        for k, mode in enumerate(modes):
+            e = dict(base_env, BENCH_PG_TAG='%s%d' % (mode, k), RANK=str(rank), WORLD_SIZE=str(world))
+            e.setdefault('LOCAL_RANK', str(rank))
+            e.setdefault('MASTER_ADDR', '127.0.0.1')
+            # without a launcher store the worker of rank 0 hosts the store itself: one port per mode
+            e['MASTER_PORT'] = str(base_port if agent_store else (base_port + k if world > 1 else (base_port if k == 0 else _free_port())))
+            cmd = [sys.executable] + list(worker_argv) + ['--shard', mode, '--worker']
+            t0 = time.perf_counter()
+            p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if rank == 0 else sys.stderr, start_new_session=True)
+            current['p'] = p
+            try:
+                stdout, _ = p.communicate(timeout=timeout)
+                rc = p.returncode
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                    try:
+                        p.wait(timeout=15)
+                    except subprocess.TimeoutExpired:
+                        os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                stdout, _ = p.communicate()
+                rc = 124
+                sys.stderr.write('bench.py rank %d: shard mode %s did not finish within %s s; killed\n' % (rank, mode, timeout))
+            current['p'] = None
+            obj = None
+            for ln in (stdout or b'').decode(errors='replace').splitlines():
+                try:
+                    o = json.loads(ln)
+                except ValueError:
+                    o = None
+                if isinstance(o, dict) and 'metric' in o and 'value' in o:
+                    obj = o
+                elif ln.strip():
+                    sys.stderr.write(ln + '\n')
+            if rc == 0 and rank == 0 and obj is None:
+                rc = 4
+            sys.stderr.write('bench.py rank %d: shard mode %s -> exit code %d after %.1f s\n' % (rank, mode, rc, time.perf_counter() - t0))
+            sys.stderr.flush()
+            results.append((mode, rc, obj))
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    if rank != 0:
+        return 0 if any(rc == 0 for _, rc, _ in results) else next(rc for _, rc, _ in results)
+    line, rc = merge_mode_results(results)
+    if line is not None and out is not None:
+        out.write(json.dumps(line) + '\n')
+        out.flush()
+    return rc
+
+
+def _init_process_group(backend, rank, world, dev, timeout):
+    """
+    The workers of one shard mode form their own process group.  Under the launcher (torch.distributed.run keeps a
+    TCPStore at MASTER_ADDR:MASTER_PORT and tells its children so) every mode's group lives under its own prefix of
+    that store (BENCH_PG_TAG) -- two groups in a row with the default keys would read each other's RCCL unique ids;
+    without a launcher store rank 0 hosts one at MASTER_PORT (a port per mode, chosen by the supervisor).
+    """
+    import torch.distributed as dist
+    kw = dict(device_id=dev) if backend == 'nccl' else {}            # bind the communicator to this rank's GPU up front
+    tag = os.environ.get('BENCH_PG_TAG')
+    if tag is None:
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout, **kw)
+        return
+    agent_store = os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True'
+    store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), world,
+                          is_master=(rank == 0 and not agent_store), timeout=timeout, wait_for_workers=False)
+    dist.init_process_group(backend, store=dist.PrefixStore('bench/' + tag, store), rank=rank, world_size=world,
+                            timeout=timeout, **kw)
+
+
+def _set_collective_timeout(seconds):
+    """lower the collective watchdog of the default group (a private torch API: guarded); returns the timeout in effect"""
+    import datetime
+    try:
+        from torch.distributed import distributed_c10d as _c10d
+        _c10d._set_pg_timeout(datetime.timedelta(seconds=float(seconds)))
+        return float(seconds)
+    except Exception as err:                 # API moved or refused: the rendezvous timeout stays
+        sys.stderr.write('bench.py: collective timeout left at the default (%s: %s)\n' % (type(err).__name__, err))
+        return None
+
+
+SELFCHECK_TOL = dict(vis=1e-5, grad=1e-4)
+
+
+def selfcheck_reference(inp, dev, bls, sample, first_times):
+    """
+    float64 reference of the self-check: the UNSHARDED model (same seed -> same parameters, widened) on the sampled
+    baselines x the first time step of every time chunk x all channels, on the float64 vector-ALU kernels, with the
+    self-check's loss (sum |V|^2 over exactly those entries).  Returns (vis, [gradients]).  Outside the timed region.
+    """
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        sub = dict(inp, times=inp['times'][first_times], zenaz=inp['zenaz'][first_times])
+        if 'pt_zenaz' in inp:
+            sub['pt_zenaz'] = inp['pt_zenaz'][first_times]
+        rime, params, attach, _ = build_model(sub, dev, [bls[i] for i in sample], dtype=torch.float64)
+        attach()
+        v = rime().data
+        (v.real ** 2 + v.imag ** 2).sum().backward()
+        torch.cuda.synchronize()
+        return v.detach(), [p.grad.detach() for p in params]
+    finally:
+        torch.set_default_dtype(old)
+
+
+# ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -433,10 +627,11 @@ def main():
                     help='NOT the headline configuration: simulate one baseline per redundant group and inflate to all '
                          'baselines (the reference\'s data_bls mechanism); N = 1 only')
     ap.add_argument('--shard', default='auto', choices=['auto', 'freq', 'bl'],
-                    help='multi-GPU partition: channel blocks or baseline (tile) blocks; auto measures both and '
-                         'reports the faster one as `value`, the other under `alt`')
+                    help='multi-GPU partition: channel blocks or baseline (tile) blocks; auto measures both, each in a '
+                         'fresh worker process, and reports the faster one as `value`, the other under `alt`')
     ap.add_argument('--chunks', type=int, default=2,
                     help='N > 1: time chunks per step (the all-gather of one chunk overlaps the kernels of the next)')
+    ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)     # set by supervise_modes
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher around it: become the launcher.  Decided BEFORE anything touches the
@@ -445,7 +640,24 @@ def main():
         raise SystemExit('--gpus must be >= 1')
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         rc, _ = launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:],
-                             timeout=float(os.environ.get('BENCH_LAUNCH_TIMEOUT', '1500')), out=sys.stdout)
+                             timeout=float(os.environ.get('BENCH_LAUNCH_TIMEOUT', '2400')), out=sys.stdout)
+        raise SystemExit(rc)
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
+    distributed = world > 1 or os.environ.get('BENCH_FORCE_DIST', '0') == '1'
+
+    # N > 1 with both partitions to measure: this rank process SUPERVISES one fresh worker per partition and never
+    # touches the GPU itself (a crash, hang or failed self-check of one partition cannot lose the other's result)
+    if distributed and args.shard == 'auto' and not args.worker:
+        nants = len(hera_array(WORKLOADS[args.workload]['array'])[0])
+        mfma_min = int(os.environ.get('RIME_MFMA_MIN_ANTS', '16'))
+        modes = list(SHARD_MODES) if nants >= mfma_min else list(SHARD_MODES[::-1])
+        rc = supervise_modes(modes, [os.path.abspath(__file__)] + sys.argv[1:], rank, world,
+                             timeout=float(os.environ.get('BENCH_MODE_TIMEOUT', '900')), out=sys.stdout)
         raise SystemExit(rc)
 
     # stdout carries exactly ONE JSON line: libraries that chat on fd 1 (RCCL's version banner, gloo's
@@ -454,11 +666,6 @@ def main():
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     # BENCH_DEVICE / BENCH_BACKEND exist only to rehearse the N > 1 code path on a one-GPU box
     # (all ranks on device 0 over gloo); the driver's runs use one rank per GPU over RCCL
     devidx = int(os.environ.get('BENCH_DEVICE', local_rank))
@@ -470,23 +677,22 @@ def main():
     torch.cuda.set_device(devidx)
     dev = torch.device('cuda', devidx)
     import torch.distributed as dist
-    distributed = world > 1 or os.environ.get('BENCH_FORCE_DIST', '0') == '1'
+    collective_timeout = None
     if distributed:
         backend = os.environ.get('BENCH_BACKEND', 'nccl')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         import datetime
-        # 'nccl' == RCCL on ROCm; device chosen above.  The rendezvous gets minutes (the first `import torch` on a fresh
-        # box pages the image in, ranks arrive staggered); after the first barrier the watchdog drops to
+        # 'nccl' == RCCL on ROCm; device chosen above.  The rendezvous and everything up to the end of the warm-up get
+        # minutes (the first `import torch` on a fresh box pages the image in, ranks arrive staggered, first-use kernel
+        # loading and uneven tile plans skew the ranks); after the warm-up the watchdog drops to
         # BENCH_COLLECTIVE_TIMEOUT seconds (default 60; a step of any workload here takes < 6 s), so a collective that some
         # rank never joins aborts the job within a minute instead of hanging it
-        kw = dict(device_id=dev) if backend == 'nccl' else {}        # bind the communicator to this rank's GPU up front
-        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10), **kw)
+        _init_process_group(backend, rank, world, dev, datetime.timedelta(minutes=10))
         if dist.get_world_size() != args.gpus:
             raise SystemExit('bench.py: %d ranks joined, --gpus %d asked for' % (dist.get_world_size(), args.gpus))
         dist.barrier()
-        from torch.distributed import distributed_c10d as _c10d
-        _c10d._set_pg_timeout(datetime.timedelta(seconds=float(os.environ.get('BENCH_COLLECTIVE_TIMEOUT', '60'))))
+        collective_timeout = 600.0
 
     from bayeslim_amd import ops, dist as rdist
 
@@ -504,12 +710,11 @@ def main():
     bls = all_baselines(inp)
     mfma_array = len(inp['ants']) >= ops.MFMA_MIN_ANTS          # antenna-factored matrix-core kernels apply
     if args.shard == 'auto':
-        modes = ['freq', 'bl'] if mfma_array else ['bl', 'freq']
+        shard = 'freq' if mfma_array else 'bl'                  # N = 1: the partition is the whole problem either way
     else:
-        modes = [args.shard]
-    if not distributed:
-        modes = modes[:1]
+        shard = args.shard
     nchunks = 1 if not distributed else max(1, min(args.chunks, nt))
+    do_check = os.environ.get('BENCH_SELFCHECK', '1' if distributed else '0') == '1'
 
     def sync():
         torch.cuda.synchronize()
@@ -519,6 +724,7 @@ def main():
 
     def run_mode(shard):
         """build this rank's shard, warm up, time `steps` steps; returns the measurements"""
+        nonlocal collective_timeout
         plan = None
         if shard == 'freq':
             bounds = rdist.shard_bounds(cfg['Nf'], world)
@@ -533,6 +739,10 @@ def main():
                 my_bls = [bls[i] for i in plan['rank_bls'][rank]]
                 counts = [len(b) for b in plan['rank_bls']]
                 inverse = torch.as_tensor(plan['inverse'], device=dev)
+                if os.environ.get('BENCH_BREAK_INVERSE') == '1':
+                    # FAULT INJECTION for tests/test_bench_gpu.py only: leave the gathered baselines in rank order, so
+                    # that the self-check has something to catch
+                    inverse = None
                 label = 'baseline-tile-sharded x%d (groups of %d antennas, %s blocks per rank)' % (
                     world, plan['group'], '/'.join(str(n) for n in plan['nblocks']))
             else:
@@ -560,12 +770,12 @@ def main():
         prof = []
         ops.PROFILE = prof
 
-        def loss_fn(vis, k):
+        def chisq_loss(vis, k):
             # sum |V|^2 through the fused chi-square epilogue (one pass forward, one pass backward);
             # the torch composition (vis.real ** 2 + vis.imag ** 2).sum() costs ten small launches and 0.3 ms per C4 step
             return ops.chisq(vis)
 
-        def step():
+        def step(loss_fn=chisq_loss):
             for p in params:
                 p.grad = None
             if not distributed:
@@ -596,6 +806,10 @@ def main():
             dbg('mode %s: warm-up step %d enqueued' % (shard, k))
         sync()
         dbg('mode %s: warm-up done' % shard)
+        if distributed:
+            # every rank has loaded its kernels and run its plan: from here on a collective takes milliseconds
+            eff = _set_collective_timeout(os.environ.get('BENCH_COLLECTIVE_TIMEOUT', '60'))
+            collective_timeout = eff if eff is not None else collective_timeout
         prof.clear()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -608,6 +822,27 @@ def main():
             dt = float(tt.item())
         ops.PROFILE = None
         dbg('mode %s: timed steps done, %.1f ms/step' % (shard, dt / args.steps * 1e3))
+
+        # ---- value self-check, OUTSIDE the timed region: one more step of the SAME sharded model with the loss
+        # restricted to sampled baselines x the first time step of every chunk x all channels; rank 0 compares the
+        # gathered visibilities and the exchanged gradients with the unsharded float64 model below
+        check = None
+        if do_check:
+            sample = sorted(set(np.linspace(0, len(bls) - 1, min(64, len(bls))).round().astype(int).tolist()))
+            s_idx = torch.as_tensor(sample, device=dev)
+            first = [int(c[0]) for c in np.array_split(np.arange(nt), nchunks)]
+            got = {}
+
+            def check_loss(vis, k):
+                s = vis.index_select(2, s_idx)[:, :, :, :1]
+                got[k] = s.detach().clone()
+                return (s.real ** 2 + s.imag ** 2).sum()
+
+            step(check_loss)
+            sync()
+            check = dict(sample=sample, first=first, vis=torch.cat([got[k] for k in range(nchunks)], dim=3),
+                         grads=[p.grad.detach().clone() for p in params])
+            dbg('mode %s: self-check step done' % shard)
         if gsync is not None:
             gsync.remove()
         grad_bytes = sum(p.numel() * p.element_size() for p in params)
@@ -615,30 +850,53 @@ def main():
         res = dict(shard=shard, label=label, dt=dt, prof=list(prof), vis_bytes=vis_bytes, grad_bytes=grad_bytes,
                    plan_load=None if plan is None else [round(x, 1) for x in plan['load']],
                    hook_order=None if gsync is None else list(gsync.fired),
-                   order_adapted=None if gsync is None else gsync.adapted)
+                   order_adapted=None if gsync is None else gsync.adapted, check=check)
         del rime, params, attach
         torch.cuda.empty_cache()
         return res
 
-    results = [run_mode(m) for m in modes]
-    best = min(results, key=lambda r: r['dt'])
-    dt, prof, shard = best['dt'], best['prof'], best['shard']
+    best = run_mode(shard)
+    dt, prof = best['dt'], best['prof']
+
+    selfcheck = None
+    if distributed and best['check'] is not None:
+        # rank 0 now computes the float64 reference while the others wait at the closing barrier: minutes, not seconds
+        _set_collective_timeout(600)
+    if best['check'] is not None and rank == 0:
+        ck = best['check']
+        v64, g64 = selfcheck_reference(inp, dev, bls, ck['sample'], ck['first'])
+        vis_rel = float((ck['vis'].to(v64.dtype) - v64).abs().max() / v64.abs().max())
+        grad_rel = max(float((a.to(b.dtype) - b).abs().max() / b.abs().max().clamp_min(1e-300)) for a, b in zip(ck['grads'], g64))
+        ok = vis_rel < SELFCHECK_TOL['vis'] and grad_rel < SELFCHECK_TOL['grad']
+        selfcheck = dict(vis_relmax=vis_rel, grad_relmax=grad_rel, tol=[SELFCHECK_TOL['vis'], SELFCHECK_TOL['grad']], ok=ok,
+                         what='%d sampled baselines x first time of each of %d chunk(s) x %d channels: gathered visibilities and '
+                              'exchanged gradients (loss = sum |V|^2 over those entries) of one extra step of the sharded model '
+                              'after the timed region, against the unsharded float64 model on the vector-ALU kernels (rank 0); '
+                              'max |a - b| / max |b|' % (len(ck['sample']), nchunks, cfg['Nf']))
+        dbg('self-check: vis %.2e grad %.2e' % (vis_rel, grad_rel))
+    best['check'] = None
 
     # kernel-level roofline from the HIP events recorded around each C-ABI launch
     kstat = {}
-    for name, e0, e1, elems, mflops in prof:
+    for name, e0, e1, elems, mflops, abytes in prof:
         ms = e0.elapsed_time(e1)
-        k = kstat.setdefault(name, [0, 0.0, 0, 0])
+        k = kstat.setdefault(name, [0, 0.0, 0, 0, 0, 0.0, []])
         k[0] += 1
         k[1] += ms
         k[2] += elems
         k[3] += mflops
+        k[6].append((abytes, ms))
+    for k in kstat.values():
+        # the kernel's largest launches (C4: the diffuse component) and their mean duration
+        k[4] = max(a for a, _ in k[6])
+        big = [m for a, m in k[6] if a == k[4]]
+        k[5] = sum(big) / len(big)
     roof = None
     if kstat:
         # dominant kernel = the one with the largest total time over the timed region, nothing else; the hot kernel with
         # the LOWEST fraction of its roof is named beside it (min_frac_kernel / min_frac)
         dom = max(kstat, key=lambda nm: kstat[nm][1])
-        n, ms, elems, mflops = kstat[dom]
+        n, ms, elems, mflops, abytes_dom, ms_dom = kstat[dom][:6]
         flop_per_elem = 10.0                 # 6 (phase rotation) + 4 (real psky accumulate), SURVEY 8(d)
         algorithmic = elems * flop_per_elem / (ms * 1e-3) / 1e12
         # useful arithmetic of the contraction itself: one complex multiply-accumulate (8 flop) per
@@ -649,40 +907,33 @@ def main():
             # execute (3 hi/lo cross products on the upper-triangular antenna tiles, tile padding included;
             # the forward folds the symmetric products of the diagonal tiles: 7 instead of 12 MFMAs there)
             achieved, peak, pipe, bound = (mflops / (ms * 1e-3) / 1e12, F16_MFMA_PEAK_TFLOPS,
-                                           'f16 MFMA (v_mfma_f32_32x32x16_f16), EXECUTED flops: 3 hi/lo split products + tile padding', 'mfma')
+                                           'f16 MFMA, EXECUTED flops: 3 hi/lo split products + tile padding', 'mfma')
         else:
             achieved, peak, pipe, bound = algorithmic, FP32_PEAK_TFLOPS, 'fp32 vector ALU (== fp32 MFMA dense peak), algorithmic flops', 'valu'
-        # HBM traffic of that kernel per launch: PMC counters cannot be read from inside the process; a
-        # committed summary of separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over this same
+        # HBM traffic of that kernel's DOMINANT launch (C4: the diffuse component): PMC counters cannot be read from inside
+        # the process; a committed summary of separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over this same
         # command is quoted when one exists for the workload (else null) and its path is given
-        traffic, traffic_source = None, None
-        for rel in ('profiles/r03/traffic.json', 'profiles/r02/traffic.json', 'profiles/r01/traffic.json'):
-            tpath = os.path.join(ROOT, rel)
-            if args.workload == 'c4' and world == 1 and not args.nf and os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(dom, {}).get('hbm_bytes_per_launch')
-                    traffic_source = rel + ' (separate rocprofv3 --pmc passes, not this run)'
-                except Exception:
-                    traffic = None
-                if traffic is not None:
-                    break
-        # the chip holds ~1.75 GHz of its 2.4 GHz under this load (GRBM_GUI_ACTIVE / kernel time in the committed PMC
-        # summary): the same executed rate against the peak AT THAT CLOCK, as information only
-        clock, clock_src = None, None
-        for rel in ('profiles/r03/pmc_summary.json', 'profiles/r02/pmc_summary.json'):
+        traffic, traffic_source, clock, clock_src = None, None, None, None
+        for rel in ('profiles/r04/pmc_summary.json', 'profiles/r03/pmc_summary.json'):
             cpath = os.path.join(ROOT, rel)
-            if clock is None and mflops > 0 and args.workload == 'c4' and os.path.exists(cpath):
+            if traffic is None and args.workload == 'c4' and world == 1 and not args.nf and os.path.exists(cpath):
                 try:
                     pm = json.load(open(cpath))
-                    clock = next((v.get('clock_GHz') for k, v in pm.items() if k.startswith(dom) and v.get('clock_GHz')), None)
-                    clock_src = rel
+                    inst = [v for k, v in pm.items() if k.split('<')[0] == dom and v.get('hbm_bytes_per_launch_larger_half')]
+                    big = max(inst, key=lambda v: v['hbm_bytes_per_launch_larger_half'])
+                    traffic = big['hbm_bytes_per_launch_larger_half']
+                    traffic_source = rel + ' (separate rocprofv3 --pmc passes of this command, not this run; the kernel\'s largest launch)'
+                    # the chip holds ~1.75 GHz of its 2.4 GHz under this load (GRBM_GUI_ACTIVE / kernel time)
+                    clock, clock_src = big.get('clock_GHz'), rel
                 except Exception:
-                    clock = None
+                    traffic = None
         # every kernel's fraction of ITS roof (f16 MFMA peak on executed flops / fp32 peak on algorithmic flops)
         per_kernel = {k: dict(launches=v[0], total_ms=round(v[1], 3),
                               **({'executed_tflops': round(v[3] / (v[1] * 1e-3) / 1e12, 2),
                                   'frac': round(v[3] / (v[1] * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4),
-                                  'useful_tflops': round(v[2] * 8.0 / (v[1] * 1e-3) / 1e12, 2)} if v[3] > 0 else
+                                  'useful_tflops': round(v[2] * 8.0 / (v[1] * 1e-3) / 1e12, 2),
+                                  'useful_frac_of_pipe_peak': round(v[2] * 8.0 / (v[1] * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4)}
+                                 if v[3] > 0 else
                                  {'algorithmic_tflops': round(v[2] * flop_per_elem / (v[1] * 1e-3) / 1e12, 2),
                                   'frac': round(v[2] * flop_per_elem / (v[1] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}))
                       for k, v in kstat.items()}
@@ -697,21 +948,39 @@ def main():
                 vendor = None
         hot = [k for k in kstat if kstat[k][1] >= 0.10 * kstat[dom][1]]      # kernels that matter for the step time
         worst = min(hot, key=lambda k: per_kernel[k]['frac'])
+        # SURVEY 8(d)'s own figure for the WHOLE step: 2 E (6 + 4) flop per fringe element (forward + backward of the
+        # baseline formulation) / wall time / the fp32 peak.  Above 1 on the matrix-core path: the antenna factorisation
+        # moved the contraction to the f16 pipe and cut the exponentials Nant-fold -- not a precision-free comparison
+        step_elems = sum(v[2] for v in kstat.values())
+        survey_frac = step_elems * flop_per_elem / dt / 1e12 / FP32_PEAK_TFLOPS
         roof = dict(bound=bound, kernel=dom, achieved=round(achieved, 2), peak=peak, unit='TFLOP/s',
                     frac=round(achieved / peak, 4),
+                    frac_note='EXECUTED flops of the dominant kernel / dense peak of its pipe' if mflops > 0 else
+                              'algorithmic flops of the dominant kernel / fp32 peak',
+                    useful_frac_of_pipe_peak=round(useful / peak, 4),
+                    useful_tflops=round(useful, 2),
+                    useful_note='8 flop (one complex MAC) per antenna pair x pixel x channel x time -- what the kernel is FOR; '
+                                'the rest of the executed flops is the price of the 3-product f16 split and of tile padding.  '
+                                'The fp32 vector / matrix peak that bounds an exact-f32 contraction is %.1f TFLOP/s' % FP32_PEAK_TFLOPS,
+                    frac_vs_fp32_roof_survey8d=round(survey_frac, 4),
+                    survey8d_note='whole step: 20 flop per fringe element (fwd + bwd, SURVEY 8d) / wall time / %.1f TFLOP/s'
+                                  % FP32_PEAK_TFLOPS,
                     min_frac_kernel=worst, min_frac=per_kernel[worst]['frac'],
                     min_frac_note='lowest fraction of its roof among the kernels with >= 10 % of the dominant kernel\'s time',
-                    traffic=traffic, traffic_source=traffic_source, pipe=pipe,
+                    traffic=traffic, traffic_source=traffic_source,
+                    algorithmic_bytes=abytes_dom,
+                    traffic_ratio=None if traffic is None or not abytes_dom else round(traffic / abytes_dom, 3),
+                    bytes_note='per launch of the kernel\'s largest component (C4: diffuse sky): algorithmic = psky + visibilities '
+                               '+ pointing vectors once; traffic = (2 FETCH_SIZE + WRITE_SIZE) KB counters, gfx950 correction',
+                    dominant_launch_ms=round(ms_dom, 4),
+                    hbm_frac_of_dominant_launch=round(abytes_dom / (ms_dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    pipe=pipe,
                     sustained_clock_GHz=None if clock is None else round(clock, 3),
                     frac_of_peak_at_sustained_clock=None if clock is None else round(achieved / (peak * clock / 2.4), 4),
                     sustained_clock_source=None if clock is None else clock_src + ' (separate PMC pass, not this run)',
                     vendor_gemm_f16_tflops=None if vendor is None else round(vendor, 1),
                     frac_of_vendor_gemm=None if vendor is None else round(achieved / vendor, 4),
                     vendor_gemm_note='torch.matmul f16 8192^3 (hipBLASLt) timed on this GPU right after the timed region',
-                    useful_tflops=round(useful, 2),
-                    useful_frac_of_pipe_peak=round(useful / peak, 4),
-                    useful_note='8 flop (one complex MAC) per antenna pair x pixel x channel x time; the fp32 vector / matrix '
-                                'peak that bounds an exact-f32 contraction is %.1f TFLOP/s' % FP32_PEAK_TFLOPS,
                     algorithmic_tflops=round(algorithmic, 2),
                     launches=n, avg_launch_ms=round(ms / n, 4), elements_per_launch=elems // n,
                     flop_per_element=flop_per_elem,
@@ -720,6 +989,8 @@ def main():
                          'hbm_equiv_frac = 16 B per fringe element of the unfused formulation / 8 TB/s',
                     kernels=per_kernel)
 
+
+    exit_code = 0
     if rank == 0:
         nvis = len(bls) * nt * cfg['Nf']
         mfma_run = bool(kstat) and max(kstat, key=lambda n: kstat[n][1]).startswith('fringe_ant')
@@ -738,6 +1009,8 @@ def main():
                                loss='sum |V|^2 (fused chi-square epilogue, rime_chisq_fwd / _bwd)',
                                parallelism=best['label']),
                    roofline=roof)
+        if selfcheck is not None and not distributed:
+            out['selfcheck'] = selfcheck
         if distributed:
             out['dist'] = dict(world_size=dist.get_world_size(), backend=dist.get_backend(),
                                nccl_version=('.'.join(str(v) for v in torch.cuda.nccl.version())
@@ -748,12 +1021,12 @@ def main():
                                tile_plan_load=best['plan_load'],
                                grad_hook_order=best['hook_order'],     # collective-order indices in firing order (rank 0)
                                grad_order_adapted=best['order_adapted'],   # the ranks agreed on the firing order and use it
+                               collective_timeout_s=collective_timeout,
+                               loss_note='every rank evaluates the loss on the gathered visibilities (%.0f MB per step)'
+                                         % (best['vis_bytes'] / 1e6),
+                               selfcheck=selfcheck,
                                overlap='vis all-gather of chunk k runs under the kernels of chunk k+1; gradient '
                                        'collectives start from autograd hooks inside the last backward')
-            alts = [r for r in results if r is not best]
-            if alts:
-                out['alt'] = [dict(shard=r['shard'], parallelism=r['label'], ms_per_step=r['dt'] / args.steps * 1e3,
-                                   value=nvis * args.steps / r['dt'], tile_plan_load=r['plan_load']) for r in alts]
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(inp)
             out['cpu_baseline'] = cb
@@ -762,8 +1035,17 @@ def main():
                 out['speedup_vs_cpu_prep_amortised'] = out['value'] / cb['value_prep_amortised']
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
+        if selfcheck is not None and not selfcheck['ok']:
+            sys.stderr.write('bench.py: SELF-CHECK FAILED: vis %.3e (tol %.0e), grad %.3e (tol %.0e)\n'
+                             % (selfcheck['vis_relmax'], SELFCHECK_TOL['vis'], selfcheck['grad_relmax'], SELFCHECK_TOL['grad']))
+            exit_code = 5
     if distributed:
-        dist.destroy_process_group()
+        try:
+            dist.barrier()                       # nobody tears its communicator down while rank 0 still checks / reports
+        finally:
+            dist.destroy_process_group()
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == '__main__':

@@ -97,3 +97,131 @@ def test_rank_process_refuses_a_world_size_other_than_gpus():
     env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], env=env, capture_output=True, timeout=300)
     assert r.returncode != 0 and b'WORLD_SIZE=1' in r.stderr and r.stdout.strip() == b''
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1: every rank supervises one fresh worker per shard mode: a mode that crashes, hangs or fails
+# its self-check must not lose the other mode's finished result
+# ---------------------------------------------------------------------------------------------------------------------
+WORKER_STUB = """
+    import argparse, json, os, sys, time
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--shard', action='append')
+    ap.add_argument('--worker', action='store_true')
+    ap.add_argument('--behave', default='')
+    a = ap.parse_args()
+    mode = a.shard[-1]                                   # the supervisor's --shard comes last and wins
+    assert a.worker and os.environ['BENCH_PG_TAG'].startswith(mode)
+    behave = dict(kv.split('=') for kv in a.behave.split(',') if kv)
+    what = behave.get(mode, 'ok')
+    if what == 'crash':
+        sys.exit(7)
+    if what == 'hang':
+        time.sleep(600)
+    ms = dict(freq=10.0, bl=30.0)[mode] if 'blfast' not in behave else dict(freq=30.0, bl=10.0)[mode]
+    if int(os.environ['RANK']) == 0:
+        print('chatter')
+        print(json.dumps(dict(metric='m', value=1000.0 / ms, ms_per_step=ms, n_gpus=int(os.environ['WORLD_SIZE']),
+                              config=dict(parallelism=mode + ' x2'),
+                              dist=dict(shard=mode, tile_plan_load=None, selfcheck=dict(ok=what != 'badcheck', vis_relmax=1e-7)))))
+    if what == 'badcheck':
+        sys.exit(5)
+    """
+
+
+def _supervise(tmp_path, behave, timeout=60):
+    import io
+    stub = _stub(tmp_path, WORKER_STUB)
+    out = io.StringIO()
+    rc = bench.supervise_modes(['freq', 'bl'], [stub, '--shard', 'auto', '--behave', behave], 0, 1, timeout, out=out,
+                               env=dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29999'))
+    lines = out.getvalue().splitlines()
+    assert len(lines) <= 1                                   # never more than ONE result line
+    return rc, (json.loads(lines[0]) if lines else None)
+
+
+def test_supervisor_merges_both_modes(tmp_path):
+    rc, res = _supervise(tmp_path, '')
+    assert rc == 0 and res['dist']['shard'] == 'freq' and res['ms_per_step'] == 10.0
+    assert res['alt'] == [dict(shard='bl', parallelism='bl x2', ms_per_step=30.0, value=1000.0 / 30.0, tile_plan_load=None,
+                               selfcheck=dict(ok=True, vis_relmax=1e-7))]
+    rc, res = _supervise(tmp_path, 'blfast=1')
+    assert rc == 0 and res['dist']['shard'] == 'bl' and res['alt'][0]['shard'] == 'freq'     # the faster mode is the line
+
+
+def test_supervisor_keeps_the_first_result_when_the_second_mode_crashes(tmp_path):
+    rc, res = _supervise(tmp_path, 'bl=crash')
+    assert rc == 0 and res['dist']['shard'] == 'freq' and res['alt'] == [dict(shard='bl', failed=7)]
+
+
+def test_supervisor_keeps_the_first_result_when_the_second_mode_hangs(tmp_path):
+    rc, res = _supervise(tmp_path, 'bl=hang', timeout=8)
+    assert rc == 0 and res['dist']['shard'] == 'freq' and res['alt'] == [dict(shard='bl', failed=124)]
+
+
+def test_supervisor_reports_the_second_mode_when_the_first_fails(tmp_path):
+    rc, res = _supervise(tmp_path, 'freq=crash')
+    assert rc == 0 and res['dist']['shard'] == 'bl' and res['alt'] == [dict(shard='freq', failed=7)]
+
+
+def test_supervisor_treats_a_failed_selfcheck_as_a_failed_mode(tmp_path):
+    rc, res = _supervise(tmp_path, 'bl=badcheck')
+    assert rc == 0 and res['dist']['shard'] == 'freq'
+    assert res['alt'] == [dict(shard='bl', failed=5, selfcheck=dict(ok=False, vis_relmax=1e-7))]
+    rc, res = _supervise(tmp_path, 'freq=badcheck,bl=badcheck')
+    assert rc == 5 and res['failed'] == [dict(shard='freq', failed=5), dict(shard='bl', failed=5)]
+
+
+def test_supervisor_fails_when_every_mode_fails(tmp_path):
+    rc, res = _supervise(tmp_path, 'freq=crash,bl=crash')
+    assert rc == 7 and res is None
+
+
+def test_two_ranks_two_modes_each_mode_its_own_process_group_on_the_launcher_store(tmp_path):
+    """end to end on the CPU: torch.distributed.run starts two rank processes (bench.launch_ranks), each supervises one
+    fresh gloo worker per mode; the workers of a mode rendezvous through bench._init_process_group (a PrefixStore per mode
+    on the launcher's TCPStore) and all-reduce; the second mode's rank-1 worker dies before its collective: rank 0's
+    worker of that mode fails on its watchdog, the first mode's line is relayed with the failure under `alt`"""
+    worker = tmp_path / 'gloo_worker.py'
+    worker.write_text(textwrap.dedent("""
+        import argparse, datetime, json, os, sys
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        import bench
+        ap = argparse.ArgumentParser()
+        ap.add_argument('--shard', action='append')
+        ap.add_argument('--worker', action='store_true')
+        ap.add_argument('--die', default='')
+        a = ap.parse_args()
+        mode, rank, world = a.shard[-1], int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+        assert os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True'
+        bench._init_process_group('gloo', rank, world, None, datetime.timedelta(seconds=60))
+        if mode == a.die and rank == 1:
+            os._exit(9)
+        bench._set_collective_timeout(10)
+        x = torch.tensor([float(rank + 1) * (1 if mode == 'freq' else 10)])
+        dist.all_reduce(x)
+        if rank == 0:
+            print(json.dumps(dict(metric='m', value=float(x), ms_per_step=dict(freq=2.0, bl=1.0)[mode], n_gpus=world,
+                                  config=dict(parallelism=mode), dist=dict(shard=mode, tile_plan_load=None, selfcheck=None))))
+        dist.destroy_process_group()
+        """ % ROOT))
+    rank_script = tmp_path / 'rank.py'
+    rank_script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import bench
+        rc = bench.supervise_modes(['freq', 'bl'], [%r] + sys.argv[1:], int(os.environ['RANK']), int(os.environ['WORLD_SIZE']),
+                                   120, out=sys.stdout)
+        sys.exit(rc)
+        """ % (ROOT, str(worker))))
+    rc, line = bench.launch_ranks(2, [str(rank_script)], timeout=300)
+    assert rc == 0, line
+    res = json.loads(line)
+    assert res['dist']['shard'] == 'bl' and res['value'] == 30.0                 # both modes ran: sums 1 + 2 and 10 + 20
+    assert res['alt'][0]['shard'] == 'freq' and res['alt'][0]['value'] == 3.0
+    rc, line = bench.launch_ranks(2, [str(rank_script), '--die', 'bl'], timeout=300)
+    assert rc == 0, line
+    res = json.loads(line)
+    assert res['dist']['shard'] == 'freq' and res['value'] == 3.0
+    assert res['alt'][0]['shard'] == 'bl' and res['alt'][0]['failed'] != 0
