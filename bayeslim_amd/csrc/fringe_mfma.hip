@@ -731,6 +731,292 @@ fringe_ant_fwd_self_kernel(AntArgs A)
 }
 
 
+// ---------------------------------------------------------------------------------------
+// forward kernel, 33..48 antennas (one diagonal block, real psky): PACKED second row tile  (round 4)
+//
+// 37 antennas (HERA-37, BASELINE configs[2]) in 64 image rows: the second row tile holds 5 real antennas, and the two
+// tiles that touch it -- (0,1) and (1,1) -- cost 12 + 7 of the 26 MFMAs per K step of the generic two-tile shape.  The
+// matrix pipe, not the 48 generated rows, is what a block waits for there (profiles/r03/lab_forward_experiments.txt (j)).
+// With <= 16 antennas in the second row tile its re and im planes fit into ONE 32-row / 32-column operand:
+//     P  = [ Br | Bi ]     (columns 0..15: Br of antennas 32..47, columns 16..31: Bi of the same antennas)
+//     Q  = [ Bi | -Br ]
+//   tile (0,1):  Lr.P + Li.Q = [ Lr.Br + Li.Bi | Lr.Bi - Li.Br ] = [ Vr | Vi ]            6 MFMAs per K step, not 12,
+//                                                                                         ONE accumulator, not three
+//   tile (1,1):  [Lr; Li].P  = [[Lr.Br, Lr.Bi], [Li.Br, Li.Bi]]                            3 MFMAs per K step, not 7;
+//                Vr = D[a][b] + D[16+a][16+b],  Vi = D[a][16+b] - D[16+a][b]: rows a and 16 + a sit in the same lane
+//                (accumulator elements e and e + 8), columns b and 16 + b in lanes 16 apart -- one cross-lane read per
+//                element in the epilogue
+//   tile (0,0):  the symmetric form of the generic kernel, 7 MFMAs.
+// 16 MFMAs per K step instead of 26 (SQ_INSTS_MFMA per launch: Nt Nf (P/16) 16), same three hi/lo split products, same
+// f32 accumulation, fixed order.  The second row tile's image holds three planes of 16 "virtual rows" of ONE plane each
+// (re, im, -re; 80-byte rows: fragment reads and the generation's ds_write_b32 are bank-conflict free); the first row
+// tile keeps the [re | im] rows of the generic kernel.  Deal: each wave takes ONE K step of every panel (w & 1) for one
+// tile group -- waves 0, 1: tile (0,0), 7 MFMAs; waves 2, 3: tiles (0,1) + (1,1), 9 MFMAs -- and the two waves of a pair
+// exchange one partial tile through LDS in the epilogue, so that every wave finishes and stores one unit.
+// Generation: the half-panel mapping of the two-tile blocks (a wave writes ONE 16-pixel half for rows 16 u + (w >> 1) + 2 ag).
+// ---------------------------------------------------------------------------------------
+struct PK {
+    static constexpr int NW = 4;
+    static constexpr int ROWB0 = MF_ROWB;               // antennas 0..31: [32 px re | 32 px im | pad], 144 B
+    static constexpr int IMG0 = 32 * ROWB0;
+    static constexpr int ROWB1 = 2 * MF_KP + 16;        // antennas 32..47: 32 px of ONE plane + pad, 80 B (5 slots of 16 B: odd)
+    static constexpr int IMG1 = 48 * ROWB1;             // virtual rows 0..15 re, 16..31 im, 32..47 -re
+    static constexpr int IMG = IMG0 + IMG1;             // one image (hi or lo)
+    static constexpr int BUF = 2 * IMG + 64;            // hi + lo + sign dwords of the panel
+    static constexpr size_t EPI = 4 * 33 * 32 * 4 + 4 * 16 * 64 * 4;      // 4 transposition tiles + 4 exchange tiles
+    static constexpr size_t LDS = 2 * (size_t)BUF < EPI ? EPI : 2 * (size_t)BUF;
+};
+static_assert(MF_KP == 32, "the packed shape assumes 32-pixel panels (two K steps, one per wave of a pair)");
+
+template <int W, bool SIGNED>
+__device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned char* smem)
+{
+    constexpr int KS = W & 1;                           // this wave's K step of every panel
+    constexpr bool PAIR_B = W >= 2;                     // waves 2, 3: tiles (0,1) + (1,1); waves 0, 1: tile (0,0)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int f = __builtin_amdgcn_readfirstlane(blockIdx.x % A.Nf), ts = blockIdx.x / A.Nf;
+    const int t = __builtin_amdgcn_readfirstlane(ts / A.S), split = __builtin_amdgcn_readfirstlane(ts % A.S);
+
+    const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
+    const float scl = A.scale[t * A.Nf + f];
+    const float* arow = A.psky + (size_t)t * A.st_t + (size_t)f * A.st_f;
+    const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
+    const int st_p = __builtin_amdgcn_readfirstlane((int)A.st_p);
+
+    // generation: lane = (pixel pair pp, antenna slot ag); this wave writes the 16-pixel half `hf` of the panel for the
+    // antennas 16 u + (W >> 1) + 2 ag, u = 0, 1 (first row tile), 2 (second); sweeps whose 8 rows are all padding are skipped
+    const int pp = lane & 7, ag = lane >> 3;
+    constexpr int hf = W & 1;
+    constexpr int NGEN = 3;
+    const int nk = min(NGEN, (A.Nant - (W >> 1) + 15) / 16);      // uniform
+    double ax[NGEN], ay[NGEN], az[NGEN];
+#pragma unroll
+    for (int u = 0; u < NGEN; ++u) {
+        const int an = 16 * u + (W >> 1) + 2 * ag;
+        const bool ok = an < A.Nant;
+        ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
+        ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
+        az[u] = ok ? nu_c * A.antpos[3 * an + 2] : 0.0;
+    }
+
+    f32x16 acc0, acc1, acc2;       // waves 0, 1: R, I (two products); waves 2, 3: tile (0,1), tile (1,1), unused
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; }
+
+    const int npanel = A.Pstride / MF_KP;
+    const int pbeg = __builtin_amdgcn_readfirstlane(split * A.panels_per_split);
+    const int pend = __builtin_amdgcn_readfirstlane(min(npanel, pbeg + A.panels_per_split));
+    if (pbeg >= pend) return;                        // uniform over the block
+
+    // panel fetch through buffer loads (see the generic kernel): descriptor in SGPRs + constant lane offset + scalar offset
+    double2 sx, sy, sz; float2 av;
+    const uint32_t lo_s = 16u * pp, lo_a0 = 8u * pp * (uint32_t)st_p, lo_a1 = lo_a0 + 4u * (uint32_t)st_p;
+    auto uniform_ptr = [](const void* q) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    };
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(sd), 0, __builtin_amdgcn_readfirstlane((int)min((long long)3 * A.Pstride * 8, 0x7fffffffLL)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(arow), 0, __builtin_amdgcn_readfirstlane((int)min((long long)A.Pstride * st_p * 4, 0x7fffffffLL)), 0x00020000);
+    auto fetch = [&](int panel) {
+        const int p0 = panel * MF_KP + 16 * hf;      // uniform
+        sx = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, p0 * 8, 0));
+        sy = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (A.Pstride + p0) * 8, 0));
+        sz = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (2 * A.Pstride + p0) * 8, 0));
+        const int so = p0 * st_p * 4;
+        av = make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a0, so, 0)),
+                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a1, so, 0)));
+    };
+    const int grow = (W >> 1) + 2 * ag;              // row inside a sweep of 16
+    auto generate = [&](unsigned char* buf, int next_panel) {
+        const float w0 = __builtin_amdgcn_sqrtf(fabsf(av.x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av.y) * scl);
+        if (SIGNED && W < 2 && lane < 8)
+            *reinterpret_cast<uint32_t*>(buf + 2 * PK::IMG + 4 * (8 * hf + pp)) =
+                ((__float_as_uint(av.x) >> 16) & 0x8000u) | (__float_as_uint(av.y) & 0x80000000u);
+#pragma unroll
+        for (int u = 0; u < NGEN; ++u) {
+            if (u < nk) {
+                const double ph0 = ax[u] * sx.x + ay[u] * sy.x + az[u] * sz.x;
+                const double ph1 = ax[u] * sx.y + ay[u] * sy.y + az[u] * sz.y;
+                const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
+                const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+                uint32_t rh, rl, ih, il;
+                split2(w0 * c0, w1 * c1, rh, rl);
+                split2(w0 * s0, w1 * s1, ih, il);
+                if (u < 2) {
+                    unsigned char* o = buf + (16 * u + grow) * PK::ROWB0 + pp * 4 + 32 * hf;
+                    *reinterpret_cast<uint32_t*>(o) = rh;
+                    *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+                    *reinterpret_cast<uint32_t*>(o + PK::IMG) = rl;
+                    *reinterpret_cast<uint32_t*>(o + PK::IMG + 2 * MF_KP) = il;
+                } else {
+                    unsigned char* o = buf + PK::IMG0 + grow * PK::ROWB1 + pp * 4 + 32 * hf;
+                    *reinterpret_cast<uint32_t*>(o) = rh;
+                    *reinterpret_cast<uint32_t*>(o + 16 * PK::ROWB1) = ih;
+                    *reinterpret_cast<uint32_t*>(o + 32 * PK::ROWB1) = rh ^ 0x80008000u;
+                    *reinterpret_cast<uint32_t*>(o + PK::IMG) = rl;
+                    *reinterpret_cast<uint32_t*>(o + PK::IMG + 16 * PK::ROWB1) = il;
+                    *reinterpret_cast<uint32_t*>(o + PK::IMG + 32 * PK::ROWB1) = rl ^ 0x80008000u;
+                }
+            }
+        }
+        fetch(next_panel);
+    };
+
+    // fragments of this wave's K step: 8 f16 of row (lane & 31), pixels 16 KS + 8 (lane >> 5) ..
+    const int f0off = (lane & 31) * PK::ROWB0 + (lane >> 5) * 16 + 32 * KS;                      // first row tile, re plane
+    const int f1off = PK::IMG0 + (lane & 31) * PK::ROWB1 + (lane >> 5) * 16 + 32 * KS;           // P: virtual row = lane & 31
+    const int f2off = PK::IMG0 + (16 + (lane & 31)) * PK::ROWB1 + (lane >> 5) * 16 + 32 * KS;    // Q: im rows, then -re rows
+    auto contract = [&](const unsigned char* buf) {
+        auto ld = [&](int off) { return *reinterpret_cast<const uint4*>(buf + off); };
+        uint4 sg = make_uint4(0, 0, 0, 0);
+        if constexpr (SIGNED) sg = *reinterpret_cast<const uint4*>(buf + 2 * PK::IMG + (2 * KS + (lane >> 5)) * 16);
+        auto sgn = [&](uint4 v) {
+            if constexpr (SIGNED) { v.x ^= sg.x; v.y ^= sg.y; v.z ^= sg.z; v.w ^= sg.w; }
+            return v;
+        };
+        if constexpr (!PAIR_B) {
+            // tile (0,0), symmetric form:  Vr = A + A^T, A = (Lrh/2).Brh + (Lih/2).Bih + Lrh.Brl + Lih.Bil;
+            //                              Vi = A - A^T, A = Lrh.Bih + Lrh.Bil - Lih.Brl   (transposes in the epilogue)
+            const uint4 Brh = ld(f0off), Bih = ld(f0off + 2 * MF_KP), Brl = ld(f0off + PK::IMG), Bil = ld(f0off + PK::IMG + 2 * MF_KP);
+            const uint4 Lrh = sgn(Brh), Lih = sgn(Bih);
+            const uint4 Hr = half_frag(Lrh), Hi = half_frag(Lih);
+            acc0 = RIME_MFMA(Hr, Brh, acc0);
+            acc1 = RIME_MFMA(Lrh, Bih, acc1);
+            acc0 = RIME_MFMA(Hi, Bih, acc0);
+            acc2 = RIME_MFMA(Lih, Brl, acc2);
+            acc0 = RIME_MFMA(Lrh, Brl, acc0);
+            acc1 = RIME_MFMA(Lrh, Bil, acc1);
+            acc0 = RIME_MFMA(Lih, Bil, acc0);
+        } else {
+            const uint4 Lrh = sgn(ld(f0off)), Lih = sgn(ld(f0off + 2 * MF_KP));
+            const uint4 Lrl = sgn(ld(f0off + PK::IMG)), Lil = sgn(ld(f0off + PK::IMG + 2 * MF_KP));
+            const uint4 Ph = ld(f1off), Pl = ld(f1off + PK::IMG), Qh = ld(f2off), Ql = ld(f2off + PK::IMG);
+            const uint4 SPh = sgn(Ph), SPl = sgn(Pl);
+            acc0 = RIME_MFMA(Lrh, Ph, acc0);
+            acc1 = RIME_MFMA(SPh, Ph, acc1);
+            acc0 = RIME_MFMA(Lih, Qh, acc0);
+            acc1 = RIME_MFMA(SPh, Pl, acc1);
+            acc0 = RIME_MFMA(Lrh, Pl, acc0);
+            acc1 = RIME_MFMA(SPl, Ph, acc1);
+            acc0 = RIME_MFMA(Lih, Ql, acc0);
+            acc0 = RIME_MFMA(Lrl, Ph, acc0);
+            acc0 = RIME_MFMA(Lil, Qh, acc0);
+        }
+    };
+
+    unsigned char* const buf0 = smem;
+    unsigned char* const buf1 = smem + PK::BUF;
+    fetch(pbeg);
+    generate(buf0, min(pbeg + 1, pend - 1));
+    __syncthreads();
+    for (int panel = pbeg; panel < pend; panel += 2) {
+        if (panel + 1 < pend) generate(buf1, min(panel + 2, pend - 1));
+        contract(buf0);
+        __syncthreads();
+        if (panel + 1 < pend) {
+            if (panel + 2 < pend) generate(buf0, min(panel + 3, pend - 1));
+            contract(buf1);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  The waves of a pair hold the two K steps' partial sums of the same tiles: wave 0 finishes the real part
+    // of tile (0,0), wave 1 its imaginary part, wave 2 tile (0,1), wave 3 tile (1,1); each hands the other unit's partial
+    // tile to its partner through LDS ([e][lane] floats behind the four transposition tiles).
+    float* dst = A.ws + (((size_t)split * A.Nt + t) * A.Nf + f) * 2 * A.Nbl;
+    const float inv = 1.0f / scl;
+    const int col = lane & 31;
+    RIME_MFMA_SETTLE();
+    float* tr = reinterpret_cast<float*>(smem) + W * (32 * 33);
+    float* ex = reinterpret_cast<float*>(smem) + 4 * (32 * 33);
+    f32x16 val;
+    if constexpr (!PAIR_B) {
+        // give: the unit the partner finishes; keep: mine.  W = 0 keeps R (acc0), gives I = acc1 - acc2; W = 1 the reverse
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float r = acc0[e], i = acc1[e] - acc2[e];
+            val[e] = W == 0 ? r : i;
+            ex[(W * 16 + e) * 64 + lane] = W == 0 ? i : r;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            val[e] = W == 2 ? acc0[e] : acc1[e];
+            ex[(W * 16 + e) * 64 + lane] = W == 2 ? acc1[e] : acc0[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) val[e] += ex[((W ^ 1) * 16 + e) * 64 + lane];
+
+    if constexpr (!PAIR_B) {
+        constexpr int im = W;                        // wave 0: real part, wave 1: imaginary part
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tr[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 33 + col] = val[e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float tv = tr[col * 33 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)];
+            val[e] = im ? val[e] - tv : val[e] + tv;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), j = col;
+            const float v = val[e] * inv;
+            const int bd = A.pair_direct[i * MF_NA + j];
+            if (bd >= 0) dst[(size_t)im * A.Nbl + bd] = v;
+            const int bc = A.pair_conj[i * MF_NA + j];
+            if (bc >= 0) dst[(size_t)im * A.Nbl + bc] = im ? -v : v;
+        }
+    } else if constexpr (W == 2) {
+        // tile (0,1): rows = antennas 0..31, columns 0..15: Vr of antenna 32 + col, columns 16..31: Vi of antenna 16 + col
+        const int im = col >> 4, j = 32 + (col & 15);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const float v = val[e] * inv;
+            const int bd = A.pair_direct[i * MF_NA + j];
+            if (bd >= 0) dst[(size_t)im * A.Nbl + bd] = v;
+            const int bc = A.pair_conj[i * MF_NA + j];
+            if (bc >= 0) dst[(size_t)im * A.Nbl + bc] = im ? -v : v;
+        }
+    } else {
+        // tile (1,1): D rows a (elements e < 8) and 16 + a (e + 8) of this lane's column, partner column in lane ^ 16:
+        //   col < 16:  Vr[a][col]      = D[a][col] + D[16 + a][16 + col]
+        //   col >= 16: Vi[a][col - 16] = D[a][col] - D[16 + a][col - 16]
+        const int im = col >> 4, j = 32 + (col & 15);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float other = __shfl_xor(val[e + 8], 16, 64);
+            const float v = (im ? val[e] - other : val[e] + other) * inv;
+            const int i = 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const int bd = A.pair_direct[i * MF_NA + j];
+            if (bd >= 0) dst[(size_t)im * A.Nbl + bd] = v;
+            const int bc = A.pair_conj[i * MF_NA + j];
+            if (bc >= 0) dst[(size_t)im * A.Nbl + bc] = im ? -v : v;
+        }
+    }
+}
+
+template <bool SIGNED>
+__global__ void __launch_bounds__(PK::NW * 64, 2)
+fringe_ant_fwd_packed_kernel(AntArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (row_is_signed(A) != SIGNED) return;              // uniform over the block
+    switch (threadIdx.x >> 6) {                          // wave-uniform: every wave runs the same barriers
+        case 0: ant_fwd_packed_body<0, SIGNED>(A, smem); break;
+        case 1: ant_fwd_packed_body<1, SIGNED>(A, smem); break;
+        case 2: ant_fwd_packed_body<2, SIGNED>(A, smem); break;
+        default: ant_fwd_packed_body<3, SIGNED>(A, smem); break;
+    }
+}
+
+
 #if defined(RIME_BUILD_FWD_V2)
 // ---------------------------------------------------------------------------------------
 // forward kernel, second form (97..128 antennas, one diagonal block): generation hidden under the MFMAs
@@ -1641,6 +1927,14 @@ static bool fwd_v2_enabled()
 }
 #endif
 
+// RIME_FWD_PACKED=0: arrays of 33..48 antennas keep the generic two-tile forward kernel (A/B measurements; ops.py reads
+// the same variable for its count of executed MFMAs)
+static bool fwd_packed_enabled()
+{
+    static const int on = [] { const char* e = getenv("RIME_FWD_PACKED"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
 static bool cross_shape_ok(int rows_i, int rows_j)
 {
     return (rows_i == 32 && rows_j == 32) || (rows_i == 32 && rows_j == 64) || (rows_i == 64 && rows_j == 64) ||
@@ -1718,7 +2012,14 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
     } while (0)
     switch ((Nrows + 31) / 32) {
         case 1: RIME_FWD_PAIR(1); break;
-        case 2: RIME_FWD_PAIR(2); break;
+        case 2:
+            if (Nrows <= 48 && fwd_packed_enabled()) {        // <= 16 antennas in the second row tile: packed planes
+                hipLaunchKernelGGL((fringe_ant_fwd_packed_kernel<true>), grid, dim3(PK::NW * 64), PK::LDS, st, A);
+                if (rowmin) hipLaunchKernelGGL((fringe_ant_fwd_packed_kernel<false>), grid, dim3(PK::NW * 64), PK::LDS, st, A);
+                break;
+            }
+            RIME_FWD_PAIR(2);
+            break;
         case 3: RIME_FWD_PAIR(3); break;
         default:
 #if defined(RIME_BUILD_FWD_V2)

@@ -128,6 +128,9 @@ MFMA_MAX_ANTS = 2048      # table memory only: 136 blocks x 128 KB at 2048 anten
 # complex psky, forward: diagonal blocks whose baselines all have one orientation run as
 # triangular self-cross blocks in ONE pass (RIME_SELF_BLOCKS=0: the two real-plane passes of the diagonal kernel)
 SELF_BLOCKS = os.environ.get('RIME_SELF_BLOCKS', '1') != '0'
+# arrays of 33..48 antennas: the forward kernel with the second row tile's re / im planes packed into one operand
+# (csrc/fringe_mfma.hip, fringe_ant_fwd_packed_kernel); RIME_FWD_PACKED=0 keeps the generic two-tile kernel (A/B)
+FWD_PACKED = os.environ.get('RIME_FWD_PACKED', '1') != '0'
 
 
 def _group_capacity(n, group):
@@ -409,6 +412,8 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
         if blk['ants_j'] is None:
             rows, TA = pi.contiguous(), (pi.shape[0] + 31) // 32
             mf_fwd = 12 * (TA * (TA - 1) // 2) + 7 * TA      # diagonal tiles: symmetric products folded
+            if 32 < pi.shape[0] <= 48 and FWD_PACKED:
+                mf_fwd = 16                                  # packed second row tile (round 4): 7 + 6 + 3 MFMAs per K step
             mf_bwd = 12 * (TA * (TA + 1) // 2)
             mf_bwd_real = 12 * (TA * (TA - 1) // 2) + 9 * TA   # real psky: symmetric form on the diagonal tiles (round 3)
             cross, fwd_cpass = 0, 0                          # forward diagonal blocks: one real plane per call ...

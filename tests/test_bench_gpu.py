@@ -29,7 +29,7 @@ def _run(args, world=2, **env):
 
 
 @pytest.mark.parametrize('args, tiles', [
-    (['--workload', 'c2', '--nt', '4', '--steps', '2', '--warmup', '1'], True),            # HERA-19: one-tile blocks
+    (['--workload', 'c2', '--nt', '4', '--steps', '2', '--warmup', '1'], False),           # HERA-19: ONE block, contiguous baseline shards
     (['--workload', 'c4', '--nf', '8', '--nt', '2', '--steps', '1', '--warmup', '1'], True),  # HERA-128 + point sources: tile plan
 ])
 def test_two_ranks_both_partitions_match_the_unsharded_float64_model(args, tiles):

@@ -169,7 +169,10 @@ def make_antenna_case(seed, Nant, Nt, Nf, P, frac=1.0, autos=0, conj=False):
 
 
 @pytest.mark.parametrize('Nant,frac,autos,force', [(70, 1.0, 3, 'auto'), (128, 0.6, 0, 'auto'),
-                                                    (10, 1.0, 2, True), (33, 0.9, 0, True)])
+                                                    (10, 1.0, 2, True), (33, 0.9, 0, True),
+                                                    # 33..48 antennas: the packed-second-row-tile forward kernel (round 4)
+                                                    (34, 1.0, 0, 'auto'), (37, 1.0, 2, 'auto'), (41, 0.8, 0, 'auto'),
+                                                    (45, 0.7, 45, 'auto'), (48, 1.0, 1, 'auto'), (49, 1.0, 0, 'auto')])
 @pytest.mark.parametrize('conj', [False, True])
 def test_fringe_sum_matrix_core_path(ops, Nant, frac, autos, force, conj):
     """antenna-factored MFMA kernels (float32 1-pol): visibilities and psky gradient against the
@@ -209,6 +212,31 @@ def test_fringe_sum_matrix_core_path(ops, Nant, frac, autos, force, conj):
     # float64 / complex / multi-pol inputs keep using the baseline-formulation kernels
     v64 = ops.fringe_sum(pad_psky(psky, Ps).cuda(), geom)
     assert relmax(v64, ref) < 1e-11
+
+
+@pytest.mark.parametrize('Nant', [33, 37, 40, 44, 48])
+def test_fringe_sum_packed_forward_kernel_non_negative_rows_and_repeat(ops, Nant):
+    """33..48 antennas (fringe_ant_fwd_packed_kernel): a non-negative psky (rows of the mask-free instantiation) mixed with
+    signed rows, several pixel splits with an odd number of panels, against the float64 oracle and the float64
+    vector-ALU kernels; bitwise identical when repeated"""
+    ant, pairs, blvecs, freqs, zenaz, psky = make_antenna_case(1000 + Nant, Nant, Nt=2, Nf=7, P=17000 + 32 * Nant, frac=1.0)
+    psky = psky.abs()
+    psky[1, :, :, 2] *= -1.0                                  # one all-negative row
+    psky[0, :, :, 4, ::3] *= -1.0                             # one mixed row
+    Nt, _, P = zenaz.shape
+    Ps = ops.pad_to_tile(P)
+    sdir = torch.zeros(Nt, 3, Ps, dtype=torch.float64)
+    for t in range(Nt):
+        sdir[t, :, :P] = orc.pointing_vectors(zenaz[t, 0], zenaz[t, 1])
+    geom = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, antpos=ant.cuda(), bl_ants=pairs, mfma='auto')
+    assert geom.ant is not None and len(geom.ant['blocks']) == 1
+    x = pad_psky(psky, Ps).float().cuda()
+    vis = ops.fringe_sum(x, geom)
+    v64 = ops.fringe_sum(pad_psky(psky, Ps).cuda(), ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs))
+    assert relmax(vis, v64.cpu().numpy()) < 1e-5
+    ref = oracle_fringe_sum(psky[:, :, :, :2], blvecs[:60], zenaz, freqs[:2], [0] * 60)
+    assert relmax(vis[:, :60, :, :2], ref) < 1e-5
+    assert torch.equal(vis, ops.fringe_sum(x, geom))
 
 
 @pytest.mark.parametrize('Npp,cplx', [(2, False), (1, True), (4, True)])
