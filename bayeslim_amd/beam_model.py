@@ -217,7 +217,8 @@ class PixelBeam(utils.Module):
             return beam1[:, :1] * sky[0:1, 0:1]                       # (2, 1, Nmp, Nf, P)
         assert tuple(sky.shape[:2]) == (2, 2)
         if (sky.is_complex() and sky.is_cuda and FUSED_JONES and sky.shape[2] in (1, beam1.shape[2])
-                and beam1.dtype in (sky.dtype, sky.real.dtype)):
+                and tuple(sky.shape[-2:]) == tuple(beam1.shape[-2:])          # a sky that broadcasts over Nf / P: torch path
+                and beam1.dtype in (sky.dtype, sky.real.dtype) and beam2.dtype == beam1.dtype):
             # J_p S J_q^dagger in one pass (csrc/jones.hip) instead of two broadcast products with 8x temporaries
             return ops.jones_apply(beam1, beam1 if (beam2 is beam1) else beam2, sky)
         dt = torch.promote_types(beam1.dtype, sky.dtype)

@@ -38,7 +38,7 @@ constexpr int MF_NA = 128;                   // antennas per block (4 x 4 tiles)
 #define RIME_OCTX_NW4 1         /* 0: the 4-wave complex-psky blocks keep the two-half generation mapping (lab) */
 #endif
 #ifndef RIME_MF_SPLIT_PIX
-#define RIME_MF_SPLIT_PIX 8192
+#define RIME_MF_SPLIT_PIX 16384
 #endif
 constexpr int MF_SPLIT_PIX = RIME_MF_SPLIT_PIX;           // pixels per block (bounds the f32 MFMA accumulation chain)
 
@@ -134,7 +134,9 @@ __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_
 //     generate): 40 spilled registers at 2 waves per SIMD, and with 1 wave per SIMD (accumulators in
 //     AGPRs, no spills) LDS latency and barriers are exposed: 13.0-13.5 ms against 10.7.
 // Every block covers at most MF_SPLIT_PIX pixels and STORES its result (no read-modify-write):
-// f32 accumulation inside the MFMA chain stays below eps*sqrt(512), and the pixel splits are
+// f32 accumulation inside the MFMA chain stays below eps*sqrt(1024) (round 4: 16 384 pixels per block instead of 8192 --
+// half the slab traffic, C4 forward - 1 %, measured error against float64 2.3e-6 -> 2.8e-6 of the maximum, identical for
+// 24 576: profiles/r04/split_size.txt), and the pixel splits are
 // summed (and transposed into the result layout) by reduce_vis_kernel in a fixed order.
 // History (C4 shape, 128 antennas, 256 channels x 2 times, 98304 px): interleaved (re,im) K layout
 // with separate L/B images, rot90 on the fly and whole-tile deal: 13.4 ms; this kernel: 10.7 ms
@@ -289,12 +291,21 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
 #endif
     constexpr int SWX = SH::NW * 4;                    // rows of an OCTX sweep: 32 (8 waves) or 16 (4 waves)
     constexpr int NGEN = OCT8 ? SH::ROWS / 32 : OCT ? SH::ROWS / 16 : (OCTX ? 2 : 1) * (SH::SELF ? SH::GEN_I : SH::GEN);
-    const int nk = (OCT && !OCT8) ? min(NGEN, (A.Nant - (W >> 1) + 15) / 16) : NGEN;     // uniform
+    // (round 4) the rows of a sweep are one OCTET per wave pair -- rows 16 u + 8 (W >> 1) + 2 (ag & 3) + (ag >> 2), conflict-free
+    // ds_write_b32 as before -- instead of the rows of one parity: the sweeps a wave skips are then whole octets of padding,
+    // 19 antennas cost 2 + 1 sweeps per wave pair instead of 2 + 2, 37 antennas 3 + 2 instead of 3 + 3 (same bits)
+#if defined(RIME_LAB_PARITY_ROWS)      /* lab: the mapping of rounds 1-3 (rows of one parity per wave pair) */
+    const int orow = (W >> 1) + 2 * ag;
+    const int nk = (OCT && !OCT8) ? min(NGEN, (A.Nant - (W >> 1) + 15) / 16) : NGEN;
+#else
+    const int orow = 8 * (W >> 1) + 2 * (ag & 3) + (ag >> 2);
+    const int nk = (OCT && !OCT8) ? min(NGEN, (A.Nant - 8 * (W >> 1) + 15) / 16) : NGEN;     // uniform
+#endif
     const int growx = SH::NW == 8 ? 2 * ag + 16 * ((W >> 1) & 1) + (W >> 2) : 2 * ag + (W >> 1);
     double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
     for (int u = 0; u < NGEN; ++u) {
-        const int an = OCT8 ? 32 * u + growx : OCT ? 16 * u + (W >> 1) + 2 * ag : (OCTX ? SWX * u + growx : SH::GROWS * u + grow);
+        const int an = OCT8 ? 32 * u + growx : OCT ? 16 * u + orow : (OCTX ? SWX * u + growx : SH::GROWS * u + grow);
         const bool ok = an < A.Nant;
         ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
         ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
@@ -378,7 +389,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                     uint32_t rh, rl, ih, il;
                     split2(w0 * c0, w1 * c1, rh, rl);
                     split2(w0 * s0, w1 * s1, ih, il);
-                    unsigned char* o = buf + (OCT8 ? 32 * u + growx : 16 * u + (W >> 1) + 2 * ag) * MF_ROWB + pp * 4 + 32 * hf;
+                    unsigned char* o = buf + (OCT8 ? 32 * u + growx : 16 * u + orow) * MF_ROWB + pp * 4 + 32 * hf;
                     *reinterpret_cast<uint32_t*>(o) = rh;
                     *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
                     *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
@@ -753,7 +764,7 @@ fringe_ant_fwd_self_kernel(AntArgs A)
 // tile keeps the [re | im] rows of the generic kernel.  Deal: each wave takes ONE K step of every panel (w & 1) for one
 // tile group -- waves 0, 1: tile (0,0), 7 MFMAs; waves 2, 3: tiles (0,1) + (1,1), 9 MFMAs -- and the two waves of a pair
 // exchange one partial tile through LDS in the epilogue, so that every wave finishes and stores one unit.
-// Generation: the half-panel mapping of the two-tile blocks (a wave writes ONE 16-pixel half for rows 16 u + (w >> 1) + 2 ag).
+// Generation: the half-panel mapping of the two-tile blocks (a wave writes ONE 16-pixel half for one octet of rows per sweep).
 // ---------------------------------------------------------------------------------------
 struct PK {
     static constexpr int NW = 4;
@@ -784,15 +795,22 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
     const int st_p = __builtin_amdgcn_readfirstlane((int)A.st_p);
 
     // generation: lane = (pixel pair pp, antenna slot ag); this wave writes the 16-pixel half `hf` of the panel for the
-    // antennas 16 u + (W >> 1) + 2 ag, u = 0, 1 (first row tile), 2 (second); sweeps whose 8 rows are all padding are skipped
+    // antennas 16 u + 8 (W >> 1) + 2 (ag & 3) + (ag >> 2), u = 0, 1 (first row tile), 2 (second); sweeps whose octet is all
+    // padding are skipped (the waves with fewer sweeps are the ones with more MFMAs)
     const int pp = lane & 7, ag = lane >> 3;
     constexpr int hf = W & 1;
     constexpr int NGEN = 3;
-    const int nk = min(NGEN, (A.Nant - (W >> 1) + 15) / 16);      // uniform
+#if defined(RIME_LAB_PARITY_ROWS)      /* lab */
+    const int grow = (W >> 1) + 2 * ag;
+    const int nk = min(NGEN, (A.Nant - (W >> 1) + 15) / 16);
+#else
+    const int grow = 8 * (W >> 1) + 2 * (ag & 3) + (ag >> 2);     // row inside a sweep of 16: one octet per wave pair
+    const int nk = min(NGEN, (A.Nant - 8 * (W >> 1) + 15) / 16);  // uniform: 37 antennas -> 3 sweeps (waves 0, 1), 2 (waves 2, 3)
+#endif
     double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
     for (int u = 0; u < NGEN; ++u) {
-        const int an = 16 * u + (W >> 1) + 2 * ag;
+        const int an = 16 * u + grow;
         const bool ok = an < A.Nant;
         ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
         ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
@@ -829,7 +847,6 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
         av = make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a0, so, 0)),
                          __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a1, so, 0)));
     };
-    const int grow = (W >> 1) + 2 * ag;              // row inside a sweep of 16
     auto generate = [&](unsigned char* buf, int next_panel) {
         const float w0 = __builtin_amdgcn_sqrtf(fabsf(av.x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av.y) * scl);
         if (SIGNED && W < 2 && lane < 8)

@@ -654,6 +654,7 @@ class _JonesApply(torch.autograd.Function):
         j2 = j1 if same else J2.detach().contiguous()
         sk = S.detach().contiguous()
         assert sk.is_complex() and tuple(j1.shape[:2]) == (2, 2) and tuple(sk.shape[:2]) == (2, 2) and j1.shape == j2.shape
+        assert j2.dtype == j1.dtype, 'both Jones operands must have one dtype (%s vs %s)' % (j1.dtype, j2.dtype)
         code, rdt = _real_dtype(sk)
         bc = j1.is_complex()
         assert (j1.dtype == sk.dtype) if bc else (j1.dtype == rdt), 'beam %s vs sky %s' % (j1.dtype, sk.dtype)
@@ -709,8 +710,12 @@ class InterpStencil:
         self.inds = inds.to(torch.int32).contiguous()
         self.wgts = wgts.contiguous()
         flat = self.inds.reshape(-1).to(torch.int64)
-        order = torch.sort(flat, stable=True).indices
-        counts = torch.bincount(flat, minlength=self.Npb)
+        # entries of weight 0 (the padding slots of a one-node FoV-cut stencil all point at the last pixel; samples on a
+        # grid node) stay out of the inverse index: the gather skips them too (w != 0), so 0 * inf / NaN of a padded
+        # gradient slot cannot reach the map gradient, and no node collects thousands of dead entries for one wave to walk
+        keep = torch.nonzero(self.wgts.reshape(-1) != 0).reshape(-1)
+        order = keep[torch.sort(flat[keep], stable=True).indices]
+        counts = torch.bincount(flat[keep], minlength=self.Npb)
         ptr = torch.zeros(self.Npb + 1, dtype=torch.int64, device=inds.device)
         ptr[1:] = torch.cumsum(counts, 0)
         self.csr_ptr = ptr.to(torch.int32).contiguous()
