@@ -774,7 +774,7 @@ struct PK {
     static constexpr int IMG1 = 48 * ROWB1;             // virtual rows 0..15 re, 16..31 im, 32..47 -re
     static constexpr int IMG = IMG0 + IMG1;             // one image (hi or lo)
     static constexpr int BUF = 2 * IMG + 64;            // hi + lo + sign dwords of the panel
-    static constexpr size_t EPI = 4 * 33 * 32 * 4 + 4 * 16 * 64 * 4;      // 4 transposition tiles + 4 exchange tiles
+    static constexpr size_t EPI = 4 * 33 * 32 * 4 + 5 * 16 * 64 * 4;      // 4 transposition tiles + 5 exchange tiles
     static constexpr size_t LDS = 2 * (size_t)BUF < EPI ? EPI : 2 * (size_t)BUF;
 };
 static_assert(MF_KP == 32, "the packed shape assumes 32-pixel panels (two K steps, one per wave of a pair)");
@@ -817,9 +817,9 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
         az[u] = ok ? nu_c * A.antpos[3 * an + 2] : 0.0;
     }
 
-    f32x16 acc0, acc1, acc2;       // waves 0, 1: R, I (two products); waves 2, 3: tile (0,1), tile (1,1), unused
+    f32x16 acc0, acc1, acc2, acc3; // waves 0, 1: R (hi x lo), I (two products), R (hi x hi); waves 2, 3: tile (0,1), tile (1,1)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; }
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
 
     const int npanel = A.Pstride / MF_KP;
     const int pbeg = __builtin_amdgcn_readfirstlane(split * A.panels_per_split);
@@ -855,11 +855,27 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
 #pragma unroll
         for (int u = 0; u < NGEN; ++u) {
             if (u < nk) {
+#if defined(RIME_LAB_FWD_CHEAP)    /* lab, TIMING ONLY: 3 of 4 channels pay 4 plain instructions per phasor (a stand-in for E *= D) */
+                float s0, c0, s1, c1;
+                if ((f & 3) != 0) {
+                    const float q = (float)sx.x, r_ = (float)sy.y;
+                    const float a_ = fmaf(q, 0.37f + u, r_), b_ = fmaf(r_, 0.11f, q);
+                    c0 = fmaf(a_, b_, q); s0 = fmaf(b_, q, a_); c1 = fmaf(a_, q, b_); s1 = fmaf(b_, r_, a_);
+                    c0 = fmaf(c0, s1, a_); s0 = fmaf(s0, c1, b_); c1 = fmaf(c1, s0, a_); s1 = fmaf(s1, c0, b_);
+                } else {
+                    const double ph0 = ax[u] * sx.x + ay[u] * sy.x + az[u] * sz.x;
+                    const double ph1 = ax[u] * sx.y + ay[u] * sy.y + az[u] * sz.y;
+                    const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                    s0 = __builtin_amdgcn_sinf(r0); c0 = __builtin_amdgcn_cosf(r0);
+                    s1 = __builtin_amdgcn_sinf(r1); c1 = __builtin_amdgcn_cosf(r1);
+                }
+#else
                 const double ph0 = ax[u] * sx.x + ay[u] * sy.x + az[u] * sz.x;
                 const double ph1 = ax[u] * sx.y + ay[u] * sy.y + az[u] * sz.y;
                 const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
                 const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                 const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+#endif
                 uint32_t rh, rl, ih, il;
                 split2(w0 * c0, w1 * c1, rh, rl);
                 split2(w0 * s0, w1 * s1, ih, il);
@@ -898,12 +914,21 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
         if constexpr (!PAIR_B) {
             // tile (0,0), symmetric form:  Vr = A + A^T, A = (Lrh/2).Brh + (Lih/2).Bih + Lrh.Brl + Lih.Bil;
             //                              Vi = A - A^T, A = Lrh.Bih + Lrh.Bil - Lih.Brl   (transposes in the epilogue)
+            // (the hi x hi products Lrh.Brh + Lih.Bih are symmetric by themselves: they go to an accumulator of their own,
+            //  acc3, added once in the epilogue -- Vr = acc3 + acc0 + acc0^T -- instead of halving the L fragments in every K
+            //  step: 8 v_pk_mul_f16 per K step less on the waves that also carry the extra generation sweep)
             const uint4 Brh = ld(f0off), Bih = ld(f0off + 2 * MF_KP), Brl = ld(f0off + PK::IMG), Bil = ld(f0off + PK::IMG + 2 * MF_KP);
             const uint4 Lrh = sgn(Brh), Lih = sgn(Bih);
+#if defined(RIME_LAB_PK_HALF)      /* lab: the halved fragments of the generic kernel (acc3 stays zero) */
             const uint4 Hr = half_frag(Lrh), Hi = half_frag(Lih);
             acc0 = RIME_MFMA(Hr, Brh, acc0);
             acc1 = RIME_MFMA(Lrh, Bih, acc1);
             acc0 = RIME_MFMA(Hi, Bih, acc0);
+#else
+            acc3 = RIME_MFMA(Lrh, Brh, acc3);
+            acc1 = RIME_MFMA(Lrh, Bih, acc1);
+            acc3 = RIME_MFMA(Lih, Bih, acc3);
+#endif
             acc2 = RIME_MFMA(Lih, Brl, acc2);
             acc0 = RIME_MFMA(Lrh, Brl, acc0);
             acc1 = RIME_MFMA(Lrh, Bil, acc1);
@@ -950,14 +975,18 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
     RIME_MFMA_SETTLE();
     float* tr = reinterpret_cast<float*>(smem) + W * (32 * 33);
     float* ex = reinterpret_cast<float*>(smem) + 4 * (32 * 33);
-    f32x16 val;
+    f32x16 val, sym;                                 // sym: the part of the real unit that is symmetric as it stands
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sym[e] = 0.f;
     if constexpr (!PAIR_B) {
-        // give: the unit the partner finishes; keep: mine.  W = 0 keeps R (acc0), gives I = acc1 - acc2; W = 1 the reverse
+        // give: the unit the partner finishes; keep: mine.  W = 0 keeps R (acc0, acc3), gives I = acc1 - acc2; W = 1 the
+        // reverse (its two R parts go through its own exchange tile and a fifth one)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float r = acc0[e], i = acc1[e] - acc2[e];
             val[e] = W == 0 ? r : i;
-            ex[(W * 16 + e) * 64 + lane] = W == 0 ? i : r;
+            if constexpr (W == 0) { sym[e] = acc3[e]; ex[(0 * 16 + e) * 64 + lane] = i; }
+            else { ex[(1 * 16 + e) * 64 + lane] = r; ex[(4 * 16 + e) * 64 + lane] = acc3[e]; }
         }
     } else {
 #pragma unroll
@@ -969,6 +998,10 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 16; ++e) val[e] += ex[((W ^ 1) * 16 + e) * 64 + lane];
+    if constexpr (W == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sym[e] += ex[(4 * 16 + e) * 64 + lane];
+    }
 
     if constexpr (!PAIR_B) {
         constexpr int im = W;                        // wave 0: real part, wave 1: imaginary part
@@ -978,7 +1011,7 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float tv = tr[col * 33 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)];
-            val[e] = im ? val[e] - tv : val[e] + tv;
+            val[e] = im ? val[e] - tv : (val[e] + tv) + sym[e];
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -1552,6 +1585,19 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                             for (int u = 0; u < 4; ++u) { ec[8 * ks + 4 * jq + u] = 0.f; es[8 * ks + 4 * jq + u] = 0.f; }
                             continue;
                         }
+#if defined(RIME_LAB_BWD_CHEAP)   /* lab, TIMING ONLY: 3 of 4 channels pay 4 plain instructions per phasor (a stand-in for E *= D) */
+                        if ((f & 3) != 0) {
+                            const float q = (float)sx, r_ = (float)sy;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int jj = 4 * jq + u;
+                                const float a_ = fmaf(q, 0.37f + jj, r_), b_ = fmaf(r_, 0.11f + ks, q);
+                                ec[8 * ks + jj] = fmaf(a_, b_, q);
+                                es[8 * ks + jj] = fmaf(b_, q, a_);
+                            }
+                            continue;
+                        }
+#endif
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int jj = 4 * jq + u;

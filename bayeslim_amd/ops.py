@@ -975,6 +975,14 @@ def _ylm_packed(Ylm, Y, ys, direction):
     tensor (AlmModel.setup_Ylm replaces it) or an in-place update packs again.  Returns None when packing is switched
     off, the matrix is small, or the GPU has no room for another copy (the unpacked kernels then run).
     `Ylm` is the caller's tensor object (the cache lives on it), `Y` its contiguous detached alias.
+
+    MEMORY: each direction keeps a buffer of Ylm's own size on the device (8 bytes per (coefficient, pixel)): a model that
+    runs forward AND backward holds THREE times the matrix (C3: 3.3 GB -> 9.9 GB) until the Ylm tensor is released or
+    `release_ylm_packed(Ylm)` is called; RIME_ALM_PACKED=0 switches the copies off (kernels that split on the fly, ~25 %
+    slower at the C3 shape).  A copy is only made while the device has that much free memory + 1 GB, counting the blocks the
+    caching allocator holds but does not use; a refusal is re-examined on later calls (not remembered for the life of the
+    tensor).  The pack kernel runs on the stream that is current at first use; an event recorded behind it is kept with
+    the buffer and every later use on ANOTHER stream waits for it first.
     """
     if not ALM_PACKED or Y.dtype != torch.complex64 or ys <= 0 or Y.numel() * 8 < ALM_PACKED_MIN_BYTES:
         return None
@@ -985,18 +993,35 @@ def _ylm_packed(Ylm, Y, ys, direction):
             Ylm._rime_packed = tag
         except Exception:
             return None
-    buf = tag[3].get(direction)
-    if buf is None:
+    entry = tag[3].get(direction)
+    stream = torch.cuda.current_stream(Y.device)
+    if entry is None or entry is False:
         Nc, Npix = Y.shape
         nbytes = int(lib.rime_alm2pix_packed_bytes(Nc, Npix, direction))
         free, _ = torch.cuda.mem_get_info(Y.device)
+        # blocks the caching allocator has reserved but not handed out are usable too
+        free += torch.cuda.memory_reserved(Y.device) - torch.cuda.memory_allocated(Y.device)
         if nbytes == 0 or free < nbytes + (1 << 30):
-            tag[3][direction] = False                    # remembered: do not ask the allocator on every call
+            tag[3][direction] = False                    # no room NOW: asked again on the next call (two cheap queries)
             return None
         buf = torch.empty(nbytes, dtype=torch.uint8, device=Y.device)
         check(lib.rime_alm2pix_pack(_ptr(torch.view_as_real(Y)), ys, Nc, Npix, direction, _ptr(buf), _stream()), 'rime_alm2pix_pack')
-        tag[3][direction] = buf
-    return buf if buf is not False else None
+        ready = torch.cuda.Event()
+        ready.record(stream)
+        entry = tag[3][direction] = (buf, ready, stream.cuda_stream)
+    buf, ready, made_on = entry
+    if made_on != stream.cuda_stream:
+        stream.wait_event(ready)                         # packed on another stream: order this use behind the pack kernel
+    return buf
+
+
+def release_ylm_packed(Ylm):
+    """drop the cached packed copies of `Ylm` (two buffers of its size; see _ylm_packed); they are rebuilt on the next use"""
+    if getattr(Ylm, '_rime_packed', None) is not None:
+        try:
+            del Ylm._rime_packed
+        except Exception:
+            Ylm._rime_packed = None
 
 
 class _Alm2Pix(torch.autograd.Function):
@@ -1025,7 +1050,10 @@ class _Alm2Pix(torch.autograd.Function):
             rc = lib.rime_alm2pix_fwd(code, _ptr(torch.view_as_real(a)), _ptr(torch.view_as_real(Y)), ys,
                                       R, Nc, Npix, _ptr(out), _ptr(ws), ws.numel(), _stream())
             check(rc, 'rime_alm2pix_fwd')
-        ctx.Y, ctx.shape, ctx.dtype, ctx.ys, ctx.Ylm = Y, tuple(alm.shape), alm.dtype, ys, Ylm
+        # the packed-copy cache lives on the CALLER's tensor object: a weak reference finds it again in the backward without
+        # keeping that object (and its two packed buffers) alive through the graph
+        import weakref
+        ctx.Y, ctx.shape, ctx.dtype, ctx.ys, ctx.Ylm = Y, tuple(alm.shape), alm.dtype, ys, weakref.ref(Ylm)
         return out
 
     @staticmethod
@@ -1038,7 +1066,8 @@ class _Alm2Pix(torch.autograd.Function):
         R = int(np.prod(ctx.shape[:-1])) if len(ctx.shape) > 1 else 1
         nbytes = lib.rime_alm2pix_bwd_workspace(code, R, Nc, Npix)
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=g.device)
-        packed = _ylm_packed(ctx.Ylm, Y, ctx.ys, 1) if ctx.ys > 0 else None
+        owner = ctx.Ylm()
+        packed = _ylm_packed(owner, Y, ctx.ys, 1) if (ctx.ys > 0 and owner is not None) else None
         if packed is not None:
             rc = lib.rime_alm2pix_bwd_packed(_ptr(g), _ptr(packed), ctx.ys, R, Nc, Npix,
                                              _ptr(torch.view_as_real(ga)), _ptr(ws), ws.numel(), _stream())

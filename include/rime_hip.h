@@ -292,7 +292,9 @@ int rime_alm2pix_bwd(int dtype, const void* gout, const void* Ylm, double y_scal
  * direction (0 = forward: contraction over coefficients; 1 = backward: contraction over pixels).  The transforms on a
  * packed copy do no arithmetic on the streamed operand and read it as fully coalesced 1-KB fragments; the products are
  * those of rime_alm2pix_fwd / _bwd with y_scale > 0 (same split, same MFMAs): the forward is bitwise equal (same summation
- * order over K), the backward differs in the order of its float32 partial sums over pixels (~1e-6).  The caller owns the packed buffer (rime_alm2pix_packed_bytes) and must pack
+ * order over K) as long as it runs WITHOUT a K split -- maps that offer fewer 4-wave blocks than 1.5 resident grids (the C3
+ * shape: 2 splits) sum two partial planes in a second kernel, another order of the float32 sums (~2e-6 of the maximum) --, the backward
+ * differs in the order of its float32 partial sums over pixels (~1e-6).  The caller owns the packed buffer (rime_alm2pix_packed_bytes) and must pack
  * again when Ylm or y_scale changes.  Workspaces: rime_alm2pix_fwd_workspace / rime_alm2pix_bwd_workspace bytes.
  * Same reference lines as above (sph_harm.py:1342-1372); the reference recomputes the einsum on the complex matrix. */
 size_t rime_alm2pix_packed_bytes(int Ncoeff, int Npix, int direction);

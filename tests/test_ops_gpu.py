@@ -1040,7 +1040,8 @@ def test_alm2pix_mfma_shapes(ops, R, lmax, Npix):
 @pytest.mark.parametrize('R,lmax,Npix', [(128, 24, 3000), (40, 12, 1111), (3, 40, 5000), (70, 31, 2048), (128, 15, 12289)])
 def test_alm2pix_packed_ylm_equals_unpacked(ops, R, lmax, Npix, monkeypatch):
     """the cached pre-split copies of Ylm in fragment order (rime_alm2pix_pack / _fwd_packed / _bwd_packed): same
-    split and the same products as the kernels that split Ylm on the fly -- forward bitwise equal (same summation order),
+    split and the same products as the kernels that split Ylm on the fly -- forward bitwise equal (same summation order;
+    these shapes run without a K split, the split forward is compared in test_alm2pix_packed_forward_with_a_k_split),
     backward to 2e-6 (another deal of the pixel chunks) -- and both against the float64 oracle; row tiles 4 / 2 / 1, ragged coefficient and pixel tails, one-block and many-block grids"""
     rng = np.random.default_rng(R + Npix)
     l, m = orc.gen_lm(lmax)
@@ -1069,6 +1070,27 @@ def test_alm2pix_packed_ylm_equals_unpacked(ops, R, lmax, Npix, monkeypatch):
     # per chunk; odd pixel counts: the unpacked path is another kernel altogether): same products, another order of the
     # float32 partial sums
     assert relmax(res[True][1], res[False][1]) < 2e-6
+
+
+def test_alm2pix_packed_forward_with_a_k_split(ops, monkeypatch):
+    """the packed forward splits K over blockIdx.z when the map offers too few blocks (2 splits at the C3 shape) and sums
+    the partial planes in a second kernel: another order of the float32 sums than the unsplit kernel -- equal to 5e-6, not
+    bitwise; forced here with a pixel count small enough for the planner to split"""
+    rng = np.random.default_rng(77)
+    l, m = orc.gen_lm(60)
+    Npix, R = 4096, 64
+    th, ph = np.arccos(rng.uniform(-1, 1, Npix)), rng.uniform(0, 2 * np.pi, Npix)
+    Y = torch.as_tensor(orc.sph_Ylm(th, ph, l, m))
+    a = torch.as_tensor(rng.normal(size=(R, len(l))) + 1j * rng.normal(size=(R, len(l))))
+    ref = orc.forward_alm(a, Y)
+    Yd = Y.to(torch.complex64).cuda()
+    res = {}
+    for packed in (False, True):
+        monkeypatch.setattr(ops, 'ALM_PACKED', packed)
+        monkeypatch.setattr(ops, 'ALM_PACKED_MIN_BYTES', 0)
+        res[packed] = ops.alm2pix(a.to(torch.complex64).cuda(), Yd).detach()
+        assert relmax(res[packed], ref) < 1e-5
+    assert relmax(res[True], res[False].cpu().numpy()) < 5e-6        # measured 1.6e-6: not bitwise
 
 
 def test_alm2pix_packed_ylm_is_repacked_when_ylm_changes(ops, monkeypatch):
@@ -1100,6 +1122,23 @@ def test_alm2pix_packed_ylm_is_repacked_when_ylm_changes(ops, monkeypatch):
     o1 = A(a)
     A.setup_Ylm(np.rad2deg(th), np.rad2deg(ph), Ylm=(Y2 * 3.0).contiguous(), alm_mult=None)
     assert relmax(A(a), 3.0 * o1) < 1e-6
+    # explicit release (two buffers of Ylm's size per matrix) and use from another stream: the pack kernel's event orders it
+    ops.release_ylm_packed(Y2)
+    assert getattr(Y2, '_rime_packed', None) is None
+    side = torch.cuda.Stream()
+    y4 = ops.alm2pix(a, Y2)                                                       # packs on the current stream
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        y5 = ops.alm2pix(a, Y2)                                                   # cached copy, other stream: waits for the event
+    side.synchronize()
+    assert torch.equal(y4, y5) and relmax(y4, 0.5 * y1) < 1e-6
+    # a backward pass after the caller dropped its Ylm object falls back to the kernels that split on the fly
+    x = a.clone().requires_grad_(True)
+    Y3 = (Y2 * 1.0).contiguous()
+    out = ops.alm2pix(x, Y3)
+    del Y3
+    out.sum().backward()
+    assert torch.isfinite(torch.view_as_real(x.grad)).all()
 
 
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
