@@ -1448,7 +1448,11 @@ __device__ __forceinline__ int tri_index(int ti, int tj) { return ti * 4 - ti * 
 // CPLX: psky is complex (interleaved).  With Z = sum_ij conj(F_ij) g_ij = conj(sum_i conj(E_i) T_i) the two
 // gradient planes are Re Z and Im Z: the same T, a second lane-local contraction (Ei Tr - Er Ti) -- the
 // imaginary plane costs 32 FMAs per pixel tile and wave instead of a second pass.
-template <bool CPLX>
+// TAMAX: row / column tiles the instantiation is compiled for (round 4).  4: any array of up to 128 antennas.  2: arrays of up to 64
+// antennas (HERA-19, HERA-37, the tile shards of a rank) -- four accumulators instead of eight: half the zero-fill moves per
+// pixel tile (a quarter of the kernel's VALU instructions at 37 antennas) and 60 registers less; the tile loops of the
+// general instantiation only DROP the iterations of absent tiles, they still pay for their registers.
+template <bool CPLX, int TAMAX>
 __global__ void __launch_bounds__(512, 2)
 fringe_ant_bwd_kernel(AntBwdArgs A)
 {
@@ -1536,15 +1540,15 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
     for (int pt = tbeg + wave; pt < tend; pt += 8) {
         const int p = pt * 32 + (lane & 31);
         const double sx = sd[p], sy = sd[A.Pstride + p], sz = sd[2 * (size_t)A.Pstride + p];
-        f32x16 accR[4], accI[4];
+        f32x16 accR[TAMAX], accI[TAMAX];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < TAMAX; ++q)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { accR[q][e] = 0.f; accI[q][e] = 0.f; }
         float part = 0.f, parti = 0.f;
 #pragma unroll
-        for (int tjr = 0; tjr < 4; ++tjr) {
-            const int tj = 3 - tjr;                          // descending: row tile tj completes here
+        for (int tjr = 0; tjr < TAMAX; ++tjr) {
+            const int tj = TAMAX - 1 - tjr;                  // descending: row tile tj completes here
             if (tj < TA) {
                 float ec[16], es[16];                        // E of antennas 32 tj + (e&3) + 8 (e>>2) + 4 h
 #pragma unroll
@@ -1615,7 +1619,7 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                         split2_plain(es[8 * ks + 2 * q], es[8 * ks + 2 * q + 1], eih[q], eil[q]);
                     }
 #pragma unroll
-                    for (int ti = 0; ti < 4; ++ti) {
+                    for (int ti = 0; ti < TAMAX; ++ti) {
                         if (ti <= tj) {
                             // two lane bases + 16-bit immediates reach all six planes (left alone, the compiler
                             // keeps 19 per-tile bases and adds the plane offsets: 62 v_add per pixel tile)
@@ -1998,6 +2002,13 @@ static bool fwd_packed_enabled()
     return on != 0;
 }
 
+// RIME_BWD_SMALL=0: arrays of up to 64 antennas keep the four-tile instantiation of the backward kernel (A/B measurements)
+static bool bwd_small_enabled()
+{
+    static const int on = [] { const char* e = getenv("RIME_BWD_SMALL"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
 static bool cross_shape_ok(int rows_i, int rows_j)
 {
     return (rows_i == 32 && rows_j == 32) || (rows_i == 32 && rows_j == 64) || (rows_i == 64 && rows_j == 64) ||
@@ -2181,8 +2192,14 @@ extern "C" int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cr
         if (psky_complex) hipLaunchKernelGGL(fringe_ant_bwd_cross_kernel<true>, grid, dim3(512), MX_LDS, st, A);
         else hipLaunchKernelGGL(fringe_ant_bwd_cross_kernel<false>, grid, dim3(512), MX_LDS, st, A);
     } else {
-        if (psky_complex) hipLaunchKernelGGL(fringe_ant_bwd_kernel<true>, grid, dim3(512), MB_LDS, st, A);
-        else hipLaunchKernelGGL(fringe_ant_bwd_kernel<false>, grid, dim3(512), MB_LDS, st, A);
+        const bool small = Nrows <= 64 && bwd_small_enabled();
+        if (psky_complex) {
+            if (small) hipLaunchKernelGGL((fringe_ant_bwd_kernel<true, 2>), grid, dim3(512), MB_LDS, st, A);
+            else hipLaunchKernelGGL((fringe_ant_bwd_kernel<true, 4>), grid, dim3(512), MB_LDS, st, A);
+        } else {
+            if (small) hipLaunchKernelGGL((fringe_ant_bwd_kernel<false, 2>), grid, dim3(512), MB_LDS, st, A);
+            else hipLaunchKernelGGL((fringe_ant_bwd_kernel<false, 4>), grid, dim3(512), MB_LDS, st, A);
+        }
     }
     return check_launch();
 }
