@@ -16,10 +16,12 @@ Terms and their sizes (what the round-1 stand-in, a bare LST rotation, left out)
     annual aberration           ~ 20.5 arcsec            Earth velocity from the Sun's true longitude
                                                          (Meeus ch. 25; ~ 0.02 arcsec)
     diurnal aberration          ~ 0.3 arcsec             exact
-NOT modelled (needs IERS data or is below the above): polar motion (~0.3 arcsec), UT1-UTC unless
-passed as `dut1` (<= 0.9 s = 13 arcsec; -0.02..+0.02 s in 2022-23), light deflection by the Sun
+Earth orientation parameters (round 4): UT1-UTC (<= 0.9 s = 13 arcsec of hour angle) and the polar motion
+(xp, yp ~ 0.3 arcsec) are INPUTS -- `dut1` [s], `xp`, `yp` [rad] of observation_frame(), interpolated from an IERS
+table (`EarthOrientation`, finals2000A / EOP C04 / plain 4-column text: what astropy reads from its IERS files)
+when `TelescopeModel(iers_file=...)` is given one, 0 otherwise.  NOT modelled: light deflection by the Sun
 (<= 4 mas beyond 45 deg elongation), atmospheric refraction (astropy's AltAz default pressure is 0:
-none).  Expected agreement with astropy: a few 0.1 arcsec given the same UT1-UTC.  PARITY UNPINNED
+none), the TIO locator s' (< 0.1 mas).  Expected agreement with astropy given the same table: ~10 mas.  PARITY UNPINNED
 against astropy itself (absent here); pinned instead to SOFA's published known-answer values
 (tests/golden/sofa_vectors.json, tests/test_host_logic.py).
 """
@@ -183,12 +185,14 @@ def local_matrix(lat_deg):
     return np.array([[0.0, 1.0, 0.0], [-math.sin(p), 0.0, math.cos(p)], [math.cos(p), 0.0, math.sin(p)]], dtype=np.float64)
 
 
-def observation_frame(location, jd_utc, dut1=0.0):
+def observation_frame(location, jd_utc, dut1=0.0, xp=0.0, yp=0.0):
     """
     Everything that depends on the observation time only: returns (M, vbary, vdiurnal) with
     M (3, 3) float64 ICRS -> local (East, North, Up); vbary (3,) the observer's barycentric velocity / c
     in ICRS axes (annual aberration); vdiurnal the eastward velocity / c of the site (diurnal aberration).
     location = (lon, lat[, alt]) geodetic degrees (metres), as the reference's TelescopeModel.
+    dut1 = UT1 - UTC [s]; xp, yp = coordinates of the celestial intermediate pole in the terrestrial frame [rad]
+    (polar motion, W = R1(-yp) R2(-xp) between the Earth rotation and the site's longitude).
     """
     lon, lat = float(location[0]), float(location[1])
     alt = float(location[2]) if len(location) > 2 else 0.0
@@ -197,8 +201,11 @@ def observation_frame(location, jd_utc, dut1=0.0):
     dpsi, deps = nutation(T)
     PB = precession_matrix(T) @ frame_bias()
     NPB = nutation_matrix(eps0, dpsi, deps) @ PB
-    theta = gast(jd_utc + dut1 / 86400.0, T, dpsi, eps0) + lon * D2R
-    M = local_matrix(lat) @ rz(theta) @ NPB
+    theta = gast(jd_utc + dut1 / 86400.0, T, dpsi, eps0)
+    if xp == 0.0 and yp == 0.0:
+        M = local_matrix(lat) @ rz(theta + lon * D2R) @ NPB
+    else:
+        M = local_matrix(lat) @ rz(lon * D2R) @ rx(-yp) @ ry(-xp) @ rz(theta) @ NPB
     vbary = PB.T @ earth_velocity(T)                      # mean-of-date -> ICRS axes
     # site velocity from the Earth's rotation: omega * distance from the axis (WGS84)
     a, f = 6378137.0, 1.0 / 298.257223563
@@ -208,9 +215,9 @@ def observation_frame(location, jd_utc, dut1=0.0):
     return M, vbary, vdiurnal
 
 
-def icrs_to_topo(location, jd_utc, ra, dec, dut1=0.0):
+def icrs_to_topo(location, jd_utc, ra, dec, dut1=0.0, xp=0.0, yp=0.0):
     """numpy float64 restatement of the device path: (zen, az) [deg], az East of North"""
-    M, vb, vd = observation_frame(location, jd_utc, dut1)
+    M, vb, vd = observation_frame(location, jd_utc, dut1, xp, yp)
     a, d = np.deg2rad(np.atleast_1d(np.asarray(ra, dtype=np.float64))), np.deg2rad(np.atleast_1d(np.asarray(dec, dtype=np.float64)))
     p = np.stack([np.cos(d) * np.cos(a), np.cos(d) * np.sin(a), np.sin(d)])
     p = aberrate(p, vb)
@@ -229,3 +236,70 @@ def aberrate(p, v):
     bm1 = math.sqrt(1.0 - float((v * v).sum()))
     q = (bm1 * p + (1.0 + pdv / (1.0 + bm1)) * v) / (1.0 + pdv)
     return q / np.linalg.norm(q, axis=0, keepdims=True)
+
+
+class EarthOrientation:
+    """
+    UT1-UTC and polar motion from an IERS table, linearly interpolated in time: what astropy's ICRS -> AltAz takes from
+    its IERS-A / IERS-B files (telescope_model.py:469-502 of the reference goes through astropy.time / astropy.coordinates).
+    Accepted text formats, recognised per line:
+      * IERS `finals2000A.all` / `.daily` / `.data` (fixed columns: MJD 8-15, PM-x 19-27, PM-y 38-46 [arcsec],
+        UT1-UTC 59-68 [s]; Bulletin A values, predictions included);
+      * IERS EOP C04 (`year month day MJD x y UT1-UTC ...`, arcsec / s);
+      * plain `MJD xp yp UT1-UTC` (arcsec, arcsec, s); `#` starts a comment.
+    A leap second makes UT1-UTC jump by +1 s between two rows: the interpolation is done on the continuous UT1-TAI.
+    Outside the table the nearest row is used and `extrapolated` is set.
+    """
+    def __init__(self, mjd, xp_arcsec, yp_arcsec, dut1_s):
+        order = np.argsort(np.asarray(mjd, dtype=np.float64))
+        self.mjd = np.asarray(mjd, dtype=np.float64)[order]
+        self.xp = np.asarray(xp_arcsec, dtype=np.float64)[order] * AS2R
+        self.yp = np.asarray(yp_arcsec, dtype=np.float64)[order] * AS2R
+        self.dut1 = np.asarray(dut1_s, dtype=np.float64)[order]
+        assert len(self.mjd) >= 1 and len(np.unique(self.mjd)) == len(self.mjd), 'IERS table: empty or repeated dates'
+        # continuous quantity across leap seconds: UT1 - TAI = (UT1 - UTC) - (TAI - UTC)
+        self._ut1_tai = self.dut1 - np.array([tai_minus_utc(m + 2400000.5) for m in self.mjd])
+        self.extrapolated = False
+
+    @classmethod
+    def from_file(cls, path):
+        rows = []
+        with open(path) as f:
+            for line in f:
+                row = cls._parse(line)
+                if row is not None:
+                    rows.append(row)
+        if not rows:
+            raise ValueError('no Earth orientation rows recognised in %s' % path)
+        a = np.array(rows)
+        return cls(a[:, 0], a[:, 1], a[:, 2], a[:, 3])
+
+    @staticmethod
+    def _parse(line):
+        text = line.split('#')[0].rstrip('\n')
+        if not text.strip():
+            return None
+        if len(text) >= 68 and text[16:17] in ('I', 'P') and text[57:58] in ('I', 'P'):     # finals2000A
+            try:
+                return float(text[7:15]), float(text[18:27]), float(text[37:46]), float(text[58:68])
+            except ValueError:
+                return None                                   # the rows past the last prediction are blank
+        tok = text.split()
+        try:
+            if len(tok) >= 7 and all(t.lstrip('-').isdigit() for t in tok[:3]):                # EOP C04
+                return float(tok[3]), float(tok[4]), float(tok[5]), float(tok[6])
+            if len(tok) >= 4:
+                return float(tok[0]), float(tok[1]), float(tok[2]), float(tok[3])
+        except ValueError:
+            pass
+        return None
+
+    def at(self, jd_utc):
+        """(dut1 [s], xp [rad], yp [rad]) at a UTC Julian date"""
+        mjd = float(jd_utc) - 2400000.5
+        if mjd < self.mjd[0] or mjd > self.mjd[-1]:
+            self.extrapolated = True
+        xp = float(np.interp(mjd, self.mjd, self.xp))
+        yp = float(np.interp(mjd, self.mjd, self.yp))
+        dut1 = float(np.interp(mjd, self.mjd, self._ut1_tai)) + tai_minus_utc(float(jd_utc))
+        return dut1, xp, yp

@@ -36,13 +36,23 @@ _WARNED = False
 
 
 class TelescopeModel:
-    def __init__(self, location, tloc=None, device=None, dtype=None):
-        """location = (lon, lat[, alt]) in degrees, as the reference (:22-53)"""
+    def __init__(self, location, tloc=None, device=None, dtype=None, iers_file=None):
+        """location = (lon, lat[, alt]) in degrees, as the reference (:22-53).
+        iers_file (not in the reference, whose astropy reads its own IERS tables): an IERS Earth-orientation table
+        (finals2000A / EOP C04 / `MJD xp yp UT1-UTC` text, astrometry.EarthOrientation) supplying UT1-UTC and the polar
+        motion to the astrometry chain that serves a conv_cache miss; without one they are 0 (or `self.dut1` [s])."""
         self.location = location
         self.tloc = tloc
         self.dtype = dtype
         self.conv_cache = {}
         self.device = device
+        self.eop = astrometry.EarthOrientation.from_file(iers_file) if iers_file is not None else None
+
+    def earth_orientation(self, time):
+        """(UT1-UTC [s], xp, yp [rad]) at a UTC Julian date: from the IERS table when one was given, else (self.dut1 | 0, 0, 0)"""
+        if getattr(self, 'eop', None) is not None:
+            return self.eop.at(float(time))
+        return float(getattr(self, 'dut1', 0.0) or 0.0), 0.0, 0.0
 
     def hash(self, time, ra):
         return (time, len(ra))
@@ -71,16 +81,18 @@ class TelescopeModel:
             _WARNED = True
             warnings.warn("TelescopeModel.eq2top: (zen, az) not in conv_cache; computed by bayeslim_amd.astrometry "
                           "(IAU 2006 precession, truncated IAU 1980 nutation, annual + diurnal aberration) instead of "
-                          "astropy's ICRS->AltAz. Not modelled: polar motion, UT1-UTC (set TelescopeModel.dut1 [s]), "
-                          "light deflection; expected agreement a few 0.1 arcsec.", stacklevel=2)
-        M, vb, vd = astrometry.observation_frame(self.location, float(time), getattr(self, 'dut1', 0.0))
+                          "astropy's ICRS->AltAz. UT1-UTC and polar motion are 0 unless TelescopeModel(iers_file=...) supplies an IERS "
+                          "table (or .dut1 [s] is set); light deflection is not modelled; expected agreement ~10 mas with "
+                          "the table, a few 0.1 arcsec (+ 15 arcsec per second of UT1-UTC) without.", stacklevel=2)
+        dut1, xp, yp = self.earth_orientation(time)
+        M, vb, vd = astrometry.observation_frame(self.location, float(time), dut1, xp, yp)
         if isinstance(ra, torch.Tensor) and ra.is_cuda:
             angs = ops.eq2top(ra, torch.as_tensor(dec, device=ra.device), M, vb, vd)
             if self.device is not None:
                 angs = angs.to(self.device)
         else:
             zen, az = astrometry.icrs_to_topo(self.location, float(time), utils.tensor2numpy(ra), utils.tensor2numpy(dec),
-                                              getattr(self, 'dut1', 0.0))
+                                              dut1, xp, yp)
             angs = torch.as_tensor(np.stack([zen, az]), device=self.device, dtype=self.dtype)
         if store:
             self.conv_cache[key] = angs

@@ -604,6 +604,83 @@ def test_astrometry_host_chain_against_the_independent_oracle():
     assert np.abs(np.asarray(zen) - z2).max() > 0.1
 
 
+def test_astrometry_with_earth_orientation_parameters_reproduces_sofa_atco13(tmp_path):
+    """UT1-UTC and polar motion as inputs.  (i) the host chain with the dut1, xp, yp of SOFA's atco13
+    case reproduces its published observed direction to the oracle's level (15 mas; 0.21 arcsec without the polar motion);
+    (ii) against the independent oracle with polar motion on random directions; (iii) the same values read from IERS
+    tables in the three accepted formats through TelescopeModel(iers_file=...), interpolated, across a leap second."""
+    import json, math, os
+    import numpy as np
+    from bayeslim_amd import astrometry as A, telescope_model
+    from oracle import eq2top_oracle as E
+    g = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'sofa_vectors.json')))
+    ap, c = g['apco13'], g['atco13']
+    jd = c['utc1'] + c['utc2']
+    p = E.sofa_case_star_direction(c['rc'], c['dc'], c['pr'], c['pd'], c['px'], c['rv'], jd + (E.dat(jd) + 32.184) / 86400.0)
+    ra, dec = math.degrees(math.atan2(p[1, 0], p[0, 0])), math.degrees(math.asin(p[2, 0]))
+    loc = (math.degrees(c['elong']), math.degrees(c['phi']), c['hm'])
+    ztrue = math.degrees(E.sofa_case_remove_refraction(c['zob'], ap['refa'], ap['refb']))
+    mas = 1.0 / 3.6e6
+
+    def err(zen, az):
+        return (abs(float(zen[0]) - ztrue) / mas, abs(float(az[0]) - math.degrees(c['aob'])) * math.sin(c['zob']) / mas)
+
+    e_with = err(*A.icrs_to_topo(loc, jd, [ra], [dec], c['dut1'], c['xp'], c['yp']))
+    e_without = err(*A.icrs_to_topo(loc, jd, [ra], [dec], c['dut1']))
+    assert max(e_with) < 15.0, e_with
+    assert max(e_without) > 150.0, e_without                 # the polar motion of this case: 0.21 arcsec in zenith angle
+    # (ii) random directions, two sites, polar motion and UT1-UTC of realistic size
+    rng = np.random.default_rng(3)
+    rr, dd = rng.uniform(0, 360, 3000), np.rad2deg(np.arcsin(rng.uniform(-1, 1, 3000)))
+    for site in [(21.42827, -30.72148, 1050.0), (-107.6, 34.08, 2124.0)]:
+        for jdv, dut1, xp, yp in [(2459861.37, -0.0123, 0.21 * A.AS2R, 0.35 * A.AS2R), (2457755.1, 0.591, -0.1 * A.AS2R, 0.5 * A.AS2R)]:
+            zen, az = A.icrs_to_topo(site, jdv, rr, dd, dut1, xp, yp)
+            z2, a2 = E.eq2top(site, jdv, rr, dd, dut1, xp, yp)
+            da = np.abs(az - a2)
+            da = np.minimum(da, 360 - da) * np.sin(np.deg2rad(zen))
+            assert np.abs(zen - z2).max() * 3600 < 0.020 and da.max() * 3600 < 0.020
+    # (iii) IERS tables.  Rows around the date of the SOFA case (+ a leap second on 2017-01-01, MJD 57754 = UT1-UTC jumps by +1 s)
+    mjd0 = math.floor(jd - 2400000.5)
+    as_ = 1.0 / A.AS2R
+    rows = [(mjd0 - 1, c['xp'] * as_ - 0.002, c['yp'] * as_ + 0.001, c['dut1'] + 0.0011),
+            (mjd0, c['xp'] * as_ - 0.0005, c['yp'] * as_ + 0.0003, c['dut1'] + 0.0005),
+            (mjd0 + 1, c['xp'] * as_ + 0.0010, c['yp'] * as_ - 0.0004, c['dut1'] - 0.0006),
+            (57753, 0.1, 0.3, -0.5910), (57754, 0.1, 0.3, 0.4080), (57755, 0.1, 0.3, 0.4070)]
+    plain = tmp_path / 'eop.txt'
+    plain.write_text('# MJD xp yp UT1-UTC\n' + ''.join('%d %.6f %.6f %.7f\n' % r for r in rows))
+    c04 = tmp_path / 'eopc04.txt'
+    c04.write_text('  # header line\n' + ''.join('2013   4   %d  %d  %.6f  %.6f  %.7f  0.001 0.0 0.0 0.0 0.0\n' % ((r[0] % 30,) + r) for r in rows))
+    finals = tmp_path / 'finals2000A.all'
+    finals.write_text(''.join('13 4 2 %8.2f I %9.6f 0.000040 %9.6f 0.000030  I%10.7f 0.0000050' % r + ' ' * 100 + '\n' for r in rows)
+                      + ' ' * 7 + '%8.2f' % 99999.0 + ' ' * 170 + '\n')              # a trailing row without values
+    frac = jd - 2400000.5 - mjd0
+    want_dut1 = rows[1][3] + frac * (rows[2][3] - rows[1][3])
+    want_xp = (rows[1][1] + frac * (rows[2][1] - rows[1][1])) * A.AS2R
+    for path in (plain, c04, finals):
+        eop = A.EarthOrientation.from_file(str(path))
+        assert len(eop.mjd) == 6
+        d, x, y = eop.at(jd)
+        assert abs(d - want_dut1) < 1e-9 and abs(x - want_xp) < 1e-15, path
+        # half a day before the leap second: interpolated on UT1 - TAI, not across the 1-s jump
+        d2, _, _ = eop.at(2400000.5 + 57753.5)
+        assert abs(d2 - (-0.5910 - 0.0005)) < 1e-9, (path, d2)
+        d3, _, _ = eop.at(2400000.5 + 57754.5)
+        assert abs(d3 - 0.4075) < 1e-9
+        assert not eop.extrapolated
+        eop.at(2400000.5 + 60000.0)
+        assert eop.extrapolated
+    telescope_model._WARNED = True
+    tel = telescope_model.TelescopeModel(loc, iers_file=str(finals))
+    tel.use_astropy = False
+    za = tel.eq2top(jd, np.array([ra]), np.array([dec])).numpy()
+    assert max(err(za[0], za[1])) < 15.0
+    tel0 = telescope_model.TelescopeModel(loc)
+    tel0.use_astropy = False
+    tel0.dut1 = c['dut1']
+    assert max(err(*tel0.eq2top(jd, np.array([ra]), np.array([dec])).numpy())) > 150.0
+    assert tel0.earth_orientation(jd) == (c['dut1'], 0.0, 0.0)
+
+
 def test_rime_zenaz_cache_follows_the_conv_cache_entry_not_its_address():
     """RIME's per-key (zen, az) cache was validated by id() of the telescope's conv_cache entry; after
     clear_cache() + repopulate CPython can hand the same address to the new entry and the stale angles were served.

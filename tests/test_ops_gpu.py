@@ -1334,8 +1334,8 @@ def test_eq2top_kernel_against_the_independent_oracle(ops):
             worst = max(worst, dz.max(), daz.max())
             assert dz.max() < tol_deg and daz.max() < tol_deg, (loc, jd, dz.max() * 3.6e6, daz.max() * 3.6e6)
     # SOFA's own end-to-end case through the DEVICE path: the star of `atco13` at its date (space motion applied by the
-    # oracle's adaptor), refraction removed from the published observed values; polar motion (0.21 arcsec here) is not
-    # modelled by the product, hence 0.3 arcsec
+    # oracle's adaptor), refraction removed from the published observed values; without the case's polar motion (0.21 arcsec)
+    # 0.3 arcsec, with it (observation_frame(..., xp, yp), what TelescopeModel(iers_file=...) supplies) 20 mas
     import json, math
     c = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'sofa_vectors.json')))
     ap, c = c['apco13'], c['atco13']
@@ -1343,10 +1343,11 @@ def test_eq2top_kernel_against_the_independent_oracle(ops):
     p = E.sofa_case_star_direction(c['rc'], c['dc'], c['pr'], c['pd'], c['px'], c['rv'], jd + (E.dat(jd) + 32.184) / 86400.0)
     ra1, dec1 = math.degrees(math.atan2(p[1, 0], p[0, 0])), math.degrees(math.asin(p[2, 0]))
     loc = (math.degrees(c['elong']), math.degrees(c['phi']), c['hm'])
-    M, vb, vd = A.observation_frame(loc, jd, c['dut1'])
-    za = ops.eq2top(torch.as_tensor([ra1]).cuda(), torch.as_tensor([dec1]).cuda(), M, vb, vd).cpu().numpy()
     ztrue = math.degrees(E.sofa_case_remove_refraction(c['zob'], ap['refa'], ap['refb']))
-    assert abs(za[0, 0] - ztrue) * 3600 < 0.3 and abs(za[1, 0] - math.degrees(c['aob'])) * math.sin(c['zob']) * 3600 < 0.3
+    for eop, tol in (((), 0.3), ((c['xp'], c['yp']), 0.02)):       # round 4: with the case's polar motion 20 mas, not 0.3 arcsec
+        M, vb, vd = A.observation_frame(loc, jd, c['dut1'], *eop)
+        za = ops.eq2top(torch.as_tensor([ra1]).cuda(), torch.as_tensor([dec1]).cuda(), M, vb, vd).cpu().numpy()
+        assert abs(za[0, 0] - ztrue) * 3600 < tol and abs(za[1, 0] - math.degrees(c['aob'])) * math.sin(c['zob']) * 3600 < tol, (eop, za)
     # through the model (conv_cache miss -> astrometry chain on the device)
     telescope_model._WARNED = True
     tel = telescope_model.TelescopeModel((21.42827, -30.72148, 1050.0))
