@@ -916,7 +916,7 @@ def main():
         traffic, traffic_source, clock, clock_src = None, None, None, None
         for rel in ('profiles/r04/pmc_summary.json', 'profiles/r03/pmc_summary.json'):
             cpath = os.path.join(ROOT, rel)
-            if traffic is None and args.workload == 'c4' and world == 1 and not args.nf and os.path.exists(cpath):
+            if traffic is None and args.workload == 'c4' and not distributed and not args.nf and os.path.exists(cpath):
                 try:
                     pm = json.load(open(cpath))
                     inst = [v for k, v in pm.items() if k.split('<')[0] == dom and v.get('hbm_bytes_per_launch_larger_half')]

@@ -13,9 +13,9 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 worst = [0.0, 0.0]
 for trial in range(ntrial):
     rng = np.random.default_rng(seed0 + trial)
-    Nant = int(rng.choice([3, 17, 33, 40, 64, 65, 97, 128, 129, 160, 257]))
+    Nant = int(rng.choice([3, 17, 33, 37, 40, 45, 48, 64, 65, 97, 128, 129, 160, 257]))
     Nt, Nf = int(rng.integers(1, 4)), int(rng.integers(1, 40))
-    P = int(rng.choice([1, 30, 64, 100, 700, 3000, 9000]))
+    P = int(rng.choice([1, 30, 64, 100, 700, 3000, 9000, 20000]))
     Npp, cplx = [(1, False), (2, False), (1, True), (4, True), (4, False)][int(rng.integers(0, 5))]
     frac = float(rng.choice([1.0, 0.6, 0.15]))
     ant = rng.normal(0, 70.0, (Nant, 3)); ant[:, 2] *= 0.03
