@@ -36,6 +36,7 @@ SIGNATURES = {
     'rime_fringe_ant_fwd_block': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
                                        _i, _vp, _sz, _vp]),
     'rime_fringe_row_scale': (_i, [_vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp]),
+    'rime_fringe_row_scale_cplx': (_i, [_vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp, _vp]),
     'rime_fringe_ant_fwd_finish': (_i, [_vp, _sz, _vp, _i, _i, _i, _i, _vp]),
     'rime_fringe_ant_bwd_prepare': (_i, [_vp, _i, _i, _i, _vp, _sz, _vp]),
     'rime_fringe_ant_bwd_block': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
@@ -49,11 +50,14 @@ SIGNATURES = {
     'rime_eq2top': (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _vp, _vp]),
     'rime_interp_gather_fwd': (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'rime_interp_scatter_bwd': (_i, [_i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'rime_interp_scatter_rows_bwd': (_i, [_i, _i, _vp, _ll, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     'rime_beam_sky_fwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rime_beam_sky_bwd_workspace': (_sz, [_i, _i, _i, _i]),
     'rime_beam_sky_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'rime_jones_apply_fwd': (_i, [_i, _i, _vp, _vp, _vp, _ll, _ll, _vp, _vp]),
     'rime_jones_apply_bwd': (_i, [_i, _i, _vp, _vp, _vp, _vp, _ll, _ll, _vp, _vp, _vp, _vp]),
+    'rime_stokes2coh_fwd': (_i, [_i, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _vp, _vp]),
+    'rime_stokes2coh_bwd': (_i, [_i, _vp, _vp, _ll, _ll, _ll, _ll, _ll, _vp, _vp]),
     'rime_chisq_workspace': (_sz, []),
     'rime_chisq_fwd': (_i, [_i, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     'rime_chisq_bwd': (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),

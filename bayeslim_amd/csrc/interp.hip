@@ -264,6 +264,71 @@ extern "C" int rime_interp_scatter_bwd(int dtype, int is_complex, const void* go
 }
 
 // ---------------------------------------------------------------------------------------
+// Adjoint of a ONE-NODE gather (the FoV cut of the generic psky path, the redundant inflation: out[r, q] = w[q] m[r, inds[q]])
+// on ROW-MAJOR buffers: gm[r, j] = sum over the CSR list of j of w[q] gout[r, q].  Lanes run along the map pixels j: the store is
+// coalesced and the reads nearly so (the points that select consecutive pixels are consecutive but for the cut's gaps), so the
+// two transposing copies the general kernel needs (goutT, gmT -- and the strided gradient it hands upstream, which the next
+// consumer has to make contiguous: 5 ms of a C5 rank step) disappear.  Same fixed summation order: deterministic.
+// ---------------------------------------------------------------------------------------
+namespace rime {
+
+template <typename T, int EW, int RB>
+__global__ void __launch_bounds__(256)
+scatter_rows_kernel(const T* __restrict__ gout, long long gstride, const int* __restrict__ csr_ptr, const int* __restrict__ csr_src,
+                    const T* __restrict__ wgts, int R, int Npb, T* __restrict__ gm)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * RB;
+    if (j >= Npb) return;
+    const int e0 = csr_ptr[j], e1 = csr_ptr[j + 1];
+    T acc[RB][EW];
+#pragma unroll
+    for (int k = 0; k < RB; ++k)
+#pragma unroll
+        for (int c = 0; c < EW; ++c) acc[k][c] = T(0);
+    for (int e = e0; e < e1; ++e) {
+        const int q = csr_src[e];
+        const T w = wgts[q];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            if (r0 + k < R) {
+                const T* p = gout + ((size_t)(r0 + k) * gstride + q) * EW;
+#pragma unroll
+                for (int c = 0; c < EW; ++c) acc[k][c] = tfma<T>(w, p[c], acc[k][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+        if (r0 + k < R) {
+            T* o = gm + ((size_t)(r0 + k) * Npb + j) * EW;
+#pragma unroll
+            for (int c = 0; c < EW; ++c) o[c] = acc[k][c];
+        }
+    }
+}
+
+} // namespace rime
+
+extern "C" int rime_interp_scatter_rows_bwd(int dtype, int is_complex, const void* gout, long long gout_stride,
+                                            const int* csr_ptr, const int* csr_src, const void* wgts, int R, int Npb,
+                                            void* gm, void* stream)
+{
+    if (!gout || !csr_ptr || !csr_src || !wgts || !gm || R <= 0 || Npb <= 0 || gout_stride <= 0) return RIME_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    constexpr int RB = 8;
+    dim3 grid((Npb + 255) / 256, (R + RB - 1) / RB);
+    if (grid.y > 65535) return RIME_EUNSUPPORTED;
+#define RIME_SR(T, EW) hipLaunchKernelGGL((rime::scatter_rows_kernel<T, EW, RB>), grid, dim3(256), 0, st, (const T*)gout, gout_stride, \
+                                          csr_ptr, csr_src, (const T*)wgts, R, Npb, (T*)gm)
+    if (dtype == RIME_F32) { if (is_complex) RIME_SR(float, 2); else RIME_SR(float, 1); }
+    else if (dtype == RIME_F64) { if (is_complex) RIME_SR(double, 2); else RIME_SR(double, 1); }
+    else return RIME_EINVAL;
+#undef RIME_SR
+    return rime::check_launch();
+}
+
+// ---------------------------------------------------------------------------------------
 // Fused psky builder for the 1-pol power-beam case (beam_model.py:238-269 gen_beam's interpolation,
 // beam_model.py:1681-1698 cut_sky_fov and the beam x sky product of apply_beam :313-322):
 //     psky[r, q] = ( sum_k w[q,k] bmapT[inds[q,k], r] ) * sky[r, cut[q]]      r = channel, q = (t, p)

@@ -117,9 +117,89 @@ jones_apply_bwd_kernel(const T* __restrict__ J1, const T* __restrict__ J2, const
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Stokes I + fractional polarisation -> coherency matrix, one pass each way (sky_model.py:1160-1300, the branch a
+// Stokes-I sky with fractions (fQ, fU, fV) takes):
+//     C = I [[1 + fQ, fU - i fV], [fU + i fV, 1 - fQ]]
+// The torch composition is ~15 elementwise / stack kernels over (Nf x Npix) maps and as many in the backward (4.8 of the
+// 8 ms of torch glue in a C5 rank step, profiles/r04/glue_ops_c5.txt); HBM-bound: 4 B in + 32 B out per (channel, pixel).
+// Fractions are read through element strides (0 = broadcast): f[k * fs_k + r * fs_r + p * fs_p].
+// Backward for the REAL input I (torch's convention, grad = dL/dRe + i dL/dIm; out = c I -> gI = Re(conj(c) g)):
+//     gI = (1 + fQ) Re g00 + (1 - fQ) Re g11 + fU (Re g01 + Re g10) + fV (Im g10 - Im g01)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+stokes2coh_fwd_kernel(const T* __restrict__ I, const T* __restrict__ fr, long long fs_k, long long fs_r, long long fs_p,
+                      long long R, long long P, T* __restrict__ out)
+{
+    const long long N = R * P;
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const long long r = n / P, p = n - r * P;
+    const T* f = fr + r * fs_r + p * fs_p;
+    const T v = I[n], fq = f[0], fu = f[fs_k], fv = f[2 * fs_k];
+    cx<T>* o = reinterpret_cast<cx<T>*>(out);
+    o[n] = {v + v * fq, T(0)};
+    o[N + n] = {v * fu, -(v * fv)};
+    o[2 * N + n] = {v * fu, v * fv};
+    o[3 * N + n] = {v - v * fq, T(0)};
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+stokes2coh_bwd_kernel(const T* __restrict__ g, const T* __restrict__ fr, long long fs_k, long long fs_r, long long fs_p,
+                      long long R, long long P, T* __restrict__ gI)
+{
+    const long long N = R * P;
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const long long r = n / P, p = n - r * P;
+    const T* f = fr + r * fs_r + p * fs_p;
+    const T fq = f[0], fu = f[fs_k], fv = f[2 * fs_k];
+    const cx<T>* gg = reinterpret_cast<const cx<T>*>(g);
+    const cx<T> g00 = gg[n], g01 = gg[N + n], g10 = gg[2 * N + n], g11 = gg[3 * N + n];
+    gI[n] = (g00.x + g11.x) + fq * (g00.x - g11.x) + fu * (g01.x + g10.x) + fv * (g10.y - g01.y);
+}
+
 } // namespace rime
 
 using namespace rime;
+
+extern "C" int rime_stokes2coh_fwd(int dtype, const void* stokesI, const void* frac, long long fs_k, long long fs_r,
+                                   long long fs_p, long long R, long long P, void* coh, void* stream)
+{
+    if (!stokesI || !frac || !coh || R <= 0 || P <= 0 || fs_k < 0 || fs_r < 0 || fs_p < 0) return RIME_EINVAL;
+    const long long N = R * P;
+    if ((N + 255) / 256 > 0x7fffffffLL) return RIME_EUNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((N + 255) / 256));
+    if (dtype == RIME_F32)
+        hipLaunchKernelGGL((stokes2coh_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)stokesI, (const float*)frac,
+                           fs_k, fs_r, fs_p, R, P, (float*)coh);
+    else if (dtype == RIME_F64)
+        hipLaunchKernelGGL((stokes2coh_fwd_kernel<double>), grid, dim3(256), 0, st, (const double*)stokesI, (const double*)frac,
+                           fs_k, fs_r, fs_p, R, P, (double*)coh);
+    else return RIME_EINVAL;
+    return check_launch();
+}
+
+extern "C" int rime_stokes2coh_bwd(int dtype, const void* gcoh, const void* frac, long long fs_k, long long fs_r,
+                                   long long fs_p, long long R, long long P, void* gI, void* stream)
+{
+    if (!gcoh || !frac || !gI || R <= 0 || P <= 0 || fs_k < 0 || fs_r < 0 || fs_p < 0) return RIME_EINVAL;
+    const long long N = R * P;
+    if ((N + 255) / 256 > 0x7fffffffLL) return RIME_EUNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((N + 255) / 256));
+    if (dtype == RIME_F32)
+        hipLaunchKernelGGL((stokes2coh_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)gcoh, (const float*)frac,
+                           fs_k, fs_r, fs_p, R, P, (float*)gI);
+    else if (dtype == RIME_F64)
+        hipLaunchKernelGGL((stokes2coh_bwd_kernel<double>), grid, dim3(256), 0, st, (const double*)gcoh, (const double*)frac,
+                           fs_k, fs_r, fs_p, R, P, (double*)gI);
+    else return RIME_EINVAL;
+    return check_launch();
+}
 
 extern "C" int rime_jones_apply_fwd(int dtype, int beam_complex, const void* J1, const void* J2, const void* S,
                                     long long N, long long Ns, void* out, void* stream)

@@ -275,10 +275,19 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
     flops = 0
     if not backward:
         # inp: psky (Nt, Nmp, Npp, Nf, Ps[, 2]) float32 view; out: vis (Npp, Nbl, Nt, Nf, 2) float32
-        if cplx:
+        if cplx and inp.stride(-1) == 1 and inp.stride(-2) == 2 and all(inp.stride(k) % 2 == 0 for k in range(4)):
+            # interleaved complex rows: scale from max(|re|, |im|) and the minimum of each plane in ONE pass (round 4; torch's
+            # abs + amax + amin passes were 1.1 ms of a C5 rank step)
+            scale = torch.empty((Nmp, Npp, Nt, Nf), dtype=torch.float32, device=dev)
+            rowmin = [torch.empty_like(scale), torch.empty_like(scale)]
+            check(lib.rime_fringe_row_scale_cplx(_ptr(inp), Nmp, Npp, Nt, Nf, inp.stride(1) // 2, inp.stride(2) // 2,
+                                                 inp.stride(0) // 2, inp.stride(3) // 2, inp.shape[-2], _ptr(scale),
+                                                 _ptr(rowmin[0]), _ptr(rowmin[1]), _stream()), 'rime_fringe_row_scale_cplx')
+        elif cplx:
             amax = inp.abs().amax(dim=(-1, -2))                                    # (Nt, Nmp, Npp, Nf)
             lo = inp.amin(dim=-2)                                                  # (Nt, Nmp, Npp, Nf, 2): per plane
             rowmin = [lo[..., c].permute(1, 2, 0, 3).contiguous() for c in range(2)]
+            scale = _pow2_scale(amax.permute(1, 2, 0, 3)).contiguous()             # (Nmp, Npp, Nt, Nf)
         elif inp.stride(-1) == 1:
             # one launch: power-of-two scale and minimum of every (mp, pp, t, f) row, through the view's strides
             scale = torch.empty((Nmp, Npp, Nt, Nf), dtype=torch.float32, device=dev)
@@ -290,7 +299,6 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
             lo, hi = torch.aminmax(inp, dim=-1)                                    # one pass, no |psky| temporary
             amax = torch.maximum(hi, -lo)
             rowmin = [lo.permute(1, 2, 0, 3).contiguous()]
-        if cplx or inp.stride(-1) != 1:
             scale = _pow2_scale(amax.permute(1, 2, 0, 3)).contiguous()             # (Nmp, Npp, Nt, Nf)
         nbytes = lib.rime_fringe_ant_workspace(Nbl, Nt, Nf, geom.Pstride)
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
@@ -700,6 +708,75 @@ def jones_apply(J1, J2, S):
     return _JonesApply.apply(J1, J2, S, J2 is J1)
 
 
+class _Stokes2Coh(torch.autograd.Function):
+    """C = I [[1 + fQ, fU - i fV], [fU + i fV, 1 - fQ]] in one pass each way (csrc/jones.hip); fractions without gradient"""
+    @staticmethod
+    def forward(ctx, I, frb):
+        _require_cuda(I, frb)
+        x = I.detach().contiguous()
+        code, rdt = _real_dtype(x)
+        cdt = torch.complex64 if rdt == torch.float32 else torch.complex128
+        P = x.shape[-1]
+        R = x.numel() // P
+        out = torch.empty((2, 2) + tuple(x.shape), dtype=cdt, device=x.device)
+        # frb: (3,) + I.shape expanded view of the fractions: element strides, 0 on broadcast axes; rows must share ONE stride
+        fs = _frac_strides(frb, x.shape)
+        check(lib.rime_stokes2coh_fwd(code, _ptr(x), _ptr(frb), fs[0], fs[1], fs[2], R, P, _ptr(torch.view_as_real(out)), _stream()),
+              'rime_stokes2coh_fwd')
+        ctx.frb, ctx.fs, ctx.shape, ctx.code = frb, fs, tuple(I.shape), code
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        P = ctx.shape[-1]
+        R = int(np.prod(ctx.shape[:-1])) if len(ctx.shape) > 1 else 1
+        gI = torch.empty(ctx.shape, dtype=ctx.frb.dtype, device=g.device)
+        check(lib.rime_stokes2coh_bwd(ctx.code, _ptr(torch.view_as_real(g)), _ptr(ctx.frb), ctx.fs[0], ctx.fs[1], ctx.fs[2], R, P,
+                                      _ptr(gI), _stream()), 'rime_stokes2coh_bwd')
+        return gI, None
+
+
+def _frac_strides(frb, shape):
+    """(fs_k, fs_r, fs_p) element strides of an expanded (3,) + shape view, or None when the leading axes of `shape` cannot
+    be addressed by one row stride (then the caller keeps the torch composition)"""
+    st = frb.stride()
+    fs_p = st[-1] if shape[-1] > 1 else 0
+    lead, lst = list(shape[:-1]), list(st[1:-1])
+    # rows r = flattened leading axes: one stride only if the axes are jointly contiguous or all broadcast
+    live = [(n, s_) for n, s_ in zip(lead, lst) if n > 1]
+    if not live or all(s_ == 0 for _, s_ in live):
+        fs_r = 0
+    else:
+        fs_r = live[-1][1]
+        acc = fs_r
+        for n, s_ in reversed(live):
+            if s_ != acc:
+                return None
+            acc *= n
+    return (st[0], fs_r, fs_p)
+
+
+def stokes2coherency(I, frac):
+    """
+    Stokes I map (..., Npix) real on the GPU + fractional polarisation `frac` (3, 1, ...) broadcastable to (3,) + I.shape
+    (fQ, fU, fV) -> coherency (2, 2, ..., Npix) complex (sky_model.Stokes2Coherency's Stokes-I branch, sky_model.py:1160-1300)
+    in one fused pass; differentiable w.r.t. I.  Returns None when the layout is not served (fractions that require a
+    gradient, another dtype, leading axes without a common stride): the caller keeps the torch composition.
+    """
+    if not (I.is_cuda and I.dtype in (torch.float32, torch.float64) and not I.is_complex()):
+        return None
+    if frac.requires_grad or frac.dtype != I.dtype or frac.shape[0] != 3 or frac.device != I.device:
+        return None
+    try:
+        frb = frac.detach().reshape((3,) + tuple(frac.shape[2:])).expand((3,) + tuple(I.shape))
+    except RuntimeError:
+        return None
+    if _frac_strides(frb, tuple(I.shape)) is None or any(s_ < 0 for s_ in frb.stride()):
+        return None
+    return _Stokes2Coh.apply(I, frb)
+
+
 # ---------------------------------------------------------------------------------------
 class InterpStencil:
     """(inds, wgts) of PixInterp plus the CSR inverse index the deterministic adjoint uses."""
@@ -753,6 +830,16 @@ class _InterpGather(torch.autograd.Function):
         st = ctx.st
         code, rdt = _real_dtype(gout)
         R = int(np.prod(ctx.shape[:-1])) if len(ctx.shape) > 1 else 1
+        if st.Nnn == 1:
+            # one-node stencil (FoV cut, redundant inflation): row-major adjoint, no transposed copies, and the gradient that
+            # goes upstream is contiguous
+            g = gout.contiguous()
+            gm = torch.empty(ctx.shape, dtype=gout.dtype, device=gout.device)
+            rc = lib.rime_interp_scatter_rows_bwd(code, int(ctx.cplx), _ptr(torch.view_as_real(g) if ctx.cplx else g),
+                                                  ctx.out_stride, _ptr(st.csr_ptr), _ptr(st.csr_src), _ptr(st.weights(rdt)),
+                                                  R, st.Npb, _ptr(torch.view_as_real(gm) if ctx.cplx else gm), _stream())
+            check(rc, 'rime_interp_scatter_rows_bwd')
+            return gm, None, None
         # transposed working layout [pixel][row]: every read / write of the kernel is coalesced
         gT = gout.reshape(R, ctx.out_stride)[:, :st.P].t().contiguous()
         gmT = torch.empty((st.Npb, R), dtype=gout.dtype, device=gout.device)

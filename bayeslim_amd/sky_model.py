@@ -10,7 +10,7 @@ The only heavy piece, the a_lm -> pixel transform of `spatial_mode='alm'`, runs 
 import numpy as np
 import torch
 
-from . import utils, dataset
+from . import utils, dataset, ops
 from .utils import _float, _cfloat
 
 
@@ -288,6 +288,11 @@ class Stokes2Coherency(utils.Module):
                 return torch.stack([torch.stack([I, z]), torch.stack([z, I])])
             fr = self.params if isinstance(self.params, torch.Tensor) else self.params().data
             fr = fr.to(I.device)
+            if len(fr) == 3 and I.is_cuda:
+                # one fused pass each way (ops.stokes2coherency, csrc/jones.hip) instead of ~15 elementwise / stack kernels
+                coh = ops.stokes2coherency(I, fr)
+                if coh is not None:
+                    return coh
             Q = I * fr[0, 0]
             U = I * fr[1, 0] if len(fr) > 1 else torch.zeros_like(I)
             V = I * fr[2, 0] if len(fr) > 2 else None

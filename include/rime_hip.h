@@ -172,6 +172,12 @@ int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, const 
  * inputs with); the reference has no counterpart. */
 int rime_fringe_row_scale(const float* x, int d0, int d1, int d2, int d3, long long s0, long long s1,
                           long long s2, long long s3, int L, float* scale, float* rowmin, void* stream);
+/* The same for rows of an INTERLEAVED COMPLEX float32 psky (full-polarisation layouts; strides and L in complex elements):
+ * scale[row] from max(|re|, |im|) over the row, rowmin_re / rowmin_im (or NULL) the minimum of each plane -- the `rowmin`
+ * inputs of the per-plane forward passes. */
+int rime_fringe_row_scale_cplx(const float* x, int d0, int d1, int d2, int d3, long long s0, long long s1,
+                               long long s2, long long s3, int L, float* scale, float* rowmin_re, float* rowmin_im,
+                               void* stream);
 int rime_fringe_ant_fwd_finish(const void* workspace, size_t workspace_bytes, float* vis,
                                int Nbl, int Nt, int Nf, int Pstride, void* stream);
 int rime_fringe_ant_bwd_prepare(const float* gvis, int Nbl, int Nt, int Nf,
@@ -226,6 +232,12 @@ int rime_interp_gather_fwd(int dtype, int is_complex, const void* m, const int* 
 int rime_interp_scatter_bwd(int dtype, int is_complex, const void* goutT,
                             const int* csr_ptr, const int* csr_src, const void* wgts,
                             int R, int Npb, int P, int Nnn, void* gmT, void* stream);
+/* The same adjoint for a ONE-NODE stencil (Nnn = 1: the FoV cut, cut_sky_fov beam_model.py:1681-1698, and the redundant
+ * inflation, rime_model.py:436-437) on ROW-MAJOR buffers -- no transposed copies:
+ *   gout T [R, gout_stride] (complex: [R, gout_stride, 2]), gm T [R, Npb]; csr_src holds point indices q, wgts T [P]. */
+int rime_interp_scatter_rows_bwd(int dtype, int is_complex, const void* gout, long long gout_stride,
+                                 const int* csr_ptr, const int* csr_src, const void* wgts, int R, int Npb,
+                                 void* gm, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused psky builder (1-pol power beam, one beam model):
@@ -263,6 +275,16 @@ int rime_jones_apply_fwd(int dtype, int beam_complex, const void* J1, const void
                          long long N, long long Ns, void* out, void* stream);
 int rime_jones_apply_bwd(int dtype, int beam_complex, const void* J1, const void* J2, const void* S,
                          const void* G, long long N, long long Ns, void* gJ1, void* gJ2, void* gS, void* stream);
+
+/* Stokes I + fractional polarisation -> coherency matrix, one pass each way
+ *   C = I [[1 + fQ, fU - i fV], [fU + i fV, 1 - fQ]]
+ * (sky_model.py:1160-1300: Stokes2Coherency on a Stokes-I sky with fractions; the reference composes it from ~15 tensor ops).
+ *   stokesI : T [R, P] contiguous;  frac : T, element f_k[r, p] at frac[k fs_k + r fs_r + p fs_p] (strides 0 = broadcast), k = Q, U, V
+ *   coh, gcoh : complex<T> [2, 2, R, P];   gI : T [R, P] = (1 + fQ) Re g00 + (1 - fQ) Re g11 + fU (Re g01 + Re g10) + fV (Im g10 - Im g01) */
+int rime_stokes2coh_fwd(int dtype, const void* stokesI, const void* frac, long long fs_k, long long fs_r, long long fs_p,
+                        long long R, long long P, void* coh, void* stream);
+int rime_stokes2coh_bwd(int dtype, const void* gcoh, const void* frac, long long fs_k, long long fs_r, long long fs_p,
+                        long long R, long long P, void* gI, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a_lm -> pixel transform:  out[r, j] = sum_c ( are[r,c] * Yre[c,j] - aim[r,c] * Yim[c,j] )

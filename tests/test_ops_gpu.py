@@ -1181,6 +1181,62 @@ def test_jones_apply_against_the_einsum(ops, dtype, beam_complex, Nmp, same):
     assert d1.grad.dtype == bdt and ds.grad.shape == ds.shape
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('fshape', [(3, 1, 1, 1), (3, 1, 7, 1), (3, 1, 1, 501), (3, 1, 7, 501)])
+def test_stokes2coherency_fused_against_the_torch_composition(ops, dtype, fshape):
+    """sky_model.Stokes2Coherency on a Stokes-I sky with fractional (Q, U, V): the fused kernels (rime_stokes2coh_fwd / _bwd)
+    against the module's own torch composition (the reference's arithmetic, sky_model.py:1160-1300) -- values and the gradient
+    w.r.t. the Stokes-I map, fractions broadcast over channels and / or pixels; fractions that require a gradient keep torch"""
+    from bayeslim_amd import sky_model
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    I = torch.randn(1, 1, 7, 501, device='cuda', dtype=dtype, generator=gen)
+    fr = 0.3 * torch.randn(*fshape, device='cuda', dtype=dtype, generator=gen)
+    cdt = torch.complex64 if dtype == torch.float32 else torch.complex128
+    G = torch.randn(2, 2, 7, 501, device='cuda', dtype=cdt, generator=gen)
+    s2c = sky_model.Stokes2Coherency(params=fr)
+    a = I.clone().requires_grad_(True)
+    out = s2c(a)
+    assert out.shape == (2, 2, 7, 501) and out.dtype == cdt
+    (out * G.conj()).real.sum().backward()
+    # the composition, spelled out
+    b = I.clone().requires_grad_(True)
+    i0 = b[0, 0]
+    Q, U, V = i0 * fr[0, 0], i0 * fr[1, 0], i0 * fr[2, 0]
+    ref = torch.stack([torch.stack([i0 + Q, U - 1j * V]), torch.stack([U + 1j * V, i0 - Q])])
+    (ref * G.conj()).real.sum().backward()
+    tol = 1e-6 if dtype == torch.float32 else 1e-14
+    assert float((out - ref).abs().max()) <= tol * float(ref.abs().max())
+    assert float((a.grad - b.grad).abs().max()) <= tol * float(b.grad.abs().max())
+    assert ops.stokes2coherency(I[0, 0], fr) is not None
+    assert ops.stokes2coherency(I[0, 0], fr.clone().requires_grad_(True)) is None          # torch path keeps the fraction gradient
+    frg = fr.clone().requires_grad_(True)
+    out2 = sky_model.Stokes2Coherency(params=frg)(I)
+    (out2 * G.conj()).real.sum().backward()
+    assert frg.grad is not None and float((out2 - ref).abs().max()) <= 10 * tol * float(ref.abs().max())
+
+
+def test_complex_row_scale_kernel_against_torch(ops):
+    """rime_fringe_row_scale_cplx (scale from max(|re|, |im|), per-plane minima of interleaved complex rows through strides)
+    against the torch passes it replaces, on a permuted (time-inner) psky view with an all-zero and a tiny row"""
+    from bayeslim_amd import _lib
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    Nt, Nmp, Npp, Nf, Ps = 3, 2, 4, 5, 1000
+    base = torch.randn(Npp, Nmp, Nf, Nt, Ps, 2, device='cuda', generator=gen) * torch.exp(6 * torch.randn(Npp, Nmp, Nf, Nt, 1, 1, device='cuda', generator=gen))
+    base[1, 0, 2, 1] = 0.0
+    base[2, 1, 0, 0] *= 1e-30
+    inp = base.permute(3, 1, 0, 2, 4, 5)                               # (Nt, Nmp, Npp, Nf, Ps, 2), not contiguous
+    scale = torch.empty(Nmp, Npp, Nt, Nf, device='cuda')
+    lo = [torch.empty_like(scale), torch.empty_like(scale)]
+    _lib.check(_lib.lib.rime_fringe_row_scale_cplx(inp.data_ptr(), Nmp, Npp, Nt, Nf, inp.stride(1) // 2, inp.stride(2) // 2,
+                                                   inp.stride(0) // 2, inp.stride(3) // 2, Ps, scale.data_ptr(),
+                                                   lo[0].data_ptr(), lo[1].data_ptr(), torch.cuda.current_stream().cuda_stream), 'row_scale_cplx')
+    amax = inp.abs().amax(dim=(-1, -2)).permute(1, 2, 0, 3)
+    assert torch.equal(scale, ops._pow2_scale(amax).contiguous())
+    ref_lo = inp.amin(dim=-2)
+    for c in range(2):
+        assert torch.equal(lo[c], ref_lo[..., c].permute(1, 2, 0, 3).contiguous())
+
+
 def test_ops_refuse_cpu_tensors(ops):
     with pytest.raises(RuntimeError):
         ops.alm2pix(torch.zeros(2, 3, dtype=torch.complex64), torch.zeros(3, 4, dtype=torch.complex64))

@@ -8,6 +8,8 @@ from bayeslim_amd import ops
 from torch.profiler import profile, ProfilerActivity
 
 wl = sys.argv[1] if len(sys.argv) > 1 else 'c2'
+if len(sys.argv) > 2:                                   # second argument: number of channels (c5 64 = one rank's share)
+    bench.WORKLOADS[wl] = dict(bench.WORKLOADS[wl], Nf=int(sys.argv[2]))
 dev = torch.device('cuda', 0)
 inp = bench.build_inputs(wl, bench.WORKLOADS[wl]['nt'])
 rime, params, attach, _ = bench.build_model(inp, dev, bench.all_baselines(inp))
@@ -37,5 +39,5 @@ for e in ka:
         rows.append((dt, e.count, e.key, str(e.input_shapes)[:60], (stack[0] if stack else (e.stack[0] if e.stack else '?'))[-100:]))
 rows.sort(reverse=True)
 print('%d aten op groups with device time, %.1f us in total' % (len(rows), sum(r[0] for r in rows)))
-for r in rows[:45]:
+for r in rows[:60]:
     print('%8.1f us x%d %-20s %-60s %s' % r)
