@@ -849,7 +849,7 @@ class _InterpGather(torch.autograd.Function):
                                          R, st.Npb, st.P, st.Nnn,
                                          _ptr(torch.view_as_real(gmT) if ctx.cplx else gmT), _stream())
         check(rc, 'rime_interp_scatter_bwd')
-        return gmT.t().reshape(ctx.shape), None, None
+        return gmT.t().contiguous().reshape(ctx.shape), None, None
 
 
 def interp_gather(m, stencil, out_stride=None):
@@ -897,7 +897,9 @@ class _BeamSkyProduct(torch.autograd.Function):
         rc = lib.rime_interp_scatter_bwd(code, 0, _ptr(T1), _ptr(st.csr_ptr), _ptr(st.csr_src), _ptr(st.weights(rdt)),
                                          R, Npb, Q, st.Nnn, _ptr(gmT), _stream())
         check(rc, 'rime_interp_scatter_bwd')
-        return gmT.t(), gsky, None, None, None, None, None
+        # one explicit transposition: everything upstream (the |.| of a power beam, the sum of the sky components' beam
+        # gradients, the accumulation into .grad) then runs on a contiguous tensor instead of a transposed view
+        return gmT.t().contiguous(), gsky, None, None, None, None, None
 
 
 def beam_sky_product(bmap, sky, stencil, cut, pos, Nt, Ps):

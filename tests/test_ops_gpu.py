@@ -1221,11 +1221,13 @@ def test_complex_row_scale_kernel_against_torch(ops):
     from bayeslim_amd import _lib
     gen = torch.Generator(device='cuda').manual_seed(5)
     Nt, Nmp, Npp, Nf, Ps = 3, 2, 4, 5, 1000
-    base = torch.randn(Npp, Nmp, Nf, Nt, Ps, 2, device='cuda', generator=gen) * torch.exp(6 * torch.randn(Npp, Nmp, Nf, Nt, 1, 1, device='cuda', generator=gen))
+    f32 = torch.float32                                                 # whatever default dtype an earlier test left behind
+    base = torch.randn(Npp, Nmp, Nf, Nt, Ps, 2, device='cuda', generator=gen, dtype=f32) * torch.exp(
+        6 * torch.randn(Npp, Nmp, Nf, Nt, 1, 1, device='cuda', generator=gen, dtype=f32))
     base[1, 0, 2, 1] = 0.0
     base[2, 1, 0, 0] *= 1e-30
     inp = base.permute(3, 1, 0, 2, 4, 5)                               # (Nt, Nmp, Npp, Nf, Ps, 2), not contiguous
-    scale = torch.empty(Nmp, Npp, Nt, Nf, device='cuda')
+    scale = torch.empty(Nmp, Npp, Nt, Nf, device='cuda', dtype=f32)
     lo = [torch.empty_like(scale), torch.empty_like(scale)]
     _lib.check(_lib.lib.rime_fringe_row_scale_cplx(inp.data_ptr(), Nmp, Npp, Nt, Nf, inp.stride(1) // 2, inp.stride(2) // 2,
                                                    inp.stride(0) // 2, inp.stride(3) // 2, Ps, scale.data_ptr(),
