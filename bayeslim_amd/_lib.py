@@ -8,6 +8,12 @@ symbol cannot be resolved, importing this module raises.
 import ctypes
 import os
 
+# torch FIRST: it ships its own HIP runtime (torch/lib/libamdhip64.so); loaded before this library, the library's HIP
+# symbols resolve to that copy and both share one runtime.  The other order (this library first, pulling /opt/rocm's copy,
+# then torch) leaves two runtimes in the process and every launch from here fails with "no ROCm-capable device is detected"
+# (seen with __graft_entry__.build() followed by smoke() in ONE process).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RIME_LIB_PATH') or os.path.join(_HERE, 'lib', 'librime_hip.so')   # override: lab builds only
 
