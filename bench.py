@@ -657,7 +657,7 @@ def main():
         mfma_min = int(os.environ.get('RIME_MFMA_MIN_ANTS', '16'))
         modes = list(SHARD_MODES) if nants >= mfma_min else list(SHARD_MODES[::-1])
         rc = supervise_modes(modes, [os.path.abspath(__file__)] + sys.argv[1:], rank, world,
-                             timeout=float(os.environ.get('BENCH_MODE_TIMEOUT', '900')), out=sys.stdout)
+                             timeout=float(os.environ.get('BENCH_MODE_TIMEOUT', '600')), out=sys.stdout)
         raise SystemExit(rc)
 
     # stdout carries exactly ONE JSON line: libraries that chat on fd 1 (RCCL's version banner, gloo's
