@@ -1445,39 +1445,23 @@ constexpr size_t MB_LDS = 6 * (size_t)MB_PLANE + MF_NA * 3 * sizeof(double);
 
 __device__ __forceinline__ int tri_index(int ti, int tj) { return ti * 4 - ti * (ti - 1) / 2 + (tj - ti); }
 
-// CPLX: psky is complex (interleaved).  With Z = sum_ij conj(F_ij) g_ij = conj(sum_i conj(E_i) T_i) the two
-// gradient planes are Re Z and Im Z: the same T, a second lane-local contraction (Ei Tr - Er Ti) -- the
-// imaginary plane costs 32 FMAs per pixel tile and wave instead of a second pass.
-// TAMAX: row / column tiles the instantiation is compiled for (round 4).  4: any array of up to 128 antennas.  2: arrays of up to 64
-// antennas (HERA-19, HERA-37, the tile shards of a rank) -- four accumulators instead of eight: half the zero-fill moves per
-// pixel tile (a quarter of the kernel's VALU instructions at 37 antennas) and 60 registers less; the tile loops of the
-// general instantiation only DROP the iterations of absent tiles, they still pay for their registers.
-template <bool CPLX, int TAMAX>
-__global__ void __launch_bounds__(512, 2)
-fringe_ant_bwd_kernel(AntBwdArgs A)
+// Staging of a diagonal block of the backward: antenna coordinates (x sign nu / c) and the six G planes in A-fragment order into
+// LDS (shared by the 8-wave kernel and the pipelined 4-wave kernel below; NT = threads of the block).
+template <bool CPLX, int NT>
+__device__ __forceinline__ void bwd_stage_diag(const AntBwdArgs& A, unsigned char* g_img, double* ant_lds, int t, int f, int TA, float& gs)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* g_img = smem;              // planes: 0 Gr_hi, 1 Gi_hi, 2 -Gi_hi, 3 Gr_lo, 4 Gi_lo, 5 -Gi_lo
-    double* ant_lds = reinterpret_cast<double*>(smem + 6 * MB_PLANE);      // [128][3]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // 1-D grid, channel fastest: blocks that run together share (t, split), i.e. the same pointing
-    // vectors (L2 hits), and no grid dimension hits the 65535 cap
-    const int f = blockIdx.x % A.Nf, ts = blockIdx.x / A.Nf;
-    const int t = ts / A.S, split = ts % A.S;
-    const int TA = (A.Nant + 31) / 32;
-
+    const int tid = threadIdx.x;
     const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
-    for (int i = tid; i < MF_NA * 3; i += 512)
+    for (int i = tid; i < MF_NA * 3; i += NT)
         ant_lds[i] = (i < A.Nant * 3) ? nu_c * A.antpos[i] : 0.0;
 
     // stage G: fragment element (tile, ks, h, row, jj) <-> pair (i = 32 ti + row,
     // j = 32 tj + (jj & 3) + 8 (2 ks + (jj >> 2)) + 4 h); a thread packs the (jj, jj + 1) pair
-    const float gs = A.gscale[t * A.Nf + f];
+    gs = A.gscale[t * A.Nf + f];
     // tiles (ti, tj) with ti <= tj < TA are the ones the contraction reads: in the 4 x 4 upper-triangular numbering they end at
     // index 0 / 4 / 7 / 9 for TA = 1 .. 4, so small arrays stage 1 / 5 / 8 tiles instead of 10
     const int ntl = TA == 1 ? 1 : TA == 2 ? 5 : TA == 3 ? 8 : MB_TILES;
-    for (int e = tid; e < ntl * 2 * 2 * 32 * 4; e += 512) {
+    for (int e = tid; e < ntl * 2 * 2 * 32 * 4; e += NT) {
         const int jp = e & 3, row = (e >> 2) & 31, h = (e >> 7) & 1, ks = (e >> 8) & 1, tile = e >> 9;
         int ti = 0, rem = tile;
         while (rem >= 4 - ti) { rem -= 4 - ti; ++ti; }
@@ -1525,6 +1509,32 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
         *reinterpret_cast<uint32_t*>(g_img + 4 * MB_PLANE + off) = il;
         *reinterpret_cast<uint32_t*>(g_img + 5 * MB_PLANE + off) = il ^ 0x80008000u;
     }
+}
+
+// CPLX: psky is complex (interleaved).  With Z = sum_ij conj(F_ij) g_ij = conj(sum_i conj(E_i) T_i) the two
+// gradient planes are Re Z and Im Z: the same T, a second lane-local contraction (Ei Tr - Er Ti) -- the
+// imaginary plane costs 32 FMAs per pixel tile and wave instead of a second pass.
+// TAMAX: row / column tiles the instantiation is compiled for (round 4).  4: any array of up to 128 antennas.  2: arrays of up to 64
+// antennas (HERA-19, HERA-37, the tile shards of a rank) -- four accumulators instead of eight: half the zero-fill moves per
+// pixel tile (a quarter of the kernel's VALU instructions at 37 antennas) and 60 registers less; the tile loops of the
+// general instantiation only DROP the iterations of absent tiles, they still pay for their registers.
+template <bool CPLX, int TAMAX>
+__global__ void __launch_bounds__(512, 2)
+fringe_ant_bwd_kernel(AntBwdArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* g_img = smem;              // planes: 0 Gr_hi, 1 Gi_hi, 2 -Gi_hi, 3 Gr_lo, 4 Gi_lo, 5 -Gi_lo
+    double* ant_lds = reinterpret_cast<double*>(smem + 6 * MB_PLANE);      // [128][3]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 1-D grid, channel fastest: blocks that run together share (t, split), i.e. the same pointing
+    // vectors (L2 hits), and no grid dimension hits the 65535 cap
+    const int f = blockIdx.x % A.Nf, ts = blockIdx.x / A.Nf;
+    const int t = ts / A.S, split = ts % A.S;
+    const int TA = (A.Nant + 31) / 32;
+
+    float gs;
+    bwd_stage_diag<CPLX, 512>(A, g_img, ant_lds, t, f, TA, gs);
     __syncthreads();
 
     const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
@@ -1697,6 +1707,227 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// backward, 97..128 antennas, real psky: SOFTWARE-PIPELINED form, one wave per SIMD  (round 4; RIME_BWD_PIPE)
+//
+// What the counters say about the kernel above at C4: matrix pipe busy 61 % + other VALU issue 38 % of the SIMD cycles =
+// 99 %: the two waves of a SIMD take turns, an MFMA of one wave and the VALU work of the OTHER never overlap
+// (profiles/r01/overlap_lab.txt), so a pixel tile costs (MFMA time) + (VALU time) = 216 x 32 + ~1160 x 4 cycles.  Inside ONE
+// wave, however, the ~4 instructions that follow an MFMA issue in its shadow (32x32x16: 1 MFMA + 4 independent VALU = 34
+// cycles instead of 32 + 16).  This form gives every SIMD ONE wave (4-wave blocks, the whole register file: the eight
+// accumulators live beside two operand sets) and orders the instruction stream itself: the E operands of K step k + 1
+// (phasors, hi / lo split) and the lane-local contraction of the row tile that completed last are placed between the MFMAs of
+// K step k, region by region (sched_barrier fences between regions, sched_group_barrier inside).  Same products in the same
+// order per accumulator as the kernel above: same bits.
+// ---------------------------------------------------------------------------------------
+#define RIME_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+template <int M, int Q>
+__device__ __forceinline__ void pipe_groups()
+{
+    // M x { 1 MFMA, Q VALU }: the scheduler fills each slot from the region's instructions (LDS reads and waits are placed by
+    // their dependences)
+    static_for<0, M>([&](auto) { RIME_SGB(0x008, 1); RIME_SGB(0x100, 1); RIME_SGB(0x002, Q); });
+}
+
+// the same with T transcendental instructions (v_sin / v_cos: ~11 cycles each, they hide only when spread) per MFMA
+template <int M, int T, int Q>
+__device__ __forceinline__ void pipe_groups_t()
+{
+    static_for<0, M>([&](auto) { RIME_SGB(0x008, 1); RIME_SGB(0x100, 1); RIME_SGB(0x400, T); RIME_SGB(0x002, Q); });
+}
+
+__global__ void __launch_bounds__(256, 1)
+fringe_ant_bwd_pipe_kernel(AntBwdArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* g_img = smem;              // planes: 0 Gr_hi, 1 Gi_hi, 2 -Gi_hi, 3 Gr_lo, 4 Gi_lo, 5 -Gi_lo
+    double* ant_lds = reinterpret_cast<double*>(smem + 6 * MB_PLANE);      // [128][3]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = blockIdx.x % A.Nf, ts = blockIdx.x / A.Nf;
+    const int t = ts / A.S, split = ts % A.S;
+    float gs;
+    bwd_stage_diag<false, 256>(A, g_img, ant_lds, t, f, 4, gs);
+    __syncthreads();
+
+    const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
+    float* orow = A.gpsky + (size_t)t * A.st_t + (size_t)f * A.st_f;
+    const float inv = 1.0f / gs;
+    const int h = lane >> 5;
+    const int ntile = A.Pstride / 32;
+    const int tbeg = split * A.tiles_per_split;
+    const int tend = min(ntile, tbeg + A.tiles_per_split);
+    if (tbeg + wave >= tend) return;          // no barrier follows
+
+    uint32_t gl0 = (h * 32 + (lane & 31)) * 16, gl1 = gl0 + 3 * MB_PLANE;
+    asm volatile("" : "+v"(gl1));             // opaque: keeps gl1 a second base register
+
+    float ec[4][16], es[4][16];               // E of the lane's 16 antennas of row tile tj: set tj
+    uint4 F[2][4];                            // Erh, Erl, Eih, Eil of K step q: buffer q & 1
+    uint4 G[2][6];                            // G fragments of a tile step, double buffered by step parity
+    double C[24];                             // antenna coordinates of the K step whose phases are computed next
+    float rr[8], rq[8];                       // reduced phases between the phase stage and the sin / cos stage (two K steps in flight)
+    f32x16 accR[1][4], accI[1][4];
+
+    // K steps (tj, ks) of a pixel tile in the order  (3,0) (0,0) (3,1) (0,1) (2,0) (1,0) (2,1) (1,1):  a step with many tiles
+    // (H: 45 or 33 MFMAs) is followed by one with few (L: 9 or 21), and the operand generation of BOTH following steps sits in
+    // the H step's region (the L step's region only finishes the sin / cos + split of the next H step), so that every region
+    // has 3 - 6 vector instructions per MFMA.  Stages of a K step: loadC (antenna coordinates from LDS), genP (phases, f64),
+    // genTS (sin / cos, hi / lo split -> F).
+    auto loadC = [&](auto tjc, auto ksc) {
+        constexpr int tj = decltype(tjc)::value, ks = decltype(ksc)::value;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int an = 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
+            C[3 * jj] = ant_lds[3 * an]; C[3 * jj + 1] = ant_lds[3 * an + 1]; C[3 * jj + 2] = ant_lds[3 * an + 2];
+        }
+    };
+    auto genP = [&](float (&r)[8], double sx, double sy, double sz) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+            r[jj] = (float)__builtin_amdgcn_fract(C[3 * jj] * sx + C[3 * jj + 1] * sy + C[3 * jj + 2] * sz);
+    };
+    auto genTS = [&](auto tjc, auto ksc, auto bufc, const float (&r)[8]) {
+        constexpr int tj = decltype(tjc)::value, ks = decltype(ksc)::value, buf = decltype(bufc)::value;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            ec[tj][8 * ks + jj] = __builtin_amdgcn_cosf(r[jj]);
+            es[tj][8 * ks + jj] = __builtin_amdgcn_sinf(r[jj]);
+        }
+        uint32_t* erh = reinterpret_cast<uint32_t*>(&F[buf][0]); uint32_t* erl = reinterpret_cast<uint32_t*>(&F[buf][1]);
+        uint32_t* eih = reinterpret_cast<uint32_t*>(&F[buf][2]); uint32_t* eil = reinterpret_cast<uint32_t*>(&F[buf][3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            split2_plain(ec[tj][8 * ks + 2 * q], ec[tj][8 * ks + 2 * q + 1], erh[q], erl[q]);
+            split2_plain(es[tj][8 * ks + 2 * q], es[tj][8 * ks + 2 * q + 1], eih[q], eil[q]);
+        }
+    };
+    // G fragments of one tile step (tj, ks, ti): six planes (diagonal tiles: four) through two lane bases + immediates
+    auto loadG = [&](auto tjc, auto ksc, auto tic, uint4 (&g)[6]) {
+        constexpr int tj = decltype(tjc)::value, ks = decltype(ksc)::value, ti = decltype(tic)::value;
+        constexpr int tk = ((ti * 4 - ti * (ti - 1) / 2 + (tj - ti)) * 2 + ks) * 1024;
+        g[0] = *reinterpret_cast<const uint4*>(g_img + gl0 + 0 * MB_PLANE + tk);       // Grh (diagonal: S hi)
+        g[1] = *reinterpret_cast<const uint4*>(g_img + gl1 + 0 * MB_PLANE + tk);       // Grl
+        g[2] = *reinterpret_cast<const uint4*>(g_img + gl0 + 2 * MB_PLANE + tk);       // Gnh (diagonal: A hi)
+        g[3] = *reinterpret_cast<const uint4*>(g_img + gl1 + 2 * MB_PLANE + tk);       // Gnl
+        if constexpr (ti != tj) {
+            g[4] = *reinterpret_cast<const uint4*>(g_img + gl0 + 1 * MB_PLANE + tk);   // Gih
+            g[5] = *reinterpret_cast<const uint4*>(g_img + gl1 + 1 * MB_PLANE + tk);   // Gil
+        }
+    };
+    // the MFMAs of the tile steps [T0, T1) of K step q = (tj, ks), E operands in F[q & 1]: tile (ti, tj) from the fragments the
+    // PREVIOUS tile step loaded, while the next one's are loaded (BASE = tile steps of the pixel tile before this K step: the
+    // buffer parity; (ntj, nks) = the K step that follows); the first K step starts the accumulators
+    auto mm = [&](auto parc, auto tjc, auto ksc, auto bufc, auto basec, auto t0c, auto t1c, auto ntjc, auto nksc) {
+        constexpr int par = decltype(parc)::value;
+        constexpr int tj = decltype(tjc)::value, ks = decltype(ksc)::value, buf = decltype(bufc)::value;
+        constexpr int base = decltype(basec)::value, T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
+        constexpr bool first = tj == 3 && ks == 0;
+        const uint4 Erh = F[buf][0], Erl = F[buf][1], Eih = F[buf][2], Eil = F[buf][3];
+        f32x16 zero;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+        static_for<T0, T1>([&](auto tic) {
+            constexpr int ti = decltype(tic)::value;
+            constexpr int cur = (base + ti) & 1, nxt = cur ^ 1;
+            if constexpr (ti < tj) loadG(tjc, ksc, std::integral_constant<int, ti + 1>{}, G[nxt]);
+            else loadG(ntjc, nksc, std::integral_constant<int, 0>{}, G[nxt]);
+            const uint4 Grh = G[cur][0], Grl = G[cur][1], Gnh = G[cur][2], Gnl = G[cur][3];
+            if constexpr (ti == tj) {                 // diagonal tile, symmetric form: 9 MFMAs
+                accR[par][ti] = RIME_MFMA(Grh, Erh, first ? zero : accR[par][ti]);
+                accI[par][ti] = RIME_MFMA(Grh, Eih, first ? zero : accI[par][ti]);
+                accI[par][ti] = RIME_MFMA(Gnh, Erh, accI[par][ti]);
+                accR[par][ti] = RIME_MFMA(Grh, Erl, accR[par][ti]);
+                accI[par][ti] = RIME_MFMA(Grh, Eil, accI[par][ti]);
+                accI[par][ti] = RIME_MFMA(Gnh, Erl, accI[par][ti]);
+                accR[par][ti] = RIME_MFMA(Grl, Erh, accR[par][ti]);
+                accI[par][ti] = RIME_MFMA(Grl, Eih, accI[par][ti]);
+                accI[par][ti] = RIME_MFMA(Gnl, Erh, accI[par][ti]);
+            } else {
+                const uint4 Gih = G[cur][4], Gil = G[cur][5];
+                accR[par][ti] = RIME_MFMA(Grh, Erh, first ? zero : accR[par][ti]);
+                accI[par][ti] = RIME_MFMA(Grh, Eih, first ? zero : accI[par][ti]);
+                accR[par][ti] = RIME_MFMA(Gih, Eih, accR[par][ti]);
+                accI[par][ti] = RIME_MFMA(Gnh, Erh, accI[par][ti]);
+                accR[par][ti] = RIME_MFMA(Grh, Erl, accR[par][ti]);
+                accI[par][ti] = RIME_MFMA(Grh, Eil, accI[par][ti]);
+                accR[par][ti] = RIME_MFMA(Gih, Eil, accR[par][ti]);
+                accI[par][ti] = RIME_MFMA(Gnh, Erl, accI[par][ti]);
+                accR[par][ti] = RIME_MFMA(Grl, Erh, accR[par][ti]);
+                accI[par][ti] = RIME_MFMA(Grl, Eih, accI[par][ti]);
+                accR[par][ti] = RIME_MFMA(Gil, Eih, accR[par][ti]);
+                accI[par][ti] = RIME_MFMA(Gnl, Erh, accI[par][ti]);
+            }
+        });
+    };
+    // row tile tj of accumulator set par is complete (last written a whole region ago): contract elements [e0, e1) with E_i of
+    // the same antennas into `acc`
+    auto contract = [&](auto parc, auto tjc, float& acc, int e0 = 0, int e1 = 16) {
+        constexpr int par = decltype(parc)::value, tj = decltype(tjc)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (e >= e0 && e < e1) {
+                acc = fmaf(ec[tj][e], accR[par][tj][e], acc);
+                acc = fmaf(es[tj][e], accI[par][tj][e], acc);
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+#define RIME_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define RIME_IC(n) std::integral_constant<int, n>{}
+
+    int pt = tbeg + wave;
+    int p = pt * 32 + (lane & 31);
+    double sx = sd[p], sy = sd[A.Pstride + p], sz = sd[2 * (size_t)A.Pstride + p];
+    float part = 0.f;
+    const int plast = (tend - 1 - ((tend - 1 - (tbeg + wave)) & 3));            // this wave's last tile
+    // prologue: operands of the first K step (3,0), coordinates of the second (0,0), the first tile step's G fragments
+    loadC(I3{}, I0{}); genP(rr, sx, sy, sz); genTS(I3{}, I0{}, I0{}, rr); loadC(I0{}, I0{}); loadG(I3{}, I0{}, I0{}, G[0]);
+    using P = I0;
+    for (; pt < tend; pt += 4) {
+        // the next tile's pointing vector (the last tile re-reads its own: branch-free)
+        const int pn = min(pt + 4, plast) * 32 + (lane & 31);
+        const double nx = sd[pn], ny = sd[A.Pstride + pn], nz = sd[2 * (size_t)A.Pstride + pn];
+        part = 0.f;
+        // H region (K step q with 45 or 33 MFMAs): a) the whole operand generation of q + 1 (phases, sin / cos, split), then the
+        // coordinates of q + 2;  b) phases of q + 2.  L region (q + 1: 9 or 21 MFMAs): sin / cos + split of q + 2, coordinates of q + 3.
+        // q0 = (3,0)
+        RIME_FENCE(); mm(P{}, I3{}, I0{}, I0{}, RIME_IC(0), I0{}, I2{}, I0{}, I0{}); genP(rr, sx, sy, sz); genTS(I0{}, I0{}, I1{}, rr); loadC(I3{}, I1{});   pipe_groups_t<24, 1, 3>();
+        RIME_FENCE(); mm(P{}, I3{}, I0{}, I0{}, RIME_IC(0), I2{}, I4{}, I0{}, I0{}); genP(rq, sx, sy, sz);                                                  pipe_groups<21, 2>();
+        // q1 = (0,0)
+        RIME_FENCE(); mm(P{}, I0{}, I0{}, I1{}, RIME_IC(4), I0{}, I1{}, I3{}, I1{}); genTS(I3{}, I1{}, I0{}, rq); loadC(I0{}, I1{});                        pipe_groups_t<9, 2, 4>();
+        // q2 = (3,1)
+        RIME_FENCE(); mm(P{}, I3{}, I1{}, I0{}, RIME_IC(5), I0{}, I2{}, I0{}, I1{}); genP(rr, sx, sy, sz); genTS(I0{}, I1{}, I1{}, rr); loadC(I2{}, I0{});   pipe_groups_t<24, 1, 3>();
+        RIME_FENCE(); mm(P{}, I3{}, I1{}, I0{}, RIME_IC(5), I2{}, I4{}, I0{}, I1{}); genP(rq, sx, sy, sz);                                                  pipe_groups<21, 2>();
+        // q3 = (0,1)
+        RIME_FENCE(); mm(P{}, I0{}, I1{}, I1{}, RIME_IC(9), I0{}, I1{}, I2{}, I0{}); genTS(I2{}, I0{}, I0{}, rq); loadC(I1{}, I0{});                        pipe_groups_t<9, 2, 4>();
+        // q4 = (2,0)
+        RIME_FENCE(); mm(P{}, I2{}, I0{}, I0{}, RIME_IC(10), I0{}, I2{}, I1{}, I0{}); genP(rr, sx, sy, sz); genTS(I1{}, I0{}, I1{}, rr); loadC(I2{}, I1{});  pipe_groups_t<24, 1, 3>();
+        RIME_FENCE(); mm(P{}, I2{}, I0{}, I0{}, RIME_IC(10), I2{}, I3{}, I1{}, I0{}); genP(rq, sx, sy, sz);                                                 pipe_groups<9, 5>();
+        // q5 = (1,0): + the first half of the contraction of row tile 3 (complete since q2)
+        RIME_FENCE(); mm(P{}, I1{}, I0{}, I1{}, RIME_IC(13), I0{}, I2{}, I2{}, I1{}); genTS(I2{}, I1{}, I0{}, rq); loadC(I1{}, I1{}); contract(P{}, I3{}, part, 0, 8);  pipe_groups_t<21, 1, 4>();
+        // q6 = (2,1): + its second half
+        RIME_FENCE(); mm(P{}, I2{}, I1{}, I0{}, RIME_IC(15), I0{}, I2{}, I1{}, I1{}); genP(rr, sx, sy, sz); genTS(I1{}, I1{}, I1{}, rr); loadC(I3{}, I0{}); contract(P{}, I3{}, part, 8, 16);  pipe_groups_t<24, 1, 5>();
+        RIME_FENCE(); mm(P{}, I2{}, I1{}, I0{}, RIME_IC(15), I2{}, I3{}, I1{}, I1{}); genP(rq, nx, ny, nz);                                                 pipe_groups<9, 5>();
+        // q7 = (1,1): sin / cos + split of the next tile's q0 (into ec / es [3], contracted above), coordinates of its q1; row tile 2
+        // is complete since q6: its contraction
+        RIME_FENCE(); mm(P{}, I1{}, I1{}, I1{}, RIME_IC(18), I0{}, I2{}, I3{}, I0{}); genTS(I3{}, I0{}, I0{}, rq); loadC(I0{}, I0{}); contract(P{}, I2{}, part);  pipe_groups_t<21, 1, 6>();
+        RIME_FENCE();
+        RIME_MFMA_SETTLE();
+        contract(P{}, I1{}, part); contract(P{}, I0{}, part);
+        part += __shfl_xor(part, 32, 64);
+        if (h == 0) {
+            float* o = orow + (size_t)p * A.st_p;
+            *o = A.accumulate ? *o + part * inv : part * inv;
+        }
+        p = pn; sx = nx; sy = ny; sz = nz;
+    }
+#undef RIME_FENCE
+#undef RIME_IC
+}
 
 // Cross block of the backward (arrays with more than 128 antennas): rows i in group I (antpos rows
 // 0..127), columns j in group J (rows 128..255), all 16 tiles.  T_i = sum_j conj(G[i,j]) E_j as in
@@ -2050,6 +2281,13 @@ static bool bwd_small_enabled()
     return on != 0;
 }
 
+// RIME_BWD_PIPE=1: 97..128 antennas, real psky: the software-pipelined one-wave-per-SIMD backward (lab until it pays)
+static bool bwd_pipe_enabled()
+{
+    static const int on = [] { const char* e = getenv("RIME_BWD_PIPE"); return e ? atoi(e) : 0; }();
+    return on != 0;
+}
+
 static bool cross_shape_ok(int rows_i, int rows_j)
 {
     return (rows_i == 32 && rows_j == 32) || (rows_i == 32 && rows_j == 64) || (rows_i == 64 && rows_j == 64) ||
@@ -2246,6 +2484,10 @@ extern "C" int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cr
         else hipLaunchKernelGGL(fringe_ant_bwd_cross_kernel<false>, grid, dim3(512), MX_LDS, st, A);
     } else {
         const bool small = Nrows <= 64 && bwd_small_enabled();
+        if (!psky_complex && Nrows > 96 && bwd_pipe_enabled()) {
+            hipLaunchKernelGGL(fringe_ant_bwd_pipe_kernel, grid, dim3(256), MB_LDS, st, A);
+            return check_launch();
+        }
         if (psky_complex) {
             if (small) hipLaunchKernelGGL((fringe_ant_bwd_kernel<true, 2>), grid, dim3(512), MB_LDS, st, A);
             else hipLaunchKernelGGL((fringe_ant_bwd_kernel<true, 4>), grid, dim3(512), MB_LDS, st, A);
