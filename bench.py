@@ -501,7 +501,7 @@ def supervise_modes(modes, worker_argv, rank, world, timeout, out=None, env=None
             old[sg] = signal.signal(sg, forward)
     except ValueError:                      # not the main thread (tests): no forwarding
         old = {}
-    results = []
+    results, took = [], []
     try:
         for k, mode in enumerate(modes):
             e = dict(base_env, BENCH_PG_TAG='%s%d' % (mode, k), RANK=str(rank), WORLD_SIZE=str(world))
@@ -510,11 +510,17 @@ def supervise_modes(modes, worker_argv, rank, world, timeout, out=None, env=None
             # without a launcher store the worker of rank 0 hosts the store itself: one port per mode
             e['MASTER_PORT'] = str(base_port if agent_store else (base_port + k if world > 1 else (base_port if k == 0 else _free_port())))
             cmd = [sys.executable] + list(worker_argv) + ['--shard', mode, '--worker']
+            # a mode that follows a finished one gets 4 x that one's time (at least 3 min, at most `timeout`): a hang outside any
+            # collective (those abort by their own watchdog) must not hold the finished result back for long
+            limit = timeout
+            done = [t for (_, rc_, _), t in zip(results, took) if rc_ == 0]
+            if done and timeout is not None:
+                limit = min(timeout, max(180.0, 4.0 * max(done)))
             t0 = time.perf_counter()
             p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if rank == 0 else sys.stderr, start_new_session=True)
             current['p'] = p
             try:
-                stdout, _ = p.communicate(timeout=timeout)
+                stdout, _ = p.communicate(timeout=limit)
                 rc = p.returncode
             except subprocess.TimeoutExpired:
                 try:
@@ -527,7 +533,7 @@ def supervise_modes(modes, worker_argv, rank, world, timeout, out=None, env=None
                     pass
                 stdout, _ = p.communicate()
                 rc = 124
-                sys.stderr.write('bench.py rank %d: shard mode %s did not finish within %s s; killed\n' % (rank, mode, timeout))
+                sys.stderr.write('bench.py rank %d: shard mode %s did not finish within %s s; killed\n' % (rank, mode, limit))
             current['p'] = None
             obj = None
             for ln in (stdout or b'').decode(errors='replace').splitlines():
@@ -544,6 +550,7 @@ def supervise_modes(modes, worker_argv, rank, world, timeout, out=None, env=None
             sys.stderr.write('bench.py rank %d: shard mode %s -> exit code %d after %.1f s\n' % (rank, mode, rc, time.perf_counter() - t0))
             sys.stderr.flush()
             results.append((mode, rc, obj))
+            took.append(time.perf_counter() - t0)
     finally:
         for sg, h in old.items():
             signal.signal(sg, h)
