@@ -61,6 +61,17 @@ def test_bad_arguments_are_rejected_without_launching():
     assert rc == -1                # Npp = 3
     rc = lib.rime_interp_gather_fwd(0, 0, one, one, one, 2, 10, 5, 4, one, 3, None)
     assert rc == -1                # out_stride < P
+    # round-4 entry points
+    assert lib.rime_stokes2coh_fwd(0, one, one, 0, 0, 0, 0, 16, one, None) == -1          # R = 0
+    assert lib.rime_stokes2coh_fwd(7, one, one, 0, 0, 0, 4, 16, one, None) == -1          # unknown dtype
+    assert lib.rime_stokes2coh_bwd(0, one, None, 0, 0, 0, 4, 16, one, None) == -1         # no fractions
+    assert lib.rime_stokes2coh_fwd(0, one, one, -1, 0, 0, 4, 16, one, None) == -1         # negative stride
+    assert lib.rime_fringe_row_scale_cplx(one, 1, 1, 1, 0, 0, 0, 0, 0, 64, one, None, None, None) == -1    # no rows
+    assert lib.rime_fringe_row_scale_cplx(None, 1, 1, 1, 1, 0, 0, 0, 0, 64, one, None, None, None) == -1
+    assert lib.rime_interp_scatter_rows_bwd(0, 0, one, 0, one, one, one, 4, 10, one, None) == -1           # row stride 0
+    assert lib.rime_interp_scatter_rows_bwd(5, 0, one, 16, one, one, one, 4, 10, one, None) == -1          # unknown dtype
+    # 16 384 pixels per forward block since round 4: the C4 diffuse launch (98 304 px, 8 x 256 rows) takes 6 slabs
+    assert lib.rime_fringe_ant_workspace(8128, 8, 256, 98304) == 6 * 8128 * 8 * 256 * 8
     # workspace = S partial slabs of the vis tensor (forward) -- 0 when the grid is already large
     vis_bytes = 8128 * 64 * 256 * 8
     assert lib.rime_fringe_sum_workspace(0, 8128, 64, 256, 108032, 1, 1, 0, 0) == 0
