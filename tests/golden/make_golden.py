@@ -616,6 +616,108 @@ def gen_rime_mfma_arrays(ba):
              vis=V, gvis=gw, g_sky_params=grads[0], g_beam_params=grads[1])
 
 
+def gen_rime_mfma_large(ba):
+    """
+    Reference outputs for the kernels of the HEADLINE configuration and of arrays beyond one antenna group: 128 random
+    antennas (8128 baselines: the four-row-tile forward / backward kernels of config 4) and 150 random antennas (11 175
+    baselines: group blocks, i.e. diagonal + cross kernels); diffuse pixel sky (signed), rect-linear interpolated
+    PixelBeam, visibilities + gradients w.r.t. sky pixels and beam map.  Small in every other dimension (2 channels,
+    2 times, 600 / 400 directions) so that the files stay below 1.5 MB each.
+    """
+    for tag, Nant, Nf, Npix, seed in [('rand128', 128, 2, 600, 24), ('rand150', 150, 2, 400, 25)]:
+        freqs = torch.linspace(130e6, 170e6, Nf)
+        times = 2459861.0 + np.arange(2) * 10.0 / 1440
+        rng = np.random.default_rng(seed)
+        vecs = np.stack([rng.uniform(-200, 200, Nant), rng.uniform(-200, 200, Nant), rng.normal(0, 0.5, Nant)], 1)
+        arr = ba.telescope_model.ArrayModel(ba.utils.AntposDict(list(range(Nant)), vecs), freqs=freqs,
+                                            cache_s=True, redtol=1.0)
+        tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+        ra, dec = fib_sky(Npix)
+        px_area = 4 * np.pi / Npix
+        Rs = ba.sky_model.PixelSkyResponse(freqs, cosmo=object())
+        sp = torch.as_tensor(rng.normal(size=(1, 1, Nf, len(ra))))
+        sky = ba.sky_model.PixelSky(sp.clone(), torch.stack([ra, dec]), px_area, R=Rs,
+                                    parameter=True, name='pixsky')
+        beam, tg, pg = airy_pixbeam(ba, freqs, parameter=True)
+        ants = arr.ants
+        sim_bls = [(ants[i], ants[j]) for i in range(len(ants)) for j in range(i + 1, len(ants))]
+        rime = ba.rime_model.RIME(sky, tel, beam, arr, sim_bls, times, freqs)
+        zenaz = fill_eq2top(tel, sky.name, ra, dec, times)
+        V, gw, grads = run_rime(ba, rime, [sky.params, beam.params])
+        save('rime_%s_mini' % tag, freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(arr.ants),
+             sim_bls=np.array(sim_bls, dtype=np.int16), ra=ra, dec=dec, zenaz=zenaz, px_area=np.array(px_area),
+             sky_params=sp, beam_params=beam.params.detach(), theta_grid=tg, phi_grid=pg,
+             vis=V, gvis=gw, g_sky_params=grads[0], g_beam_params=grads[1])
+
+
+def gen_rime_pol_mfma(ba):
+    """
+    4-pol on an array the build serves with its matrix-core kernels: 40 random antennas (780 baselines), (2,2) Jones
+    PixelBeam with two beam models (four model pairs), coherency sky from Stokes2Coherency of (I, 0.1 I, 0.05 I) --
+    gen_rime_c5_mini's model (same restrictions: all-real beam and sky, the case the reference runs end to end) on an
+    array above the 16-antenna threshold.
+    """
+    Nf, Nant = 3, 40
+    freqs = torch.linspace(120e6, 180e6, Nf)
+    times = 2459861.0 + np.arange(2) * 10.0 / 1440
+    rng = np.random.default_rng(51)
+    vecs = np.stack([rng.uniform(-120, 120, Nant), rng.uniform(-120, 120, Nant), rng.normal(0, 0.5, Nant)], 1)
+    arr = ba.telescope_model.ArrayModel(ba.utils.AntposDict(list(range(Nant)), vecs), freqs=freqs,
+                                        cache_s=True, redtol=1.0)
+    tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
+    Npix = 300
+    k = np.arange(Npix) + 0.5
+    dec = np.rad2deg(np.arcsin(1 - 2 * k / Npix))
+    ra = (k * 137.50776405) % 360.0
+    ra_t, dec_t = torch.as_tensor(ra), torch.as_tensor(dec)
+    I = torch.as_tensor(np.abs(rng.normal(size=(1, 1, Nf, Npix))))
+    S2C = ba.sky_model.Stokes2Coherency(
+        params=torch.as_tensor(np.array([0.1, 0.05]).reshape(2, 1, 1, 1)) * torch.ones(2, 1, Nf, Npix))
+    Rs = ba.sky_model.PixelSkyResponse(freqs, cosmo=object())
+    px_area = 4 * np.pi / Npix
+    stokes_sky = ba.sky_model.PixelSky(I.clone(), torch.stack([ra_t, dec_t]), px_area, R=Rs,
+                                       parameter=True, name='polsky')
+
+    class CohSky(ba.utils.Module):
+        def __init__(self, sky, s2c):
+            super().__init__(name='cohsky')
+            self.sky = sky
+            self.s2c = s2c
+            self.device = sky.device
+
+        def forward(self, prior_cache=None, **kw):
+            return self.s2c(self.sky(prior_cache=prior_cache))
+
+    sky = CohSky(stokes_sky, S2C)
+    tg = torch.arange(0, 91, 5.0)
+    pg = torch.arange(0, 360, 10.0)
+    b_phi, b_theta = torch.meshgrid(pg, tg, indexing='xy')
+    b_phi, b_theta = b_phi.ravel(), b_theta.ravel()
+    airy = ba.beam_model.airy_disk(b_theta * ba.utils.D2R, b_phi * ba.utils.D2R, 14.0, freqs, square=False)
+    amp = npy(airy)[None, None, None] * rng.uniform(0.8, 1.2, (2, 2, 2, 1, 1))
+    amp[0, 1] *= 0.1
+    amp[1, 0] *= 0.1
+    ph = rng.normal(0, 0.2, (2, 2, 2, Nf, amp.shape[-1]))
+    Jr = torch.as_tensor(amp * np.cos(ph)).clone()
+    R = ba.beam_model.PixelResponse(freqs, 'rect', interp_mode='linear', theta=b_theta, phi=b_phi,
+                                    theta_grid=tg, phi_grid=pg, freq_mode='channel',
+                                    powerbeam=False, realbeam=True, comp_params=False)
+    ants = arr.ants
+    ant2beam = {a: (i % 2) for i, a in enumerate(ants)}
+    beam = ba.beam_model.PixelBeam(Jr.clone(), freqs, R=R, ant2beam=ant2beam, powerbeam=False,
+                                   fov=180, parameter=True)
+    beam.ant2beam = ant2beam
+    sim_bls = [(ants[i], ants[j]) for i in range(len(ants)) for j in range(i + 1, len(ants))]
+    rime = ba.rime_model.RIME(sky, tel, beam, arr, sim_bls, times, freqs)
+    zenaz = fill_eq2top(tel, 'polsky', ra_t, dec_t, times)
+    V, gw, grads = run_rime(ba, rime, [stokes_sky.params, beam.params])
+    save('rime_pol40_mini', freqs=freqs, times=times, antvecs=arr.antvecs, ants=np.array(arr.ants),
+         sim_bls=np.array(sim_bls), ra=ra, dec=dec, zenaz=zenaz, px_area=np.array(px_area),
+         stokes_I=I, frac_pol=np.array([0.1, 0.05]), beam_params=Jr,
+         ant2beam=np.array([ant2beam[a] for a in ants]), theta_grid=tg, phi_grid=pg,
+         vis=V, gvis=gw, g_sky_params=grads[0], g_beam_params=grads[1])
+
+
 def gen_rime_composite(ba):
     """
     Diffuse pixel sky + point sources through ONE beam: the sky of the headline benchmark.  The
@@ -1160,6 +1262,8 @@ def main():
     gen_rime_c3_mini(ba)
     gen_rime_c5_mini(ba)
     gen_rime_mfma_arrays(ba)
+    gen_rime_mfma_large(ba)
+    gen_rime_pol_mfma(ba)
     gen_rime_composite(ba)
     gen_rime_two_models(ba)
 

@@ -293,6 +293,46 @@ def test_rime_arrays_served_by_matrix_cores():
         _grad_check(vis, g, [sp, bp], ['g_sky_params', 'g_beam_params'])
 
 
+def test_rime_large_arrays_served_by_matrix_cores():
+    """128 random antennas (the four-row-tile kernels of the headline configuration) and 150 (group blocks: diagonal + cross
+    kernels): reference outputs of tests/golden/make_golden.py::gen_rime_mfma_large"""
+    for tag, nbl in [('rand128', 8128), ('rand150', 11175)]:
+        g = load_golden('rime_%s_mini' % tag)
+        freqs = T(g['freqs'])
+        sp = T(g['sky_params']).clone().requires_grad_(True)
+        bp = T(g['beam_params']).clone().requires_grad_(True)
+        vis = orc.rime_forward(sp * float(g['px_area']), T(g['zenaz']), _pixbeam_fn(g, bp), _blvecs(g),
+                               [(0, 0)] * nbl, freqs)
+        assert vis.shape == g['vis'].shape and vis.shape[2] == nbl
+        assert maxrel(vis.detach().numpy(), g['vis']) < 1e-11, tag
+        _grad_check(vis, g, [sp, bp], ['g_sky_params', 'g_beam_params'])
+
+
+def test_rime_pol40_mini():
+    """4-pol, two beam models, 40 antennas (780 baselines): gen_rime_pol_mfma"""
+    g = load_golden('rime_pol40_mini')
+    freqs = T(g['freqs'])
+    I = T(g['stokes_I']).clone().requires_grad_(True)
+    bp = T(g['beam_params']).clone().requires_grad_(True)
+    tg, pg = T(g['theta_grid']), T(g['phi_grid'])
+    Npix = I.shape[-1]
+    frac = T(g['frac_pol']).reshape(-1, 1, 1) * torch.ones(len(g['frac_pol']), len(freqs), Npix)
+    sky = orc.stokes_to_coherency(I[0, 0] * float(g['px_area']), frac)
+    a2b = g['ant2beam']
+    ants = g['ants'].tolist()
+    models = [(int(a2b[ants.index(i)]), int(a2b[ants.index(j)])) for i, j in g['sim_bls']]
+    assert len(set(models)) == 4 and len(models) == 780
+
+    def beam_fn(z, a):
+        inds, w = orc.rect_interp_weights(tg, pg, z, a, 'linear')
+        return orc.interp(orc.pixel_response_forward(bp, powerbeam=False), inds, w)
+
+    vis = orc.rime_forward(sky, T(g['zenaz']), beam_fn, _blvecs(g), models, freqs, powerbeam=False)
+    assert vis.shape == g['vis'].shape and vis.shape[:3] == (2, 2, 780)
+    assert maxrel(vis.detach().numpy(), g['vis']) < 1e-11
+    _grad_check(vis, g, [I, bp], ['g_sky_params', 'g_beam_params'])
+
+
 def test_rime_composite_sky():
     """diffuse + point sources = two reference RIMEs summed (the reference cannot run both in one)"""
     for tag in ('hex7', 'hex37'):
