@@ -89,6 +89,35 @@ __device__ __forceinline__ void split2_plain(float a, float b, uint32_t& hi, uin
     lo = pack_rtz(ra, rb);
 }
 
+// Phase of a phasor in turns: a.s = ax sx + ay sy + az sz in float64 (antenna coordinates pre-multiplied by sign nu / c), reduced to
+// its fraction as a float32 for v_sin_f32 / v_cos_f32.
+// RIME_PHASE_MAGIC=1 (lab, round 4; NOT the library build): the sum accumulated ON TOP of 1.5 * 2^29, whose float64 unit in the last
+// place is 2^-23 turn -- the low 23 mantissa bits of the result ARE the fraction (two's-complement wrap included), and OR-ed under
+// the exponent of 1.0f they are the float 1 + frac(a.s): one v_and_or_b32 in place of v_fract_f64 + v_cvt_f32_f64.  Measured
+// (profiles/r04/phase_magic_ab.txt, one box): C4 84.77 -> 83.22 ms/step (-1.8 %), C3 -2.0 %, C2 -1.5 % -- and 2.2 x the phase
+// noise (a fixed-point fraction of 23 bits rounded three times against a float32 fraction rounded once): element-wise 99th
+// percentile of the visibility error 2.2e-6 -> 4.9e-6, worst entry above 5 % of the largest 6.9e-6 -> 1.5e-5.  Not adopted.
+#ifndef RIME_PHASE_MAGIC
+#define RIME_PHASE_MAGIC 0
+#endif
+__device__ __forceinline__ double phase3(double ax, double sx, double ay, double sy, double az, double sz)
+{
+#if RIME_PHASE_MAGIC
+    return __builtin_fma(ax, sx, __builtin_fma(ay, sy, __builtin_fma(az, sz, 805306368.0)));     // 1.5 * 2^29
+#else
+    return ax * sx + ay * sy + az * sz;
+#endif
+}
+__device__ __forceinline__ float turn_frac(double ph)
+{
+#if RIME_PHASE_MAGIC
+    const uint32_t lo = (uint32_t)__builtin_bit_cast(unsigned long long, ph);
+    return __builtin_bit_cast(float, (lo & 0x007fffffu) | 0x3f800000u);
+#else
+    return (float)__builtin_amdgcn_fract(ph);
+#endif
+}
+
 __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_cast(f16x8, v); }
 
 // ---------------------------------------------------------------------------------------
@@ -381,9 +410,9 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
 #pragma unroll
             for (int u = 0; u < NGEN; ++u) {
                 if (u < nk) {
-                    const double ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
-                    const double ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
-                    const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                    const double ph0 = phase3(ax[u], sx[hf].x, ay[u], sy[hf].x, az[u], sz[hf].x);
+                    const double ph1 = phase3(ax[u], sx[hf].y, ay[u], sy[hf].y, az[u], sz[hf].y);
+                    const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
                     const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                     const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
                     uint32_t rh, rl, ih, il;
@@ -408,9 +437,9 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                 const float ar0 = av[hf].x * sb, ar1 = av[hf].y * sb, ai0 = aw[hf].x * si, ai1 = aw[hf].y * si;
 #pragma unroll
                 for (int u = 0; u < NGEN; ++u) {
-                    const double ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
-                    const double ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
-                    const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                    const double ph0 = phase3(ax[u], sx[hf].x, ay[u], sy[hf].x, az[u], sz[hf].x);
+                    const double ph1 = phase3(ax[u], sx[hf].y, ay[u], sy[hf].y, az[u], sz[hf].y);
+                    const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
                     const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                     const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
                     uint32_t rh, rl, ih, il;
@@ -447,15 +476,15 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                     ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
             float c0, s0, c1, s1, dc0, ds0, dc1, ds1;
             {
-                const double ph0 = ax[0] * sx[hf].x + ay[0] * sy[hf].x + az[0] * sz[hf].x;
-                const double ph1 = ax[0] * sx[hf].y + ay[0] * sy[hf].y + az[0] * sz[hf].y;
-                const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                const double ph0 = phase3(ax[0], sx[hf].x, ay[0], sy[hf].x, az[0], sz[hf].x);
+                const double ph1 = phase3(ax[0], sx[hf].y, ay[0], sy[hf].y, az[0], sz[hf].y);
+                const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
                 s0 = w0 * __builtin_amdgcn_sinf(r0); c0 = w0 * __builtin_amdgcn_cosf(r0);
                 s1 = w1 * __builtin_amdgcn_sinf(r1); c1 = w1 * __builtin_amdgcn_cosf(r1);
                 constexpr int U1 = SH::GEN > 1 ? 1 : 0;
-                const double pd0 = ax[U1] * sx[hf].x + ay[U1] * sy[hf].x + az[U1] * sz[hf].x;
-                const double pd1 = ax[U1] * sx[hf].y + ay[U1] * sy[hf].y + az[U1] * sz[hf].y;
-                const float q0 = (float)__builtin_amdgcn_fract(pd0), q1 = (float)__builtin_amdgcn_fract(pd1);
+                const double pd0 = phase3(ax[U1], sx[hf].x, ay[U1], sy[hf].x, az[U1], sz[hf].x);
+                const double pd1 = phase3(ax[U1], sx[hf].y, ay[U1], sy[hf].y, az[U1], sz[hf].y);
+                const float q0 = turn_frac(pd0), q1 = turn_frac(pd1);
                 ds0 = __builtin_amdgcn_sinf(q0); dc0 = __builtin_amdgcn_cosf(q0);
                 ds1 = __builtin_amdgcn_sinf(q1); dc1 = __builtin_amdgcn_cosf(q1);
             }
@@ -499,9 +528,9 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                     ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
 #pragma unroll
             for (int u = 0; u < SH::GEN; ++u) {
-                const double ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
-                const double ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
-                const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                const double ph0 = phase3(ax[u], sx[hf].x, ay[u], sy[hf].x, az[u], sz[hf].x);
+                const double ph1 = phase3(ax[u], sx[hf].y, ay[u], sy[hf].y, az[u], sz[hf].y);
+                const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
                 const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                 const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
                 uint32_t rh, rl, ih, il;
@@ -863,16 +892,16 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
                     c0 = fmaf(a_, b_, q); s0 = fmaf(b_, q, a_); c1 = fmaf(a_, q, b_); s1 = fmaf(b_, r_, a_);
                     c0 = fmaf(c0, s1, a_); s0 = fmaf(s0, c1, b_); c1 = fmaf(c1, s0, a_); s1 = fmaf(s1, c0, b_);
                 } else {
-                    const double ph0 = ax[u] * sx.x + ay[u] * sy.x + az[u] * sz.x;
-                    const double ph1 = ax[u] * sx.y + ay[u] * sy.y + az[u] * sz.y;
-                    const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                    const double ph0 = phase3(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
+                    const double ph1 = phase3(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
+                    const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
                     s0 = __builtin_amdgcn_sinf(r0); c0 = __builtin_amdgcn_cosf(r0);
                     s1 = __builtin_amdgcn_sinf(r1); c1 = __builtin_amdgcn_cosf(r1);
                 }
 #else
-                const double ph0 = ax[u] * sx.x + ay[u] * sy.x + az[u] * sz.x;
-                const double ph1 = ax[u] * sx.y + ay[u] * sy.y + az[u] * sz.y;
-                const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                const double ph0 = phase3(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
+                const double ph1 = phase3(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
+                const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
                 const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                 const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
 #endif
@@ -1170,9 +1199,9 @@ __device__ __forceinline__ void ant_fwd_v2_body(const AntArgs& A, unsigned char*
                     ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
 #pragma unroll
             for (int u = 0; u < V2::GEN; ++u) {
-                const double ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
-                const double ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
-                const float r0 = (float)__builtin_amdgcn_fract(ph0), r1 = (float)__builtin_amdgcn_fract(ph1);
+                const double ph0 = phase3(ax[u], sx[hf].x, ay[u], sy[hf].x, az[u], sz[hf].x);
+                const double ph1 = phase3(ax[u], sx[hf].y, ay[u], sy[hf].y, az[u], sz[hf].y);
+                const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
                 const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                 const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
                 uint32_t rh, rl, ih, il;
@@ -1210,13 +1239,13 @@ __device__ __forceinline__ void ant_fwd_v2_body(const AntArgs& A, unsigned char*
                         *reinterpret_cast<uint32_t*>(gb + 2 * MF_IMG + 4 * (8 * hf + pp)) =
                             ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
                 }
-                ph0 = ax[u] * sx[hf].x + ay[u] * sy[hf].x + az[u] * sz[hf].x;
+                ph0 = phase3(ax[u], sx[hf].x, ay[u], sy[hf].x, az[u], sz[hf].x);
             } else if constexpr (c == 1) {
-                ph1 = ax[u] * sx[hf].y + ay[u] * sy[hf].y + az[u] * sz[hf].y;
+                ph1 = phase3(ax[u], sx[hf].y, ay[u], sy[hf].y, az[u], sz[hf].y);
                 if constexpr (u == 1) fetch(fetch_panel, hf);      // this half panel's pixel registers are free now
             } else if constexpr (c == 2) {
-                r0 = (float)__builtin_amdgcn_fract(ph0);
-                r1 = (float)__builtin_amdgcn_fract(ph1);
+                r0 = turn_frac(ph0);
+                r1 = turn_frac(ph1);
             } else if constexpr (c == 3) {
                 s0 = __builtin_amdgcn_sinf(r0); c0 = __builtin_amdgcn_cosf(r0);
                 s1 = __builtin_amdgcn_sinf(r1); c1 = __builtin_amdgcn_cosf(r1);
@@ -1575,9 +1604,9 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
 #pragma unroll
                     for (int jq = 0; jq < 2; ++jq) {
                         const int an = 32 * tj + 8 * (2 * ks + jq) + 4 * h;
-                        const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
-                        const double pd = ant_lds[3 * an + 3] * sx + ant_lds[3 * an + 4] * sy + ant_lds[3 * an + 5] * sz;
-                        const float rr = (float)__builtin_amdgcn_fract(ph), rd = (float)__builtin_amdgcn_fract(pd);
+                        const double ph = phase3(ant_lds[3 * an], sx, ant_lds[3 * an + 1], sy, ant_lds[3 * an + 2], sz);
+                        const double pd = phase3(ant_lds[3 * an + 3], sx, ant_lds[3 * an + 4], sy, ant_lds[3 * an + 5], sz);
+                        const float rr = turn_frac(ph), rd = turn_frac(pd);
                         float c = __builtin_amdgcn_cosf(rr), sn = __builtin_amdgcn_sinf(rr);
                         const float dc = __builtin_amdgcn_cosf(rd), dsn = __builtin_amdgcn_sinf(rd);
                         ec[8 * ks + 4 * jq] = c; es[8 * ks + 4 * jq] = sn;
@@ -1616,8 +1645,8 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                         for (int u = 0; u < 4; ++u) {
                             const int jj = 4 * jq + u;
                             const int an = 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
-                            const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
-                            const float rr = (float)__builtin_amdgcn_fract(ph);
+                            const double ph = phase3(ant_lds[3 * an], sx, ant_lds[3 * an + 1], sy, ant_lds[3 * an + 2], sz);
+                            const float rr = turn_frac(ph);
                             ec[8 * ks + jj] = __builtin_amdgcn_cosf(rr);
                             es[8 * ks + jj] = __builtin_amdgcn_sinf(rr);
                         }
@@ -1787,7 +1816,7 @@ fringe_ant_bwd_pipe_kernel(AntBwdArgs A)
     auto genP = [&](float (&r)[8], double sx, double sy, double sz) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj)
-            r[jj] = (float)__builtin_amdgcn_fract(C[3 * jj] * sx + C[3 * jj + 1] * sy + C[3 * jj + 2] * sz);
+            r[jj] = turn_frac(phase3(C[3 * jj], sx, C[3 * jj + 1], sy, C[3 * jj + 2], sz));
     };
     auto genTS = [&](auto tjc, auto ksc, auto bufc, const float (&r)[8]) {
         constexpr int tj = decltype(tjc)::value, ks = decltype(ksc)::value, buf = decltype(bufc)::value;
@@ -2015,8 +2044,8 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
                     const int an = JB + 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
-                    const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
-                    const float rr = (float)__builtin_amdgcn_fract(ph);
+                    const double ph = phase3(ant_lds[3 * an], sx, ant_lds[3 * an + 1], sy, ant_lds[3 * an + 2], sz);
+                    const float rr = turn_frac(ph);
                     ec[jj] = __builtin_amdgcn_cosf(rr);
                     es[jj] = __builtin_amdgcn_sinf(rr);
                 }
@@ -2063,8 +2092,8 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int an = 32 * ti + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const double ph = ant_lds[3 * an] * sx + ant_lds[3 * an + 1] * sy + ant_lds[3 * an + 2] * sz;
-                const float rr = (float)__builtin_amdgcn_fract(ph);
+                const double ph = phase3(ant_lds[3 * an], sx, ant_lds[3 * an + 1], sy, ant_lds[3 * an + 2], sz);
+                const float rr = turn_frac(ph);
                 const float ce = __builtin_amdgcn_cosf(rr), se = __builtin_amdgcn_sinf(rr);
                 part = fmaf(ce, accR[ti][e], part);
                 part = fmaf(se, accI[ti][e], part);
