@@ -195,9 +195,10 @@ def _ant_problem():
     return ant, pairs, freqs, zen, az, sky, beam
 
 
-@pytest.mark.parametrize('tiles', [False, True])
-def test_pipelined_step_overlapped_collectives_equal_single_process(tiles):
-    world = 2
+@pytest.mark.parametrize('tiles, world', [(False, 2), (True, 2), (True, 4), (False, 3)])
+def test_pipelined_step_overlapped_collectives_equal_single_process(tiles, world):
+    # world 4 with tile shards (uneven blocks of the pair matrix, inverse permutation over four ranks) and world 3 with
+    # contiguous shards (2415 baselines do not divide): rank counts beyond the pair the other tests use
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
