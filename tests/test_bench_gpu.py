@@ -74,3 +74,27 @@ def test_one_rank_over_rccl_runs_the_supervisor_and_the_selfcheck():
     assert res['n_gpus'] == 1 and res['dist']['backend'] == 'nccl' and res['dist']['selfcheck']['ok']
     assert res['alt'][0]['selfcheck']['ok'] and {res['dist']['shard'], res['alt'][0]['shard']} == {'freq', 'bl'}
     assert res['dist']['collective_timeout_s'] in (60.0, 600.0)
+
+
+def test_one_rank_under_the_launcher_over_rccl_uses_the_launcher_store():
+    """the driver's command shape -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N` -- with N = 1 and BENCH_FORCE_DIST=1: the rank process supervises one worker per
+    partition, the workers build their RCCL groups through a PrefixStore on the LAUNCHER's TCPStore (the combination the
+    multi-GPU runs use; the gloo rehearsals cover the store, test_one_rank_over_rccl the backend)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ, BENCH_FORCE_DIST='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'BENCH_BACKEND', 'BENCH_DEVICE'):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--workload', 'c2',
+                        '--nt', '4', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], env=e, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 1 and res['dist']['backend'] == 'nccl' and res['dist']['selfcheck']['ok']
+    assert res['alt'][0]['selfcheck']['ok'] and {res['dist']['shard'], res['alt'][0]['shard']} == {'freq', 'bl'}
