@@ -31,16 +31,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int MF_NA = 128;                   // antennas per block (4 x 4 tiles)
-#ifndef RIME_OCT_MAX_TA
-#define RIME_OCT_MAX_TA 2      /* lab: 3 adds the three-row-tile blocks to the half-panel generation (measured + 0.5 %) */
-#endif
-#ifndef RIME_OCTX_NW4
-#define RIME_OCTX_NW4 1         /* 0: the 4-wave complex-psky blocks keep the two-half generation mapping (lab) */
-#endif
-#ifndef RIME_MF_SPLIT_PIX
-#define RIME_MF_SPLIT_PIX 16384
-#endif
-constexpr int MF_SPLIT_PIX = RIME_MF_SPLIT_PIX;           // pixels per block (bounds the f32 MFMA accumulation chain)
+constexpr int MF_SPLIT_PIX = 16384;           // pixels per block (bounds the f32 MFMA accumulation chain)
 
 struct AntArgs {
     const double* antpos;      // [Nant, 3]
@@ -90,33 +81,13 @@ __device__ __forceinline__ void split2_plain(float a, float b, uint32_t& hi, uin
 }
 
 // Phase of a phasor in turns: a.s = ax sx + ay sy + az sz in float64 (antenna coordinates pre-multiplied by sign nu / c), reduced to
-// its fraction as a float32 for v_sin_f32 / v_cos_f32.
-// RIME_PHASE_MAGIC=1 (lab, round 4; NOT the library build): the sum accumulated ON TOP of 1.5 * 2^29, whose float64 unit in the last
-// place is 2^-23 turn -- the low 23 mantissa bits of the result ARE the fraction (two's-complement wrap included), and OR-ed under
-// the exponent of 1.0f they are the float 1 + frac(a.s): one v_and_or_b32 in place of v_fract_f64 + v_cvt_f32_f64.  Measured
-// (profiles/r04/phase_magic_ab.txt, one box): C4 84.77 -> 83.22 ms/step (-1.8 %), C3 -2.0 %, C2 -1.5 % -- and 2.2 x the phase
-// noise (a fixed-point fraction of 23 bits rounded three times against a float32 fraction rounded once): element-wise 99th
-// percentile of the visibility error 2.2e-6 -> 4.9e-6, worst entry above 5 % of the largest 6.9e-6 -> 1.5e-5.  Not adopted.
-#ifndef RIME_PHASE_MAGIC
-#define RIME_PHASE_MAGIC 0
-#endif
+// its fraction as a float32 for v_sin_f32 / v_cos_f32 (a fixed-point reduction in the low mantissa bits saves two instructions
+// per phasor for 2.2 x the phase noise: measured, not adopted -- profiles/r04/phase_magic_ab.txt, tools/lab/).
 __device__ __forceinline__ double phase3(double ax, double sx, double ay, double sy, double az, double sz)
 {
-#if RIME_PHASE_MAGIC
-    return __builtin_fma(ax, sx, __builtin_fma(ay, sy, __builtin_fma(az, sz, 805306368.0)));     // 1.5 * 2^29
-#else
     return ax * sx + ay * sy + az * sz;
-#endif
 }
-__device__ __forceinline__ float turn_frac(double ph)
-{
-#if RIME_PHASE_MAGIC
-    const uint32_t lo = (uint32_t)__builtin_bit_cast(unsigned long long, ph);
-    return __builtin_bit_cast(float, (lo & 0x007fffffu) | 0x3f800000u);
-#else
-    return (float)__builtin_amdgcn_fract(ph);
-#endif
-}
+__device__ __forceinline__ float turn_frac(double ph) { return (float)__builtin_amdgcn_fract(ph); }
 
 __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_cast(f16x8, v); }
 
@@ -171,13 +142,7 @@ __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_
 // with separate L/B images, rot90 on the fly and whole-tile deal: 13.4 ms; this kernel: 10.7 ms
 // (matrix pipe busy 46 -> 55 %, 39 % operand generation on the VALU, ~5 % idle).
 // ---------------------------------------------------------------------------------------
-#ifndef RIME_MF_KP
-#define RIME_MF_KP 32
-#endif
-#ifndef RIME_V2_VALU
-#define RIME_V2_VALU 6
-#endif
-constexpr int MF_KP = RIME_MF_KP;               // pixels per panel (one barrier per panel); 16 per MFMA
+constexpr int MF_KP = 32;                       // pixels per panel (one barrier per panel); 16 per MFMA
 constexpr int MF_NH = MF_KP / 16;               // 16-pixel K steps per panel
 constexpr int MF_ROWB = 4 * MF_KP + 16;         // [re KP x f16][im KP x f16][pad]: odd number of 16-B granules
 
@@ -305,31 +270,18 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // 3 sweeps per wave instead of 4 (padding rows of the images are never written: they only reach
     // the result rows / columns of padding antennas, which have no baseline slot)
     // OCT8: the 8-wave real-psky cross blocks (arrays of more than 128 antennas, 1-pol): sweeps of 32 rows as OCTX below
-#if defined(RIME_NO_OCT8)          /* lab */
-    constexpr bool OCT8 = false;
-#else
     constexpr bool OCT8 = SH::CROSS && !SH::SELF && !CPLX && SH::NW == 8;
-#endif
-    constexpr bool OCT = OCT8 || (!SH::CROSS && (SH::TA <= 2 || SH::TA == 4 || SH::TA <= RIME_OCT_MAX_TA));
+    constexpr bool OCT = OCT8 || (!SH::CROSS && SH::TA != 3);     // three-row-tile blocks keep the two-half mapping (+ 0.5 % with this one)
     // the same idea for the 8-wave complex-psky blocks (128 x 128 cross blocks, 128-antenna self blocks; C5): a wave generates
     // one half of the panel for twice as many antennas per lane -- sweeps of 32 rows, rows 32 u + 2 ag + 16 ((W >> 1) & 1) + (W >> 2)
-#if defined(RIME_NO_OCTX)          /* lab: the two-half mapping */
-    constexpr bool OCTX = false;
-#else
-    constexpr bool OCTX = SH::CROSS && CPLX && (SH::NW == 8 || RIME_OCTX_NW4);
-#endif
+    constexpr bool OCTX = SH::CROSS && CPLX;
     constexpr int SWX = SH::NW * 4;                    // rows of an OCTX sweep: 32 (8 waves) or 16 (4 waves)
     constexpr int NGEN = OCT8 ? SH::ROWS / 32 : OCT ? SH::ROWS / 16 : (OCTX ? 2 : 1) * (SH::SELF ? SH::GEN_I : SH::GEN);
     // (round 4) the rows of a sweep are one OCTET per wave pair -- rows 16 u + 8 (W >> 1) + 2 (ag & 3) + (ag >> 2), conflict-free
     // ds_write_b32 as before -- instead of the rows of one parity: the sweeps a wave skips are then whole octets of padding,
     // 19 antennas cost 2 + 1 sweeps per wave pair instead of 2 + 2, 37 antennas 3 + 2 instead of 3 + 3 (same bits)
-#if defined(RIME_LAB_PARITY_ROWS)      /* lab: the mapping of rounds 1-3 (rows of one parity per wave pair) */
-    const int orow = (W >> 1) + 2 * ag;
-    const int nk = (OCT && !OCT8) ? min(NGEN, (A.Nant - (W >> 1) + 15) / 16) : NGEN;
-#else
     const int orow = 8 * (W >> 1) + 2 * (ag & 3) + (ag >> 2);
     const int nk = (OCT && !OCT8) ? min(NGEN, (A.Nant - 8 * (W >> 1) + 15) / 16) : NGEN;     // uniform
-#endif
     const int growx = SH::NW == 8 ? 2 * ag + 16 * ((W >> 1) & 1) + (W >> 2) : 2 * ag + (W >> 1);
     double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
@@ -360,18 +312,6 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     const uint32_t lo_s = 16u * pp, lo_a0 = 8u * pp * (uint32_t)st_p, lo_a1 = lo_a0 + 4u * (uint32_t)st_p;
     const double* sdy = sd + A.Pstride;
     const double* sdz = sd + 2 * (size_t)A.Pstride;
-#if defined(RIME_FWD_GLOBAL_LOADS)     /* lab: the flat-load form (6 v_lshl_add_u64 per half panel for the addresses) */
-    auto fetch = [&](int panel, int hf) {
-        const int p0 = panel * MF_KP + 16 * hf;      // uniform
-        sx[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sd + p0) + lo_s);
-        sy[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sdy + p0) + lo_s);
-        sz[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sdz + p0) + lo_s);
-        const char* ab = reinterpret_cast<const char*>(arow + (size_t)p0 * st_p);
-        av[hf] = make_float2(*reinterpret_cast<const float*>(ab + lo_a0), *reinterpret_cast<const float*>(ab + lo_a1));
-        if constexpr (CPLX)
-            aw[hf] = make_float2(*reinterpret_cast<const float*>(ab + lo_a0 + 4), *reinterpret_cast<const float*>(ab + lo_a1 + 4));
-    };
-#else
     // buffer loads: descriptor (SGPRs, wave-uniform: built from kernel arguments and the block index) + constant per-lane
     // offset + scalar panel offset -- no vector address arithmetic in the generation phase, whose cost is its
     // instruction count (profiles/r03/lab_forward_experiments.txt); out-of-range reads return 0 instead of faulting
@@ -399,7 +339,6 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
             aw[hf] = make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a0 + 4, so, 0)),
                                  __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a1 + 4, so, 0)));
     };
-#endif
     auto generate = [&](unsigned char* buf, int next_panel) {
         if constexpr (OCT) {
             constexpr int hf = W & 1;
@@ -467,59 +406,6 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
             }
             return;
         }
-#if defined(RIME_LAB_CHAIN)      /* lab, TIMING ONLY (tools/fringe_mfma_lab.hip; -DRIME_LAB_CHAIN=1 or 2): rows u >= 1 by recurrence E_u = E_(u-1) D */
-#pragma unroll
-        for (int hf = 0; hf < MF_NH; ++hf) {
-            const float w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
-            if (SIGNED && tid < 8)
-                *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
-                    ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
-            float c0, s0, c1, s1, dc0, ds0, dc1, ds1;
-            {
-                const double ph0 = phase3(ax[0], sx[hf].x, ay[0], sy[hf].x, az[0], sz[hf].x);
-                const double ph1 = phase3(ax[0], sx[hf].y, ay[0], sy[hf].y, az[0], sz[hf].y);
-                const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
-                s0 = w0 * __builtin_amdgcn_sinf(r0); c0 = w0 * __builtin_amdgcn_cosf(r0);
-                s1 = w1 * __builtin_amdgcn_sinf(r1); c1 = w1 * __builtin_amdgcn_cosf(r1);
-                constexpr int U1 = SH::GEN > 1 ? 1 : 0;
-                const double pd0 = phase3(ax[U1], sx[hf].x, ay[U1], sy[hf].x, az[U1], sz[hf].x);
-                const double pd1 = phase3(ax[U1], sx[hf].y, ay[U1], sy[hf].y, az[U1], sz[hf].y);
-                const float q0 = turn_frac(pd0), q1 = turn_frac(pd1);
-                ds0 = __builtin_amdgcn_sinf(q0); dc0 = __builtin_amdgcn_cosf(q0);
-                ds1 = __builtin_amdgcn_sinf(q1); dc1 = __builtin_amdgcn_cosf(q1);
-            }
-#if RIME_LAB_CHAIN == 2          /* powers of D first: rows are independent of each other (no serial chain through E) */
-            float pc0[4] = {1.f, dc0, 0.f, 0.f}, ps0[4] = {0.f, ds0, 0.f, 0.f}, pc1[4] = {1.f, dc1, 0.f, 0.f}, ps1[4] = {0.f, ds1, 0.f, 0.f};
-            pc0[2] = dc0 * dc0 - ds0 * ds0; ps0[2] = 2.f * dc0 * ds0; pc1[2] = dc1 * dc1 - ds1 * ds1; ps1[2] = 2.f * dc1 * ds1;
-            pc0[3] = pc0[2] * dc0 - ps0[2] * ds0; ps0[3] = pc0[2] * ds0 + ps0[2] * dc0;
-            pc1[3] = pc1[2] * dc1 - ps1[2] * ds1; ps1[3] = pc1[2] * ds1 + ps1[2] * dc1;
-            const float bc0 = c0, bs0 = s0, bc1 = c1, bs1 = s1;
-#endif
-#pragma unroll
-            for (int u = 0; u < SH::GEN; ++u) {
-                if (u > 0) {
-#if RIME_LAB_CHAIN == 2
-                    c0 = bc0 * pc0[u] - bs0 * ps0[u]; s0 = bc0 * ps0[u] + bs0 * pc0[u];
-                    c1 = bc1 * pc1[u] - bs1 * ps1[u]; s1 = bc1 * ps1[u] + bs1 * pc1[u];
-#else
-                    const float nc0 = c0 * dc0 - s0 * ds0, ns0 = c0 * ds0 + s0 * dc0;
-                    const float nc1 = c1 * dc1 - s1 * ds1, ns1 = c1 * ds1 + s1 * dc1;
-                    c0 = nc0; s0 = ns0; c1 = nc1; s1 = ns1;
-#endif
-                }
-                uint32_t rh, rl, ih, il;
-                split2_plain(c0, c1, rh, rl);
-                split2_plain(s0, s1, ih, il);
-                unsigned char* o = buf + goff + u * SH::GROWS * MF_ROWB + 32 * hf;
-                *reinterpret_cast<uint32_t*>(o) = rh;
-                *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
-                *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
-                *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
-            }
-            fetch(next_panel, hf);
-        }
-        return;
-#endif
 #pragma unroll
         for (int hf = 0; hf < MF_NH; ++hf) {
             const float w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
@@ -600,21 +486,15 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh, Brh, acc[sR][0]);
                 if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh, Bih, acc[sI][0]);
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih, Bih, acc[sR][0]);
-#if !defined(RIME_LAB_3M_UPPER)   /* lab, TIMING ONLY: 9 instead of 12 MFMAs per off-diagonal tile, nothing else changed */
                 if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih, Brh, acc[sI][1]);
-#endif
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrh, Brl, acc[sR][0]);
                 if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrh, Bil, acc[sI][0]);
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lih, Bil, acc[sR][0]);
-#if !defined(RIME_LAB_3M_UPPER)
                 if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lih, Brl, acc[sI][1]);
-#endif
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lrl, Brh, acc[sR][0]);
                 if constexpr (hasI) acc[sI][0] = RIME_MFMA(Lrl, Bih, acc[sI][0]);
                 if constexpr (hasR) acc[sR][0] = RIME_MFMA(Lil, Bih, acc[sR][0]);
-#if !defined(RIME_LAB_3M_UPPER)
                 if constexpr (hasI) acc[sI][1] = RIME_MFMA(Lil, Brh, acc[sI][1]);
-#endif
             });
         }
     };
@@ -628,28 +508,16 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     }
     generate(buf0, min(pbeg + 1, pend - 1));
     __syncthreads();
-#if defined(RIME_ABL_NOGEN)        /* lab ablations (tools/fringe_mfma_lab.hip): never defined in the library build */
-#define RIME_GEN(b, n) do { if (panel < pbeg + 2) generate(b, n); } while (0)
-#else
-#define RIME_GEN(b, n) generate(b, n)
-#endif
-#if defined(RIME_ABL_NOMFMA)
-#define RIME_CON(b) do { const uint4 q = *reinterpret_cast<const uint4*>(b + foff); acc[0][0][0] += __uint_as_float(q.x ^ q.y ^ q.z ^ q.w); } while (0)
-#else
-#define RIME_CON(b) contract(b)
-#endif
     for (int panel = pbeg; panel < pend; panel += 2) {
-        if (panel + 1 < pend) RIME_GEN(buf1, min(panel + 2, pend - 1));
-        RIME_CON(buf0);
+        if (panel + 1 < pend) generate(buf1, min(panel + 2, pend - 1));
+        contract(buf0);
         __syncthreads();
         if (panel + 1 < pend) {
-            if (panel + 2 < pend) RIME_GEN(buf0, min(panel + 3, pend - 1));
-            RIME_CON(buf1);
+            if (panel + 2 < pend) generate(buf0, min(panel + 3, pend - 1));
+            contract(buf1);
         }
         __syncthreads();
     }
-#undef RIME_GEN
-#undef RIME_CON
 
     // epilogue: V[i,j] / scale -> the baseline slot(s) of pair (i,j) of this block's slab
     // ws[split][t][f][re|im][Nbl]: consecutive lanes (columns j) hit consecutive baseline slots, so
@@ -658,7 +526,12 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // fixed order and transposes into the result layout.
     float* dst = A.ws + (((size_t)split * A.Nt + t) * A.Nf + f) * 2 * A.Nbl;
     const float inv = 1.0f / scl;
-    const int col = lane & 31;
+    // (the three-row-tile self block is one register over its budget here: its epilogue re-derives the lane index from the
+    //  execution mask instead of keeping `lane & 31` / `lane >> 5` alive across the panel loop -- until round 5 that was 8 bytes
+    //  of scratch, a store before the loop and a load after it)
+    int elane = lane;
+    if constexpr (SH::SELF && SH::TI == 3) elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int col = elane & 31;
     RIME_MFMA_SETTLE();
     // the image buffers are free after the loop's last barrier: a private 32 x 33 float tile per wave
     // transposes the accumulators of diagonal-tile units (written and read by this wave only)
@@ -686,18 +559,18 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
             }
             if (is_diag<SH>(u >> 1)) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) tr[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 33 + col] = val[e];
+                for (int e = 0; e < 16; ++e) tr[((e & 3) + 8 * (e >> 2) + 4 * (elane >> 5)) * 33 + col] = val[e];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float tv = tr[col * 33 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)];
+                    const float tv = tr[col * 33 + (e & 3) + 8 * (e >> 2) + 4 * (elane >> 5)];
                     val[e] = im ? val[e] - tv : val[e] + tv;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * (elane >> 5);
                 const int i = ti * 32 + row, j = tj * 32 + col;      // indices inside group I / group J
                 const float v = val[e] * inv;
                 const int bd = A.pair_direct[i * MF_NA + j];
@@ -829,13 +702,8 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
     const int pp = lane & 7, ag = lane >> 3;
     constexpr int hf = W & 1;
     constexpr int NGEN = 3;
-#if defined(RIME_LAB_PARITY_ROWS)      /* lab */
-    const int grow = (W >> 1) + 2 * ag;
-    const int nk = min(NGEN, (A.Nant - (W >> 1) + 15) / 16);
-#else
     const int grow = 8 * (W >> 1) + 2 * (ag & 3) + (ag >> 2);     // row inside a sweep of 16: one octet per wave pair
     const int nk = min(NGEN, (A.Nant - 8 * (W >> 1) + 15) / 16);  // uniform: 37 antennas -> 3 sweeps (waves 0, 1), 2 (waves 2, 3)
-#endif
     double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
     for (int u = 0; u < NGEN; ++u) {
@@ -884,27 +752,11 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
 #pragma unroll
         for (int u = 0; u < NGEN; ++u) {
             if (u < nk) {
-#if defined(RIME_LAB_FWD_CHEAP)    /* lab, TIMING ONLY: 3 of 4 channels pay 4 plain instructions per phasor (a stand-in for E *= D) */
-                float s0, c0, s1, c1;
-                if ((f & 3) != 0) {
-                    const float q = (float)sx.x, r_ = (float)sy.y;
-                    const float a_ = fmaf(q, 0.37f + u, r_), b_ = fmaf(r_, 0.11f, q);
-                    c0 = fmaf(a_, b_, q); s0 = fmaf(b_, q, a_); c1 = fmaf(a_, q, b_); s1 = fmaf(b_, r_, a_);
-                    c0 = fmaf(c0, s1, a_); s0 = fmaf(s0, c1, b_); c1 = fmaf(c1, s0, a_); s1 = fmaf(s1, c0, b_);
-                } else {
-                    const double ph0 = phase3(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
-                    const double ph1 = phase3(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
-                    const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
-                    s0 = __builtin_amdgcn_sinf(r0); c0 = __builtin_amdgcn_cosf(r0);
-                    s1 = __builtin_amdgcn_sinf(r1); c1 = __builtin_amdgcn_cosf(r1);
-                }
-#else
                 const double ph0 = phase3(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
                 const double ph1 = phase3(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
                 const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
                 const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                 const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
-#endif
                 uint32_t rh, rl, ih, il;
                 split2(w0 * c0, w1 * c1, rh, rl);
                 split2(w0 * s0, w1 * s1, ih, il);
@@ -948,16 +800,9 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
             //  step: 8 v_pk_mul_f16 per K step less on the waves that also carry the extra generation sweep)
             const uint4 Brh = ld(f0off), Bih = ld(f0off + 2 * MF_KP), Brl = ld(f0off + PK::IMG), Bil = ld(f0off + PK::IMG + 2 * MF_KP);
             const uint4 Lrh = sgn(Brh), Lih = sgn(Bih);
-#if defined(RIME_LAB_PK_HALF)      /* lab: the halved fragments of the generic kernel (acc3 stays zero) */
-            const uint4 Hr = half_frag(Lrh), Hi = half_frag(Lih);
-            acc0 = RIME_MFMA(Hr, Brh, acc0);
-            acc1 = RIME_MFMA(Lrh, Bih, acc1);
-            acc0 = RIME_MFMA(Hi, Bih, acc0);
-#else
             acc3 = RIME_MFMA(Lrh, Brh, acc3);
             acc1 = RIME_MFMA(Lrh, Bih, acc1);
             acc3 = RIME_MFMA(Lih, Bih, acc3);
-#endif
             acc2 = RIME_MFMA(Lih, Brl, acc2);
             acc0 = RIME_MFMA(Lrh, Brl, acc0);
             acc1 = RIME_MFMA(Lrh, Bil, acc1);
@@ -1095,341 +940,6 @@ fringe_ant_fwd_packed_kernel(AntArgs A)
     }
 }
 
-
-#if defined(RIME_BUILD_FWD_V2)
-// ---------------------------------------------------------------------------------------
-// forward kernel, second form (97..128 antennas, one diagonal block): generation hidden under the MFMAs
-// -- A MEASURED DEAD END, compiled only with -DRIME_BUILD_FWD_V2 (tools/fringe_mfma_lab.hip): at the C4 lab
-// shape 10.0 ms (non-negative sky) / 10.6 ms (signed) against 9.7 / 9.8 ms of the first form
-// (profiles/r02/lab_fwd_v2.txt).  Why: generation is ~33 issue cycles of VALU per MFMA at 128 antennas (f64
-// phase FMAs, fract, convert and sin / cos take 8 issue cycles each), an MFMA leaves 24 of its 32 cycles to
-// the wave's other instructions, so the issue port (8 + 33 per MFMA), not the matrix pipe, paces either
-// form; the first form's two co-resident 4-wave blocks de-phase by themselves and lose nothing to it.
-//
-// In the kernel above a wave alternates a generation phase (VALU only) with a contraction phase (MFMA +
-// LDS reads only); VALU and MFMA instructions of DIFFERENT waves do not overlap on a SIMD, so the kernel
-// costs (MFMA issue) + (VALU issue): 1600 + ~1400 cycles per 32-pixel panel and SIMD at 128 antennas.
-// Inside ONE wave, however, an MFMA holds the issue port for 8 of its 32 cycles: ~5-6 plain VALU
-// instructions issued behind it are (nearly) free.  This form makes every wave's instruction stream
-// "MFMA, a few VALU of the NEXT panel's generation, MFMA, ...":
-//   * 8 waves per block, one block per CU, TILE-PER-WAVE deal: waves 0-5 own one off-diagonal tile
-//     each (12 MFMAs per K step, 3 accumulators), waves 6 and 7 two diagonal tiles each (14 MFMAs,
-//     6 accumulators); SIMD partners (w, w + 4) carry 24 / 24 / 26 / 26 MFMAs.  48..96 accumulator
-//     registers instead of 160 leave room for the generation state of the interleaved stream (the
-//     4-wave deal spilled when interleaved);
-//   * one loop body per panel holds the fragment reads + MFMAs of panel k AND the generation (phase,
-//     sin / cos, weight, hi/lo split, LDS writes) of panel k + 1 into the other LDS buffer, plus the
-//     pixel fetch of panel k + 2; __builtin_amdgcn_sched_group_barrier pins the interleave
-//     (1 MFMA : 6 VALU : LDS / VMEM as available);
-//   * LDS images, fragment addressing, sign masks, diagonal-tile symmetry and the epilogue are those
-//     of the first form.
-// ---------------------------------------------------------------------------------------
-struct V2 {
-    static constexpr int ROWS = 128, NW = 8, GROWS = 64, GEN = 2;
-    static constexpr int IMG = ROWS * MF_ROWB, BUF = 2 * IMG + 64;
-    static constexpr size_t LDS = 2 * (size_t)BUF;
-};
-
-template <int W, bool SIGNED>
-__device__ __forceinline__ void ant_fwd_v2_body(const AntArgs& A, unsigned char* smem)
-{
-    constexpr bool DIAG = W >= 6;
-    // off-diagonal waves: tile (TI, TJ); diagonal waves: tiles (TI, TI) and (TI + 1, TI + 1)
-    constexpr int TI = W < 3 ? 0 : (W < 5 ? 1 : (W == 5 ? 2 : (W == 6 ? 0 : 2)));
-    constexpr int TJ = W < 3 ? W + 1 : (W < 5 ? W - 1 : (W == 5 ? 3 : TI));
-    constexpr int NTW = DIAG ? 2 : 1;                 // tiles of this wave
-    constexpr int MF_IMG = V2::IMG, MF_BUF = V2::BUF;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int f = __builtin_amdgcn_readfirstlane(blockIdx.x % A.Nf), ts = blockIdx.x / A.Nf;
-    const int t = __builtin_amdgcn_readfirstlane(ts / A.S), split = __builtin_amdgcn_readfirstlane(ts % A.S);
-
-    const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
-    const float scl = A.scale[t * A.Nf + f];
-    const float* arow = A.psky + (size_t)t * A.st_t + (size_t)f * A.st_f;
-    const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
-    const int st_p = __builtin_amdgcn_readfirstlane((int)A.st_p);
-
-    const int pp = lane & 7, ag = lane >> 3;
-    const int grow = 2 * ag + 16 * (W & 3) + (W >> 2);
-    double ax[V2::GEN], ay[V2::GEN], az[V2::GEN];
-#pragma unroll
-    for (int u = 0; u < V2::GEN; ++u) {
-        const int an = V2::GROWS * u + grow;
-        const bool ok = an < A.Nant;
-        ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
-        ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
-        az[u] = ok ? nu_c * A.antpos[3 * an + 2] : 0.0;
-    }
-    const int goff = grow * MF_ROWB + pp * 4;
-
-    // per tile: real part, imaginary part (off-diagonal tiles: two products, subtracted in the epilogue;
-    // diagonal tiles: one accumulator fed with a negated Li fragment -- two tiles per wave must fit the registers)
-    constexpr int NACC = DIAG ? 2 : 3;
-    f32x16 acc[NTW][NACC];
-#pragma unroll
-    for (int q = 0; q < NTW; ++q)
-#pragma unroll
-        for (int r = 0; r < NACC; ++r)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[q][r][e] = 0.f;
-
-    const int npanel = A.Pstride / MF_KP;
-    const int pbeg = __builtin_amdgcn_readfirstlane(split * A.panels_per_split);
-    const int pend = __builtin_amdgcn_readfirstlane(min(npanel, pbeg + A.panels_per_split));
-    if (pbeg >= pend) return;
-
-    double2 sx[MF_NH], sy[MF_NH], sz[MF_NH]; float2 av[MF_NH];
-    const uint32_t lo_s = 16u * pp, lo_a0 = 8u * pp * (uint32_t)st_p, lo_a1 = lo_a0 + 4u * (uint32_t)st_p;
-    const double* sdy = sd + A.Pstride;
-    const double* sdz = sd + 2 * (size_t)A.Pstride;
-    auto fetch = [&](int panel, int hf) {
-        const int p0 = panel * MF_KP + 16 * hf;
-        sx[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sd + p0) + lo_s);
-        sy[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sdy + p0) + lo_s);
-        sz[hf] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(sdz + p0) + lo_s);
-        const char* ab = reinterpret_cast<const char*>(arow + (size_t)p0 * st_p);
-        av[hf] = make_float2(*reinterpret_cast<const float*>(ab + lo_a0), *reinterpret_cast<const float*>(ab + lo_a1));
-    };
-    auto generate = [&](unsigned char* buf, int next_panel) {          // prologue only (first panel of the block)
-#pragma unroll
-        for (int hf = 0; hf < MF_NH; ++hf) {
-            const float w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
-            if (SIGNED && tid < 8)
-                *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
-                    ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
-#pragma unroll
-            for (int u = 0; u < V2::GEN; ++u) {
-                const double ph0 = phase3(ax[u], sx[hf].x, ay[u], sy[hf].x, az[u], sz[hf].x);
-                const double ph1 = phase3(ax[u], sx[hf].y, ay[u], sy[hf].y, az[u], sz[hf].y);
-                const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
-                const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
-                const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
-                uint32_t rh, rl, ih, il;
-                split2(w0 * c0, w1 * c1, rh, rl);
-                split2(w0 * s0, w1 * s1, ih, il);
-                unsigned char* o = buf + goff + u * V2::GROWS * MF_ROWB + 32 * hf;
-                *reinterpret_cast<uint32_t*>(o) = rh;
-                *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
-                *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
-                *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
-            }
-            fetch(next_panel, hf);
-        }
-    };
-
-    const int foff = (lane & 31) * MF_ROWB + (lane >> 5) * 16;
-    constexpr int NM = (DIAG ? 14 : 12) * MF_NH;      // MFMAs of one loop body
-
-    // ---- one loop body: contraction of the panel in `cb` with the generation of the next panel into
-    // `gb` (GEN) placed chunk by chunk behind the MFMAs; sched_barrier fences keep the hand-made order
-    // (the compiler still allocates registers and places the waits).  Generation = 4 (half panel, antenna)
-    // pairs of 2 pixels x 6 chunks: phase of pixel 0 | phase of pixel 1 | fract + convert | sin / cos |
-    // real part: weight, split, store | imaginary part.  The pixel data of the panel after next are
-    // fetched as soon as the last phase of a half panel has consumed the registers.
-    double ph0, ph1; float r0 = 0.f, r1 = 0.f, s0 = 0.f, c0 = 0.f, s1 = 0.f, c1 = 0.f, w0 = 0.f, w1 = 0.f;
-    auto gen_chunk = [&](auto idx, unsigned char* gb, int fetch_panel) {
-        constexpr int IDX = decltype(idx)::value;
-        if constexpr (IDX >= 0 && IDX < 24) {
-            constexpr int pair = IDX / 6, c = IDX % 6, hf = pair >> 1, u = pair & 1;
-            if constexpr (c == 0) {
-                if constexpr (u == 0) {
-                    w0 = __builtin_amdgcn_sqrtf(fabsf(av[hf].x) * scl);
-                    w1 = __builtin_amdgcn_sqrtf(fabsf(av[hf].y) * scl);
-                    if (SIGNED && tid < 8)
-                        *reinterpret_cast<uint32_t*>(gb + 2 * MF_IMG + 4 * (8 * hf + pp)) =
-                            ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
-                }
-                ph0 = phase3(ax[u], sx[hf].x, ay[u], sy[hf].x, az[u], sz[hf].x);
-            } else if constexpr (c == 1) {
-                ph1 = phase3(ax[u], sx[hf].y, ay[u], sy[hf].y, az[u], sz[hf].y);
-                if constexpr (u == 1) fetch(fetch_panel, hf);      // this half panel's pixel registers are free now
-            } else if constexpr (c == 2) {
-                r0 = turn_frac(ph0);
-                r1 = turn_frac(ph1);
-            } else if constexpr (c == 3) {
-                s0 = __builtin_amdgcn_sinf(r0); c0 = __builtin_amdgcn_cosf(r0);
-                s1 = __builtin_amdgcn_sinf(r1); c1 = __builtin_amdgcn_cosf(r1);
-            } else if constexpr (c == 4) {
-                uint32_t rh, rl;
-                split2(w0 * c0, w1 * c1, rh, rl);
-                unsigned char* o = gb + goff + u * V2::GROWS * MF_ROWB + 32 * hf;
-                *reinterpret_cast<uint32_t*>(o) = rh;
-                *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
-            } else {
-                uint32_t ih, il;
-                split2(w0 * s0, w1 * s1, ih, il);
-                unsigned char* o = gb + goff + u * V2::GROWS * MF_ROWB + 32 * hf + 2 * MF_KP;
-                *reinterpret_cast<uint32_t*>(o) = ih;
-                *reinterpret_cast<uint32_t*>(o + MF_IMG) = il;
-            }
-        }
-    };
-#define RIME_FENCE() __builtin_amdgcn_sched_barrier(0)
-    auto body = [&](const unsigned char* cb, unsigned char* gb, int fetch_panel, auto do_gen) {
-        constexpr bool GEN = decltype(do_gen)::value;
-        auto frag = [&](int tile, int img, int im, int ks) {
-            return *reinterpret_cast<const uint4*>(cb + img * MF_IMG + tile * 32 * MF_ROWB + foff + im * 2 * MF_KP + 32 * ks);
-        };
-        auto sgn = [&](uint4 v, const uint4& sg) {
-            if constexpr (SIGNED) { v.x ^= sg.x; v.y ^= sg.y; v.z ^= sg.z; v.w ^= sg.w; }
-            return v;
-        };
-        // fragments of (tile q, K step ks): loaded one (q, ks) group ahead of their MFMAs
-        constexpr int NG = NTW * MF_NH;                   // fragment groups of the body
-        uint4 F[2][8];                                    // two groups in flight
-        uint4 sgm[2];
-        auto load_group = [&](auto gi) {
-            constexpr int g = decltype(gi)::value;
-            if constexpr (g < NG) {
-                constexpr int q = g % NTW, ks = g / NTW, sl = g & 1;
-                const int ti = TI + q, tj = DIAG ? TI + q : TJ;
-                if constexpr (SIGNED) sgm[sl] = *reinterpret_cast<const uint4*>(cb + 2 * MF_IMG + (2 * ks + (lane >> 5)) * 16);
-                F[sl][0] = frag(ti, 0, 0, ks); F[sl][1] = frag(ti, 0, 1, ks);
-                F[sl][4] = frag(tj, 0, 0, ks); F[sl][5] = frag(tj, 0, 1, ks);
-                F[sl][6] = frag(tj, 1, 0, ks); F[sl][7] = frag(tj, 1, 1, ks);
-                if constexpr (!DIAG) { F[sl][2] = frag(ti, 1, 0, ks); F[sl][3] = frag(ti, 1, 1, ks); }
-            }
-        };
-        constexpr int MPG = DIAG ? 7 : 12;                // MFMAs per fragment group
-        int chunk_dummy = 0; (void)chunk_dummy;
-        load_group(std::integral_constant<int, 0>{});
-        if constexpr (GEN) {                              // the first chunks cover the LDS latency of the first fragments
-            gen_chunk(std::integral_constant<int, 0>{}, gb, fetch_panel);
-            gen_chunk(std::integral_constant<int, 1>{}, gb, fetch_panel);
-        }
-        RIME_FENCE();
-        static_for<0, NG>([&](auto gi) {
-            constexpr int g = decltype(gi)::value, q = g % NTW, sl = g & 1;
-            uint4 Lrh = sgn(F[sl][0], sgm[sl]), Lih = sgn(F[sl][1], sgm[sl]);
-            uint4 Lrl, Lil, Hr, Hi, Ni;
-            if constexpr (DIAG) {
-                Hr = half_frag(Lrh); Hi = half_frag(Lih);
-                Ni = make_uint4(Lih.x ^ 0x80008000u, Lih.y ^ 0x80008000u, Lih.z ^ 0x80008000u, Lih.w ^ 0x80008000u);
-            }
-            else { Lrl = sgn(F[sl][2], sgm[sl]); Lil = sgn(F[sl][3], sgm[sl]); }
-            const uint4 &Brh = F[sl][4], &Bih = F[sl][5], &Brl = F[sl][6], &Bil = F[sl][7];
-            static_for<0, MPG>([&](auto mi) {
-                constexpr int m = decltype(mi)::value;
-                if constexpr (DIAG) {
-                    // Vr = A + A^T, A = (Lrh/2).Brh + (Lih/2).Bih + Lrh.Brl + Lih.Bil;  Vi = A - A^T, A = Lrh.Bih + Lrh.Bil - Lih.Brl
-                    if constexpr (m == 0) acc[q][0] = RIME_MFMA(Hr, Brh, acc[q][0]);
-                    if constexpr (m == 1) acc[q][1] = RIME_MFMA(Lrh, Bih, acc[q][1]);
-                    if constexpr (m == 2) acc[q][0] = RIME_MFMA(Hi, Bih, acc[q][0]);
-                    if constexpr (m == 3) acc[q][1] = RIME_MFMA(Ni, Brl, acc[q][1]);
-                    if constexpr (m == 4) acc[q][0] = RIME_MFMA(Lrh, Brl, acc[q][0]);
-                    if constexpr (m == 5) acc[q][1] = RIME_MFMA(Lrh, Bil, acc[q][1]);
-                    if constexpr (m == 6) acc[q][0] = RIME_MFMA(Lih, Bil, acc[q][0]);
-                } else {
-                    if constexpr (m == 0) acc[q][0] = RIME_MFMA(Lrh, Brh, acc[q][0]);
-                    if constexpr (m == 1) acc[q][1] = RIME_MFMA(Lrh, Bih, acc[q][1]);
-                    if constexpr (m == 2) acc[q][2] = RIME_MFMA(Lih, Brh, acc[q][2]);
-                    if constexpr (m == 3) acc[q][0] = RIME_MFMA(Lih, Bih, acc[q][0]);
-                    if constexpr (m == 4) acc[q][1] = RIME_MFMA(Lrh, Bil, acc[q][1]);
-                    if constexpr (m == 5) acc[q][2] = RIME_MFMA(Lih, Brl, acc[q][2]);
-                    if constexpr (m == 6) acc[q][0] = RIME_MFMA(Lrh, Brl, acc[q][0]);
-                    if constexpr (m == 7) acc[q][1] = RIME_MFMA(Lrl, Bih, acc[q][1]);
-                    if constexpr (m == 8) acc[q][2] = RIME_MFMA(Lil, Brh, acc[q][2]);
-                    if constexpr (m == 9) acc[q][0] = RIME_MFMA(Lih, Bil, acc[q][0]);
-                    if constexpr (m == 10) acc[q][0] = RIME_MFMA(Lrl, Brh, acc[q][0]);
-                    if constexpr (m == 11) acc[q][0] = RIME_MFMA(Lil, Bih, acc[q][0]);
-                }
-                if constexpr (m == 1) load_group(std::integral_constant<int, g + 1>{});     // next group's fragments
-                if constexpr (GEN) {
-                    // chunk schedule: 22 chunks (2 .. 23) over the NM MFMAs of the body
-                    constexpr int k = g * MPG + m;                       // MFMA number in the body
-                    constexpr int c_lo = 2 + (k * 22) / NM, c_hi = 2 + ((k + 1) * 22) / NM;
-                    static_for<c_lo, c_hi>([&](auto ci) { gen_chunk(ci, gb, fetch_panel); });
-                }
-                RIME_FENCE();
-            });
-        });
-    };
-#undef RIME_FENCE
-    using yes = std::true_type; using no = std::false_type;
-
-    unsigned char* const buf0 = smem;
-    unsigned char* const buf1 = smem + MF_BUF;
-#pragma unroll
-    for (int hf = 0; hf < MF_NH; ++hf) fetch(pbeg, hf);
-    generate(buf0, min(pbeg + 1, pend - 1));
-    __syncthreads();
-    int panel = pbeg;
-    // bodies with generation: two per trip (compile-time buffer addresses)
-    for (; panel + 2 < pend; panel += 2) {
-        body(buf0, buf1, panel + 2, yes{});
-        __syncthreads();
-        body(buf1, buf0, min(panel + 3, pend - 1), yes{});
-        __syncthreads();
-    }
-    if (panel + 1 < pend) {                           // two panels left: buf0 holds `panel`
-        body(buf0, buf1, pend - 1, yes{});
-        __syncthreads();
-        body(buf1, buf0, pend - 1, no{});
-    } else {
-        body(buf0, buf1, pend - 1, no{});             // one panel left
-    }
-    __syncthreads();
-
-    // epilogue (as the first form): V[i,j] / scale -> baseline slots of this block's slab
-    float* dst = A.ws + (((size_t)split * A.Nt + t) * A.Nf + f) * 2 * A.Nbl;
-    const float inv = 1.0f / scl;
-    const int col = lane & 31;
-    RIME_MFMA_SETTLE();
-    float* tr = reinterpret_cast<float*>(smem) + W * (32 * 33);
-#pragma unroll
-    for (int q = 0; q < NTW; ++q) {
-        const int ti = TI + q, tj = DIAG ? TI + q : TJ;
-#pragma unroll
-        for (int im = 0; im < 2; ++im) {
-            f32x16 val;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) val[e] = im ? (DIAG ? acc[q][1][e] : acc[q][1][e] - acc[q][NACC - 1][e]) : acc[q][0][e];
-            if constexpr (DIAG) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) tr[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 33 + col] = val[e];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float tv = tr[col * 33 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)];
-                    val[e] = im ? val[e] - tv : val[e] + tv;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int i = ti * 32 + row, j = tj * 32 + col;
-                const float v = val[e] * inv;
-                const int bd = A.pair_direct[i * MF_NA + j];
-                if (bd >= 0) dst[(size_t)im * A.Nbl + bd] = v;
-                const int bc = A.pair_conj[i * MF_NA + j];
-                if (bc >= 0) dst[(size_t)im * A.Nbl + bc] = im ? -v : v;
-            }
-        }
-    }
-}
-
-template <bool SIGNED>
-__global__ void __launch_bounds__(512, 2)
-fringe_ant_fwd_v2_kernel(AntArgs A)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    if (row_is_signed(A) != SIGNED) return;
-    switch (threadIdx.x >> 6) {
-        case 0: ant_fwd_v2_body<0, SIGNED>(A, smem); break;
-        case 1: ant_fwd_v2_body<1, SIGNED>(A, smem); break;
-        case 2: ant_fwd_v2_body<2, SIGNED>(A, smem); break;
-        case 3: ant_fwd_v2_body<3, SIGNED>(A, smem); break;
-        case 4: ant_fwd_v2_body<4, SIGNED>(A, smem); break;
-        case 5: ant_fwd_v2_body<5, SIGNED>(A, smem); break;
-        case 6: ant_fwd_v2_body<6, SIGNED>(A, smem); break;
-        default: ant_fwd_v2_body<7, SIGNED>(A, smem); break;
-    }
-}
-
-
-#endif  // RIME_BUILD_FWD_V2
-
 // ---------------------------------------------------------------------------------------
 // backward:  gpsky[t,f,p] = Re sum_{i,j} E_i(p) conj(E_j(p)) G[i,j]
 //                        = sum_i ( Er_i Tr_i + Ei_i Ti_i ),   T_i(p) = sum_j conj(G[i,j]) E_j(p)
@@ -1475,7 +985,7 @@ constexpr size_t MB_LDS = 6 * (size_t)MB_PLANE + MF_NA * 3 * sizeof(double);
 __device__ __forceinline__ int tri_index(int ti, int tj) { return ti * 4 - ti * (ti - 1) / 2 + (tj - ti); }
 
 // Staging of a diagonal block of the backward: antenna coordinates (x sign nu / c) and the six G planes in A-fragment order into
-// LDS (shared by the 8-wave kernel and the pipelined 4-wave kernel below; NT = threads of the block).
+// LDS (NT = threads of the block).
 template <bool CPLX, int NT>
 __device__ __forceinline__ void bwd_stage_diag(const AntBwdArgs& A, unsigned char* g_img, double* ant_lds, int t, int f, int TA, float& gs)
 {
@@ -1600,24 +1110,6 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                     uint4 Erh, Erl, Eih, Eil;
                     uint32_t* erh = reinterpret_cast<uint32_t*>(&Erh); uint32_t* erl = reinterpret_cast<uint32_t*>(&Erl);
                     uint32_t* eih = reinterpret_cast<uint32_t*>(&Eih); uint32_t* eil = reinterpret_cast<uint32_t*>(&Eil);
-#if defined(RIME_LAB_CHAIN)      /* lab, TIMING ONLY: antennas 4g + 1..3 by recurrence from antenna 4g */
-#pragma unroll
-                    for (int jq = 0; jq < 2; ++jq) {
-                        const int an = 32 * tj + 8 * (2 * ks + jq) + 4 * h;
-                        const double ph = phase3(ant_lds[3 * an], sx, ant_lds[3 * an + 1], sy, ant_lds[3 * an + 2], sz);
-                        const double pd = phase3(ant_lds[3 * an + 3], sx, ant_lds[3 * an + 4], sy, ant_lds[3 * an + 5], sz);
-                        const float rr = turn_frac(ph), rd = turn_frac(pd);
-                        float c = __builtin_amdgcn_cosf(rr), sn = __builtin_amdgcn_sinf(rr);
-                        const float dc = __builtin_amdgcn_cosf(rd), dsn = __builtin_amdgcn_sinf(rd);
-                        ec[8 * ks + 4 * jq] = c; es[8 * ks + 4 * jq] = sn;
-#pragma unroll
-                        for (int u = 1; u < 4; ++u) {
-                            const float nc = c * dc - sn * dsn, ns = c * dsn + sn * dc;
-                            c = nc; sn = ns;
-                            ec[8 * ks + 4 * jq + u] = c; es[8 * ks + 4 * jq + u] = sn;
-                        }
-                    }
-#else
 #pragma unroll
                     for (int jq = 0; jq < 2; ++jq) {
                         // the 8 antennas of this half K step (4 per half wave) are all padding: uniform skip -- 19 antennas
@@ -1628,19 +1120,6 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                             for (int u = 0; u < 4; ++u) { ec[8 * ks + 4 * jq + u] = 0.f; es[8 * ks + 4 * jq + u] = 0.f; }
                             continue;
                         }
-#if defined(RIME_LAB_BWD_CHEAP)   /* lab, TIMING ONLY: 3 of 4 channels pay 4 plain instructions per phasor (a stand-in for E *= D) */
-                        if ((f & 3) != 0) {
-                            const float q = (float)sx, r_ = (float)sy;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int jj = 4 * jq + u;
-                                const float a_ = fmaf(q, 0.37f + jj, r_), b_ = fmaf(r_, 0.11f + ks, q);
-                                ec[8 * ks + jj] = fmaf(a_, b_, q);
-                                es[8 * ks + jj] = fmaf(b_, q, a_);
-                            }
-                            continue;
-                        }
-#endif
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int jj = 4 * jq + u;
@@ -1651,7 +1130,6 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                             es[8 * ks + jj] = __builtin_amdgcn_sinf(rr);
                         }
                     }
-#endif
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         split2_plain(ec[8 * ks + 2 * q], ec[8 * ks + 2 * q + 1], erh[q], erl[q]);
@@ -1736,227 +1214,6 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
     }
 }
 
-
-// ---------------------------------------------------------------------------------------
-// backward, 97..128 antennas, real psky: SOFTWARE-PIPELINED form, one wave per SIMD  (round 4; RIME_BWD_PIPE)
-//
-// What the counters say about the kernel above at C4: matrix pipe busy 61 % + other VALU issue 38 % of the SIMD cycles =
-// 99 %: the two waves of a SIMD take turns, an MFMA of one wave and the VALU work of the OTHER never overlap
-// (profiles/r01/overlap_lab.txt), so a pixel tile costs (MFMA time) + (VALU time) = 216 x 32 + ~1160 x 4 cycles.  Inside ONE
-// wave, however, the ~4 instructions that follow an MFMA issue in its shadow (32x32x16: 1 MFMA + 4 independent VALU = 34
-// cycles instead of 32 + 16).  This form gives every SIMD ONE wave (4-wave blocks, the whole register file: the eight
-// accumulators live beside two operand sets) and orders the instruction stream itself: the E operands of K step k + 1
-// (phasors, hi / lo split) and the lane-local contraction of the row tile that completed last are placed between the MFMAs of
-// K step k, region by region (sched_barrier fences between regions, sched_group_barrier inside).  Same products in the same
-// order per accumulator as the kernel above: same bits.
-// ---------------------------------------------------------------------------------------
-#define RIME_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-
-template <int M, int Q>
-__device__ __forceinline__ void pipe_groups()
-{
-    // M x { 1 MFMA, Q VALU }: the scheduler fills each slot from the region's instructions (LDS reads and waits are placed by
-    // their dependences)
-    static_for<0, M>([&](auto) { RIME_SGB(0x008, 1); RIME_SGB(0x100, 1); RIME_SGB(0x002, Q); });
-}
-
-// the same with T transcendental instructions (v_sin / v_cos: ~11 cycles each, they hide only when spread) per MFMA
-template <int M, int T, int Q>
-__device__ __forceinline__ void pipe_groups_t()
-{
-    static_for<0, M>([&](auto) { RIME_SGB(0x008, 1); RIME_SGB(0x100, 1); RIME_SGB(0x400, T); RIME_SGB(0x002, Q); });
-}
-
-__global__ void __launch_bounds__(256, 1)
-fringe_ant_bwd_pipe_kernel(AntBwdArgs A)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* g_img = smem;              // planes: 0 Gr_hi, 1 Gi_hi, 2 -Gi_hi, 3 Gr_lo, 4 Gi_lo, 5 -Gi_lo
-    double* ant_lds = reinterpret_cast<double*>(smem + 6 * MB_PLANE);      // [128][3]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int f = blockIdx.x % A.Nf, ts = blockIdx.x / A.Nf;
-    const int t = ts / A.S, split = ts % A.S;
-    float gs;
-    bwd_stage_diag<false, 256>(A, g_img, ant_lds, t, f, 4, gs);
-    __syncthreads();
-
-    const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
-    float* orow = A.gpsky + (size_t)t * A.st_t + (size_t)f * A.st_f;
-    const float inv = 1.0f / gs;
-    const int h = lane >> 5;
-    const int ntile = A.Pstride / 32;
-    const int tbeg = split * A.tiles_per_split;
-    const int tend = min(ntile, tbeg + A.tiles_per_split);
-    if (tbeg + wave >= tend) return;          // no barrier follows
-
-    uint32_t gl0 = (h * 32 + (lane & 31)) * 16, gl1 = gl0 + 3 * MB_PLANE;
-    asm volatile("" : "+v"(gl1));             // opaque: keeps gl1 a second base register
-
-    float ec[4][16], es[4][16];               // E of the lane's 16 antennas of row tile tj: set tj
-    uint4 F[2][4];                            // Erh, Erl, Eih, Eil of K step q: buffer q & 1
-    uint4 G[2][6];                            // G fragments of a tile step, double buffered by step parity
-    double C[24];                             // antenna coordinates of the K step whose phases are computed next
-    float rr[8], rq[8];                       // reduced phases between the phase stage and the sin / cos stage (two K steps in flight)
-    f32x16 accR[1][4], accI[1][4];
-
-    // K steps (tj, ks) of a pixel tile in the order  (3,0) (0,0) (3,1) (0,1) (2,0) (1,0) (2,1) (1,1):  a step with many tiles
-    // (H: 45 or 33 MFMAs) is followed by one with few (L: 9 or 21), and the operand generation of BOTH following steps sits in
-    // the H step's region (the L step's region only finishes the sin / cos + split of the next H step), so that every region
-    // has 3 - 6 vector instructions per MFMA.  Stages of a K step: loadC (antenna coordinates from LDS), genP (phases, f64),
-    // genTS (sin / cos, hi / lo split -> F).
-    auto loadC = [&](auto tjc, auto ksc) {
-        constexpr int tj = decltype(tjc)::value, ks = decltype(ksc)::value;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int an = 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
-            C[3 * jj] = ant_lds[3 * an]; C[3 * jj + 1] = ant_lds[3 * an + 1]; C[3 * jj + 2] = ant_lds[3 * an + 2];
-        }
-    };
-    auto genP = [&](float (&r)[8], double sx, double sy, double sz) {
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
-            r[jj] = turn_frac(phase3(C[3 * jj], sx, C[3 * jj + 1], sy, C[3 * jj + 2], sz));
-    };
-    auto genTS = [&](auto tjc, auto ksc, auto bufc, const float (&r)[8]) {
-        constexpr int tj = decltype(tjc)::value, ks = decltype(ksc)::value, buf = decltype(bufc)::value;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            ec[tj][8 * ks + jj] = __builtin_amdgcn_cosf(r[jj]);
-            es[tj][8 * ks + jj] = __builtin_amdgcn_sinf(r[jj]);
-        }
-        uint32_t* erh = reinterpret_cast<uint32_t*>(&F[buf][0]); uint32_t* erl = reinterpret_cast<uint32_t*>(&F[buf][1]);
-        uint32_t* eih = reinterpret_cast<uint32_t*>(&F[buf][2]); uint32_t* eil = reinterpret_cast<uint32_t*>(&F[buf][3]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            split2_plain(ec[tj][8 * ks + 2 * q], ec[tj][8 * ks + 2 * q + 1], erh[q], erl[q]);
-            split2_plain(es[tj][8 * ks + 2 * q], es[tj][8 * ks + 2 * q + 1], eih[q], eil[q]);
-        }
-    };
-    // G fragments of one tile step (tj, ks, ti): six planes (diagonal tiles: four) through two lane bases + immediates
-    auto loadG = [&](auto tjc, auto ksc, auto tic, uint4 (&g)[6]) {
-        constexpr int tj = decltype(tjc)::value, ks = decltype(ksc)::value, ti = decltype(tic)::value;
-        constexpr int tk = ((ti * 4 - ti * (ti - 1) / 2 + (tj - ti)) * 2 + ks) * 1024;
-        g[0] = *reinterpret_cast<const uint4*>(g_img + gl0 + 0 * MB_PLANE + tk);       // Grh (diagonal: S hi)
-        g[1] = *reinterpret_cast<const uint4*>(g_img + gl1 + 0 * MB_PLANE + tk);       // Grl
-        g[2] = *reinterpret_cast<const uint4*>(g_img + gl0 + 2 * MB_PLANE + tk);       // Gnh (diagonal: A hi)
-        g[3] = *reinterpret_cast<const uint4*>(g_img + gl1 + 2 * MB_PLANE + tk);       // Gnl
-        if constexpr (ti != tj) {
-            g[4] = *reinterpret_cast<const uint4*>(g_img + gl0 + 1 * MB_PLANE + tk);   // Gih
-            g[5] = *reinterpret_cast<const uint4*>(g_img + gl1 + 1 * MB_PLANE + tk);   // Gil
-        }
-    };
-    // the MFMAs of the tile steps [T0, T1) of K step q = (tj, ks), E operands in F[q & 1]: tile (ti, tj) from the fragments the
-    // PREVIOUS tile step loaded, while the next one's are loaded (BASE = tile steps of the pixel tile before this K step: the
-    // buffer parity; (ntj, nks) = the K step that follows); the first K step starts the accumulators
-    auto mm = [&](auto parc, auto tjc, auto ksc, auto bufc, auto basec, auto t0c, auto t1c, auto ntjc, auto nksc) {
-        constexpr int par = decltype(parc)::value;
-        constexpr int tj = decltype(tjc)::value, ks = decltype(ksc)::value, buf = decltype(bufc)::value;
-        constexpr int base = decltype(basec)::value, T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
-        constexpr bool first = tj == 3 && ks == 0;
-        const uint4 Erh = F[buf][0], Erl = F[buf][1], Eih = F[buf][2], Eil = F[buf][3];
-        f32x16 zero;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) zero[e] = 0.f;
-        static_for<T0, T1>([&](auto tic) {
-            constexpr int ti = decltype(tic)::value;
-            constexpr int cur = (base + ti) & 1, nxt = cur ^ 1;
-            if constexpr (ti < tj) loadG(tjc, ksc, std::integral_constant<int, ti + 1>{}, G[nxt]);
-            else loadG(ntjc, nksc, std::integral_constant<int, 0>{}, G[nxt]);
-            const uint4 Grh = G[cur][0], Grl = G[cur][1], Gnh = G[cur][2], Gnl = G[cur][3];
-            if constexpr (ti == tj) {                 // diagonal tile, symmetric form: 9 MFMAs
-                accR[par][ti] = RIME_MFMA(Grh, Erh, first ? zero : accR[par][ti]);
-                accI[par][ti] = RIME_MFMA(Grh, Eih, first ? zero : accI[par][ti]);
-                accI[par][ti] = RIME_MFMA(Gnh, Erh, accI[par][ti]);
-                accR[par][ti] = RIME_MFMA(Grh, Erl, accR[par][ti]);
-                accI[par][ti] = RIME_MFMA(Grh, Eil, accI[par][ti]);
-                accI[par][ti] = RIME_MFMA(Gnh, Erl, accI[par][ti]);
-                accR[par][ti] = RIME_MFMA(Grl, Erh, accR[par][ti]);
-                accI[par][ti] = RIME_MFMA(Grl, Eih, accI[par][ti]);
-                accI[par][ti] = RIME_MFMA(Gnl, Erh, accI[par][ti]);
-            } else {
-                const uint4 Gih = G[cur][4], Gil = G[cur][5];
-                accR[par][ti] = RIME_MFMA(Grh, Erh, first ? zero : accR[par][ti]);
-                accI[par][ti] = RIME_MFMA(Grh, Eih, first ? zero : accI[par][ti]);
-                accR[par][ti] = RIME_MFMA(Gih, Eih, accR[par][ti]);
-                accI[par][ti] = RIME_MFMA(Gnh, Erh, accI[par][ti]);
-                accR[par][ti] = RIME_MFMA(Grh, Erl, accR[par][ti]);
-                accI[par][ti] = RIME_MFMA(Grh, Eil, accI[par][ti]);
-                accR[par][ti] = RIME_MFMA(Gih, Eil, accR[par][ti]);
-                accI[par][ti] = RIME_MFMA(Gnh, Erl, accI[par][ti]);
-                accR[par][ti] = RIME_MFMA(Grl, Erh, accR[par][ti]);
-                accI[par][ti] = RIME_MFMA(Grl, Eih, accI[par][ti]);
-                accR[par][ti] = RIME_MFMA(Gil, Eih, accR[par][ti]);
-                accI[par][ti] = RIME_MFMA(Gnl, Erh, accI[par][ti]);
-            }
-        });
-    };
-    // row tile tj of accumulator set par is complete (last written a whole region ago): contract elements [e0, e1) with E_i of
-    // the same antennas into `acc`
-    auto contract = [&](auto parc, auto tjc, float& acc, int e0 = 0, int e1 = 16) {
-        constexpr int par = decltype(parc)::value, tj = decltype(tjc)::value;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (e >= e0 && e < e1) {
-                acc = fmaf(ec[tj][e], accR[par][tj][e], acc);
-                acc = fmaf(es[tj][e], accI[par][tj][e], acc);
-            }
-        }
-    };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
-#define RIME_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define RIME_IC(n) std::integral_constant<int, n>{}
-
-    int pt = tbeg + wave;
-    int p = pt * 32 + (lane & 31);
-    double sx = sd[p], sy = sd[A.Pstride + p], sz = sd[2 * (size_t)A.Pstride + p];
-    float part = 0.f;
-    const int plast = (tend - 1 - ((tend - 1 - (tbeg + wave)) & 3));            // this wave's last tile
-    // prologue: operands of the first K step (3,0), coordinates of the second (0,0), the first tile step's G fragments
-    loadC(I3{}, I0{}); genP(rr, sx, sy, sz); genTS(I3{}, I0{}, I0{}, rr); loadC(I0{}, I0{}); loadG(I3{}, I0{}, I0{}, G[0]);
-    using P = I0;
-    for (; pt < tend; pt += 4) {
-        // the next tile's pointing vector (the last tile re-reads its own: branch-free)
-        const int pn = min(pt + 4, plast) * 32 + (lane & 31);
-        const double nx = sd[pn], ny = sd[A.Pstride + pn], nz = sd[2 * (size_t)A.Pstride + pn];
-        part = 0.f;
-        // H region (K step q with 45 or 33 MFMAs): a) the whole operand generation of q + 1 (phases, sin / cos, split), then the
-        // coordinates of q + 2;  b) phases of q + 2.  L region (q + 1: 9 or 21 MFMAs): sin / cos + split of q + 2, coordinates of q + 3.
-        // q0 = (3,0)
-        RIME_FENCE(); mm(P{}, I3{}, I0{}, I0{}, RIME_IC(0), I0{}, I2{}, I0{}, I0{}); genP(rr, sx, sy, sz); genTS(I0{}, I0{}, I1{}, rr); loadC(I3{}, I1{});   pipe_groups_t<24, 1, 3>();
-        RIME_FENCE(); mm(P{}, I3{}, I0{}, I0{}, RIME_IC(0), I2{}, I4{}, I0{}, I0{}); genP(rq, sx, sy, sz);                                                  pipe_groups<21, 2>();
-        // q1 = (0,0)
-        RIME_FENCE(); mm(P{}, I0{}, I0{}, I1{}, RIME_IC(4), I0{}, I1{}, I3{}, I1{}); genTS(I3{}, I1{}, I0{}, rq); loadC(I0{}, I1{});                        pipe_groups_t<9, 2, 4>();
-        // q2 = (3,1)
-        RIME_FENCE(); mm(P{}, I3{}, I1{}, I0{}, RIME_IC(5), I0{}, I2{}, I0{}, I1{}); genP(rr, sx, sy, sz); genTS(I0{}, I1{}, I1{}, rr); loadC(I2{}, I0{});   pipe_groups_t<24, 1, 3>();
-        RIME_FENCE(); mm(P{}, I3{}, I1{}, I0{}, RIME_IC(5), I2{}, I4{}, I0{}, I1{}); genP(rq, sx, sy, sz);                                                  pipe_groups<21, 2>();
-        // q3 = (0,1)
-        RIME_FENCE(); mm(P{}, I0{}, I1{}, I1{}, RIME_IC(9), I0{}, I1{}, I2{}, I0{}); genTS(I2{}, I0{}, I0{}, rq); loadC(I1{}, I0{});                        pipe_groups_t<9, 2, 4>();
-        // q4 = (2,0)
-        RIME_FENCE(); mm(P{}, I2{}, I0{}, I0{}, RIME_IC(10), I0{}, I2{}, I1{}, I0{}); genP(rr, sx, sy, sz); genTS(I1{}, I0{}, I1{}, rr); loadC(I2{}, I1{});  pipe_groups_t<24, 1, 3>();
-        RIME_FENCE(); mm(P{}, I2{}, I0{}, I0{}, RIME_IC(10), I2{}, I3{}, I1{}, I0{}); genP(rq, sx, sy, sz);                                                 pipe_groups<9, 5>();
-        // q5 = (1,0): + the first half of the contraction of row tile 3 (complete since q2)
-        RIME_FENCE(); mm(P{}, I1{}, I0{}, I1{}, RIME_IC(13), I0{}, I2{}, I2{}, I1{}); genTS(I2{}, I1{}, I0{}, rq); loadC(I1{}, I1{}); contract(P{}, I3{}, part, 0, 8);  pipe_groups_t<21, 1, 4>();
-        // q6 = (2,1): + its second half
-        RIME_FENCE(); mm(P{}, I2{}, I1{}, I0{}, RIME_IC(15), I0{}, I2{}, I1{}, I1{}); genP(rr, sx, sy, sz); genTS(I1{}, I1{}, I1{}, rr); loadC(I3{}, I0{}); contract(P{}, I3{}, part, 8, 16);  pipe_groups_t<24, 1, 5>();
-        RIME_FENCE(); mm(P{}, I2{}, I1{}, I0{}, RIME_IC(15), I2{}, I3{}, I1{}, I1{}); genP(rq, nx, ny, nz);                                                 pipe_groups<9, 5>();
-        // q7 = (1,1): sin / cos + split of the next tile's q0 (into ec / es [3], contracted above), coordinates of its q1; row tile 2
-        // is complete since q6: its contraction
-        RIME_FENCE(); mm(P{}, I1{}, I1{}, I1{}, RIME_IC(18), I0{}, I2{}, I3{}, I0{}); genTS(I3{}, I0{}, I0{}, rq); loadC(I0{}, I0{}); contract(P{}, I2{}, part);  pipe_groups_t<21, 1, 6>();
-        RIME_FENCE();
-        RIME_MFMA_SETTLE();
-        contract(P{}, I1{}, part); contract(P{}, I0{}, part);
-        part += __shfl_xor(part, 32, 64);
-        if (h == 0) {
-            float* o = orow + (size_t)p * A.st_p;
-            *o = A.accumulate ? *o + part * inv : part * inv;
-        }
-        p = pn; sx = nx; sy = ny; sz = nz;
-    }
-#undef RIME_FENCE
-#undef RIME_IC
-}
 
 // Cross block of the backward (arrays with more than 128 antennas): rows i in group I (antpos rows
 // 0..127), columns j in group J (rows 128..255), all 16 tiles.  T_i = sum_j conj(G[i,j]) E_j as in
@@ -2286,15 +1543,6 @@ extern "C" size_t rime_fringe_ant_workspace(int Nbl, int Nt, int Nf, int Pstride
     return (size_t)S * Nbl * Nt * Nf * 2 * sizeof(float);
 }
 
-#if defined(RIME_BUILD_FWD_V2)
-// lab builds: RIME_MF_FWD_V2=1 selects the interleaved forward kernel for 97..128-antenna diagonal blocks
-static bool fwd_v2_enabled()
-{
-    static const int on = [] { const char* e = getenv("RIME_MF_FWD_V2"); return e ? atoi(e) : 0; }();
-    return on != 0;
-}
-#endif
-
 // RIME_FWD_PACKED=0: arrays of 33..48 antennas keep the generic two-tile forward kernel (A/B measurements; ops.py reads
 // the same variable for its count of executed MFMAs)
 static bool fwd_packed_enabled()
@@ -2307,13 +1555,6 @@ static bool fwd_packed_enabled()
 static bool bwd_small_enabled()
 {
     static const int on = [] { const char* e = getenv("RIME_BWD_SMALL"); return e ? atoi(e) : 1; }();
-    return on != 0;
-}
-
-// RIME_BWD_PIPE=1: 97..128 antennas, real psky: the software-pipelined one-wave-per-SIMD backward (lab until it pays)
-static bool bwd_pipe_enabled()
-{
-    static const int on = [] { const char* e = getenv("RIME_BWD_PIPE"); return e ? atoi(e) : 0; }();
     return on != 0;
 }
 
@@ -2404,13 +1645,6 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
             break;
         case 3: RIME_FWD_PAIR(3); break;
         default:
-#if defined(RIME_BUILD_FWD_V2)
-            if (fwd_v2_enabled()) {
-                hipLaunchKernelGGL((fringe_ant_fwd_v2_kernel<true>), grid, dim3(512), V2::LDS, st, A);
-                if (rowmin) hipLaunchKernelGGL((fringe_ant_fwd_v2_kernel<false>), grid, dim3(512), V2::LDS, st, A);
-                break;
-            }
-#endif
             RIME_FWD_PAIR(4);
             break;
     }
@@ -2513,10 +1747,6 @@ extern "C" int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cr
         else hipLaunchKernelGGL(fringe_ant_bwd_cross_kernel<false>, grid, dim3(512), MX_LDS, st, A);
     } else {
         const bool small = Nrows <= 64 && bwd_small_enabled();
-        if (!psky_complex && Nrows > 96 && bwd_pipe_enabled()) {
-            hipLaunchKernelGGL(fringe_ant_bwd_pipe_kernel, grid, dim3(256), MB_LDS, st, A);
-            return check_launch();
-        }
         if (psky_complex) {
             if (small) hipLaunchKernelGGL((fringe_ant_bwd_kernel<true, 2>), grid, dim3(512), MB_LDS, st, A);
             else hipLaunchKernelGGL((fringe_ant_bwd_kernel<true, 4>), grid, dim3(512), MB_LDS, st, A);

@@ -94,6 +94,33 @@ def test_no_packed_f32_reader_close_to_an_mfma(src):
     assert os.path.getmtime(os.path.join(obj, src + '.scan')) >= os.path.getmtime(os.path.join(obj, src + '.o'))
 
 
+def test_product_kernels_carry_no_laboratory_code_and_no_scratch():
+    """round 5: the product source of the matrix-core fringe kernels holds no RIME_LAB_* / RIME_ABL_* /
+    lab-only build switch, the shipped library no default-off kernel (pipelined backward, second forward form), and the
+    gfx950 assembly of THIS build of the two matrix-core sources uses no scratch memory (no spill in any kernel);
+    the laboratory side is a patch that still applies (tools/lab/)"""
+    import subprocess
+    src = open(os.path.join(ROOT, 'bayeslim_amd', 'csrc', 'fringe_mfma.hip')).read()
+    for word in ('RIME_LAB', 'RIME_ABL', 'RIME_BUILD_FWD_V2', 'RIME_PHASE_MAGIC', 'bwd_pipe', 'fwd_v2', '#if'):
+        assert word not in src, word
+    obj = os.path.join(ROOT, 'bayeslim_amd', 'lib', 'obj')
+    for name in ('fringe_mfma', 'alm'):
+        path = os.path.join(obj, name + '-hip-amdgcn-amd-amdhsa-gfx950.s')
+        if not os.path.exists(path):
+            subprocess.run(['make', '-C', os.path.join(ROOT, 'bayeslim_amd', 'csrc')], check=True, capture_output=True)
+        asm = open(path).read()
+        kernels = re.findall(r'\.amdhsa_kernel (\S+)', asm)
+        assert len(kernels) >= 10
+        assert not [k for k in kernels if 'pipe' in k or '_v2_' in k], kernels
+        assert not re.findall(r'^\s*scratch_(?:load|store)', asm, flags=re.M)
+        sizes = [int(x) for x in re.findall(r'\.amdhsa_private_segment_fixed_size (\d+)', asm)]
+        assert len(sizes) == len(kernels) and max(sizes) == 0, sizes
+    lib = open(os.path.join(ROOT, 'bayeslim_amd', 'lib', 'librime_hip.so'), 'rb').read()
+    assert b'fringe_ant_bwd_pipe_kernel' not in lib and b'fringe_ant_fwd_v2_kernel' not in lib
+    assert b'fringe_ant_bwd_kernel' in lib
+    subprocess.run([os.path.join(ROOT, 'tools', 'lab', 'make_lab_source.sh'), '--check'], check=True, capture_output=True)
+
+
 def test_packed_reader_scanner_finds_planted_hazards(tmp_path):
     """the scanner itself: a packed reader 9 wait states behind an MFMA is reported -- directly, through an
     accumulation-register copy, and across a loop back edge; the same reader behind an s_nop 15 margin is not"""

@@ -3,7 +3,7 @@
 // RIME_MF_FWD_V2=1 in the environment selects the interleaved forward kernel (fringe_mfma.hip, second form)
 #define RIME_BUILD_FWD_V2 1
 #include "../bayeslim_amd/csrc/fringe.hip"
-#include "../bayeslim_amd/csrc/fringe_mfma.hip"
+#include "bin/lab_src/fringe_mfma.hip"      // the LAB source: tools/lab/make_lab_source.sh (product file + tools/lab/fringe_mfma_lab.patch); build with -Ibayeslim_amd/csrc
 #include <vector>
 #include <random>
 #include <complex>

@@ -1,6 +1,10 @@
 #!/bin/bash
-# A/B of the pipelined backward (RIME_BWD_PIPE) on one box: correctness (bitwise vs the 8-wave kernel), then timing
+# Lab: A/B of the software-pipelined one-wave-per-SIMD backward (round 4, profiles/r04/lab_bwd_pipe.txt) on one box: agreement with
+# the shipped 8-wave kernel, then timing.  The kernel lives in the lab patch only: build the lab library first, here (CPU):
+#     tools/build_variant.sh lab ""
+# and run this through gpurun; RIME_BWD_PIPE=1 selects the kernel inside that library.
 cd $GRAFT_REPO_ROOT
+export RIME_LIB_PATH=$GRAFT_REPO_ROOT/tools/bin/librime_lab.so
 python - <<'E'
 import os, subprocess, sys, json
 code = '''
