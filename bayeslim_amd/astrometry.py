@@ -26,6 +26,7 @@ against astropy itself (absent here); pinned instead to SOFA's published known-a
 (tests/golden/sofa_vectors.json, tests/test_host_logic.py).
 """
 import math
+import re
 
 import numpy as np
 
@@ -274,25 +275,38 @@ class EarthOrientation:
         a = np.array(rows)
         return cls(a[:, 0], a[:, 1], a[:, 2], a[:, 3])
 
+    # a finals2000A row starts 'yymmdd MJD' in fixed columns (year, month, day two characters each, blank-padded): '17 5 1 57874.00'
+    _FINALS_DATE = re.compile(r'^[ \d]\d[ \d]\d[ \d]\d [ \d]\d{4}\.\d\d(?:\s|$)')
+
     @staticmethod
-    def _parse(line):
+    def _plausible(mjd, xp, yp, dut1):
+        """a row of Earth orientation data: a date of the space age, a pole within 2 arcsec, |UT1-UTC| within a second"""
+        return 30000.0 <= mjd <= 100000.0 and abs(xp) <= 2.0 and abs(yp) <= 2.0 and abs(dut1) <= 1.0
+
+    @classmethod
+    def _parse(cls, line):
         text = line.split('#')[0].rstrip('\n')
         if not text.strip():
             return None
-        if len(text) >= 68 and text[16:17] in ('I', 'P') and text[57:58] in ('I', 'P'):     # finals2000A
+        row = None
+        if cls._FINALS_DATE.match(text):                                                      # finals2000A
+            # the date-only rows that follow the last prediction carry no I / P flags and no values: no data (read as
+            # plain text their four tokens 'yy m d MJD' used to become a row at MJD 17, or made from_file fail: ADVICE r04)
+            if len(text) >= 68 and text[16:17] in ('I', 'P') and text[57:58] in ('I', 'P'):
+                try:
+                    row = float(text[7:15]), float(text[18:27]), float(text[37:46]), float(text[58:68])
+                except ValueError:
+                    row = None
+        else:
+            tok = text.split()
             try:
-                return float(text[7:15]), float(text[18:27]), float(text[37:46]), float(text[58:68])
+                if len(tok) >= 7 and all(t.lstrip('-').isdigit() for t in tok[:3]):            # EOP C04
+                    row = float(tok[3]), float(tok[4]), float(tok[5]), float(tok[6])
+                elif len(tok) >= 4:
+                    row = float(tok[0]), float(tok[1]), float(tok[2]), float(tok[3])
             except ValueError:
-                return None                                   # the rows past the last prediction are blank
-        tok = text.split()
-        try:
-            if len(tok) >= 7 and all(t.lstrip('-').isdigit() for t in tok[:3]):                # EOP C04
-                return float(tok[3]), float(tok[4]), float(tok[5]), float(tok[6])
-            if len(tok) >= 4:
-                return float(tok[0]), float(tok[1]), float(tok[2]), float(tok[3])
-        except ValueError:
-            pass
-        return None
+                row = None
+        return row if row is not None and cls._plausible(*row) else None
 
     def at(self, jd_utc):
         """(dut1 [s], xp [rad], yp [rad]) at a UTC Julian date"""

@@ -314,17 +314,25 @@ extern "C" int rime_interp_scatter_rows_bwd(int dtype, int is_complex, const voi
                                             const int* csr_ptr, const int* csr_src, const void* wgts, int R, int Npb,
                                             void* gm, void* stream)
 {
-    if (!gout || !csr_ptr || !csr_src || !wgts || !gm || R <= 0 || Npb <= 0 || gout_stride <= 0) return RIME_EINVAL;
+    // csr_src may be NULL when the index is EMPTY (every weight 0: csr_ptr is all zeros and no entry is read): the result is 0
+    if (!gout || !csr_ptr || !wgts || !gm || R <= 0 || Npb <= 0 || gout_stride <= 0) return RIME_EINVAL;
+    if (dtype != RIME_F32 && dtype != RIME_F64) return RIME_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     constexpr int RB = 8;
-    dim3 grid((Npb + 255) / 256, (R + RB - 1) / RB);
-    if (grid.y > 65535) return RIME_EUNSUPPORTED;
-#define RIME_SR(T, EW) hipLaunchKernelGGL((rime::scatter_rows_kernel<T, EW, RB>), grid, dim3(256), 0, st, (const T*)gout, gout_stride, \
-                                          csr_ptr, csr_src, (const T*)wgts, R, Npb, (T*)gm)
-    if (dtype == RIME_F32) { if (is_complex) RIME_SR(float, 2); else RIME_SR(float, 1); }
-    else if (dtype == RIME_F64) { if (is_complex) RIME_SR(double, 2); else RIME_SR(double, 1); }
-    else return RIME_EINVAL;
+    // rows beyond one grid's reach (65535 x RB) go to further launches on row-offset pointers (was RIME_EUNSUPPORTED)
+    const size_t esz = (dtype == RIME_F32 ? 4 : 8) * (is_complex ? 2 : 1);
+    const int chunk = 65535 * RB;
+    for (int r0 = 0; r0 < R; r0 += chunk) {
+        const int Rc = R - r0 < chunk ? R - r0 : chunk;
+        dim3 grid((Npb + 255) / 256, (Rc + RB - 1) / RB);
+        const char* gi = (const char*)gout + (size_t)r0 * (size_t)gout_stride * esz;
+        char* go = (char*)gm + (size_t)r0 * (size_t)Npb * esz;
+#define RIME_SR(T, EW) hipLaunchKernelGGL((rime::scatter_rows_kernel<T, EW, RB>), grid, dim3(256), 0, st, (const T*)gi, gout_stride, \
+                                          csr_ptr, csr_src, (const T*)wgts, Rc, Npb, (T*)go)
+        if (dtype == RIME_F32) { if (is_complex) RIME_SR(float, 2); else RIME_SR(float, 1); }
+        else { if (is_complex) RIME_SR(double, 2); else RIME_SR(double, 1); }
 #undef RIME_SR
+    }
     return rime::check_launch();
 }
 

@@ -122,6 +122,16 @@ class FringeGeometry:
             self.bl_order = torch.as_tensor(order, dtype=torch.int32, device=dev)
 
 
+def _env_int(name, default):
+    """C atoi() of an environment variable (leading integer, else 0), as csrc/ reads its switches"""
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    import re
+    m = re.match(r'\s*([+-]?\d+)', v)
+    return int(m.group(1)) if m else 0
+
+
 MFMA_MIN_ANTS = int(os.environ.get('RIME_MFMA_MIN_ANTS', '16'))   # 'auto' threshold (see _setup_antenna_path)
 MFMA_GROUP = 128          # antennas per group of the matrix-core path (4 x 4 tiles of 32)
 MFMA_MAX_ANTS = 2048      # table memory only: 136 blocks x 128 KB at 2048 antennas
@@ -130,7 +140,7 @@ MFMA_MAX_ANTS = 2048      # table memory only: 136 blocks x 128 KB at 2048 anten
 SELF_BLOCKS = os.environ.get('RIME_SELF_BLOCKS', '1') != '0'
 # arrays of 33..48 antennas: the forward kernel with the second row tile's re / im planes packed into one operand
 # (csrc/fringe_mfma.hip, fringe_ant_fwd_packed_kernel); RIME_FWD_PACKED=0 keeps the generic two-tile kernel (A/B)
-FWD_PACKED = os.environ.get('RIME_FWD_PACKED', '1') != '0'
+FWD_PACKED = _env_int('RIME_FWD_PACKED', 1) != 0         # parsed as the library parses it (atoi)
 
 
 def _group_capacity(n, group):
@@ -768,6 +778,10 @@ def stokes2coherency(I, frac):
         return None
     if frac.requires_grad or frac.dtype != I.dtype or frac.shape[0] != 3 or frac.device != I.device:
         return None
+    # axis 1 of `frac` is the singleton the reference keeps there; the axes behind it must line up ONE TO ONE with I's (a frac
+    # with fewer trailing axes would be left-padded by expand and could land its Q/U/V axis on I's channel axis: ADVICE r04)
+    if frac.dim() - 2 != I.dim() or frac.shape[1] != 1:
+        return None
     try:
         frb = frac.detach().reshape((3,) + tuple(frac.shape[2:])).expand((3,) + tuple(I.shape))
     except RuntimeError:
@@ -840,6 +854,8 @@ class _InterpGather(torch.autograd.Function):
                                                   R, st.Npb, _ptr(torch.view_as_real(gm) if ctx.cplx else gm), _stream())
             check(rc, 'rime_interp_scatter_rows_bwd')
             return gm, None, None
+        if st.csr_src.numel() == 0:                      # every weight 0: nothing reaches the map
+            return torch.zeros(ctx.shape, dtype=gout.dtype, device=gout.device), None, None
         # transposed working layout [pixel][row]: every read / write of the kernel is coalesced
         gT = gout.reshape(R, ctx.out_stride)[:, :st.P].t().contiguous()
         gmT = torch.empty((st.Npb, R), dtype=gout.dtype, device=gout.device)
@@ -1057,13 +1073,27 @@ ALM_PACKED = os.environ.get('RIME_ALM_PACKED', '1') != '0'      # cached pre-spl
 ALM_PACKED_MIN_BYTES = 1 << 24                                   # below 16 MB of Ylm the transform is launch-bound anyway
 
 
+# registry of the packed copies: id(Ylm tensor object) -> (weak reference to it, tag).  The copies are derived data that must
+# not travel with the tensor (a torch.cuda.Event cannot be pickled or deep-copied, and a tensor's __dict__ is): a pickled /
+# deep-copied model packs again on first use (round 5).  The weak reference's callback drops the entry -- and with it the two
+# buffers -- when the tensor object dies; a recycled id() is caught by comparing the referent.
+_YLM_PACKED = {}
+
+
+def ylm_packed_state(Ylm):
+    """the cache entry of this Ylm tensor OBJECT: (version, y_scale, data_ptr, {direction: (buffer, event, stream) | False}) or None"""
+    ent = _YLM_PACKED.get(id(Ylm))
+    return ent[1] if ent is not None and ent[0]() is Ylm else None
+
+
 def _ylm_packed(Ylm, Y, ys, direction):
     """
     The packed copy of Ylm for one direction (0 forward, 1 backward; include/rime_hip.h: rime_alm2pix_pack), built on
-    first use and remembered ON the Ylm tensor object together with its version counter and y_scale -- a different
-    tensor (AlmModel.setup_Ylm replaces it) or an in-place update packs again.  Returns None when packing is switched
+    first use and remembered FOR the Ylm tensor object (module registry keyed on the object, see above) together with its
+    version counter and y_scale -- a different tensor (AlmModel.setup_Ylm replaces it) or an in-place update packs again.
+    Returns None when packing is switched
     off, the matrix is small, or the GPU has no room for another copy (the unpacked kernels then run).
-    `Ylm` is the caller's tensor object (the cache lives on it), `Y` its contiguous detached alias.
+    `Ylm` is the caller's tensor object (the cache belongs to it), `Y` its contiguous detached alias.
 
     MEMORY: each direction keeps a buffer of Ylm's own size on the device (8 bytes per (coefficient, pixel)): a model that
     runs forward AND backward holds THREE times the matrix (C3: 3.3 GB -> 9.9 GB) until the Ylm tensor is released or
@@ -1071,16 +1101,19 @@ def _ylm_packed(Ylm, Y, ys, direction):
     slower at the C3 shape).  A copy is only made while the device has that much free memory + 1 GB, counting the blocks the
     caching allocator holds but does not use; a refusal is re-examined on later calls (not remembered for the life of the
     tensor).  The pack kernel runs on the stream that is current at first use; an event recorded behind it is kept with
-    the buffer and every later use on ANOTHER stream waits for it first.
+    the buffer, every later use on ANOTHER stream waits for it first and is recorded on the buffer (`record_stream`), so
+    that releasing the copy while that stream still reads it cannot hand the block to a new owner.
     """
     if not ALM_PACKED or Y.dtype != torch.complex64 or ys <= 0 or Y.numel() * 8 < ALM_PACKED_MIN_BYTES:
         return None
-    tag = getattr(Ylm, '_rime_packed', None)
+    tag = ylm_packed_state(Ylm)
     if tag is None or tag[0] != Ylm._version or tag[1] != ys or tag[2] != Y.data_ptr():
         tag = (Ylm._version, ys, Y.data_ptr(), {})
+        key = id(Ylm)
         try:
-            Ylm._rime_packed = tag
-        except Exception:
+            import weakref
+            _YLM_PACKED[key] = (weakref.ref(Ylm, lambda r, key=key: _YLM_PACKED.pop(key, None) if key in _YLM_PACKED and _YLM_PACKED[key][0] is r else None), tag)
+        except TypeError:
             return None
     entry = tag[3].get(direction)
     stream = torch.cuda.current_stream(Y.device)
@@ -1101,16 +1134,14 @@ def _ylm_packed(Ylm, Y, ys, direction):
     buf, ready, made_on = entry
     if made_on != stream.cuda_stream:
         stream.wait_event(ready)                         # packed on another stream: order this use behind the pack kernel
+        buf.record_stream(stream)                        # ... and keep the block from being re-used under this stream's kernels
     return buf
 
 
 def release_ylm_packed(Ylm):
     """drop the cached packed copies of `Ylm` (two buffers of its size; see _ylm_packed); they are rebuilt on the next use"""
-    if getattr(Ylm, '_rime_packed', None) is not None:
-        try:
-            del Ylm._rime_packed
-        except Exception:
-            Ylm._rime_packed = None
+    if ylm_packed_state(Ylm) is not None:
+        _YLM_PACKED.pop(id(Ylm), None)
 
 
 class _Alm2Pix(torch.autograd.Function):

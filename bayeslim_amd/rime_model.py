@@ -46,6 +46,18 @@ class RIME(utils.Module):
         self._ant_like = {}         # bl group -> first FringeGeometry built for it (shares its pair tables)
         self._mp_cache = {}         # bl group -> (modelpairs, pair index per baseline)
 
+    # derived state that is rebuilt on demand and must not travel with a pickled / deep-copied model (io.py:50-66 pickles whole
+    # models, optim.py:1517-1523 and notebook users deepcopy them): geometry entries hold ctypes tables and device buffers and
+    # are keyed on addresses (`data_ptr()`, `id()`) of the ORIGINAL's tensors -- in a copy those keys describe nothing
+    _DERIVED = ('_zenaz_cache', '_npix_cache', '_geom_cache', '_ant_like', '_mp_cache', '_inflate_cache', '_blnum_cache')
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in self._DERIVED:
+            if k in state:
+                state[k] = {}
+        return state
+
     def push(self, device):
         self.sim_blvec_groups = {k: v.to(device) for k, v in self.sim_blvec_groups.items()}
         if not isinstance(device, torch.dtype):

@@ -110,6 +110,16 @@ class AlmModel:
     def clear_Ylm_cache(self):
         self.Ylm_cache = {}
 
+    def __getstate__(self):
+        # pickle / deepcopy: the per-object conversion caches are keyed on id() of the ORIGINAL's Ylm tensors (and would carry
+        # a second copy of each matrix along); the copy converts again on first use.  Ylm_cache itself travels, as in the
+        # reference (sph_harm.py:1244-1581 keeps it on the object that io.write_pkl pickles)
+        state = dict(self.__dict__)
+        for k in ('_Ylm_pack_cache', '_Ylm_cast_cache', '_inflated'):
+            state.pop(k, None)
+        state['_inflated_key'] = None
+        return state
+
     def clear_multigrid(self):
         self.multigrid = None
         self._multigrid_idx = None

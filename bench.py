@@ -478,7 +478,9 @@ def supervise_modes(modes, worker_argv, rank, world, timeout, out=None, env=None
     """
     import signal
     import subprocess
+    import tempfile
     base_env = dict(os.environ if env is None else env)
+    prev_limit = 0.0
     agent_store = base_env.get('TORCHELASTIC_USE_AGENT_STORE') == 'True'
     base_port = int(base_env.get('MASTER_PORT', '29533'))
     if not agent_store and world == 1:
@@ -516,13 +518,35 @@ def supervise_modes(modes, worker_argv, rank, world, timeout, out=None, env=None
             done = [t for (_, rc_, _), t in zip(results, took) if rc_ == 0]
             if done and timeout is not None:
                 limit = min(timeout, max(180.0, 4.0 * max(done)))
+            # The limit runs from the moment the worker reports that its group has FORMED (it touches BENCH_READY_FILE after the
+            # first barrier), not from its start: a peer that hung in the previous mode is held there until ITS limit, while
+            # this rank's worker of that mode aborted on the collective watchdog long before -- the wait for the late peer at
+            # the next rendezvous must not eat the next mode's time.  Until the marker shows up the worker may
+            # wait for as long as a peer can still be held by the previous mode (+ the kill grace), then the limit applies anyway.
+            lag = 0.0 if k == 0 or timeout is None else max(0.0, prev_limit - took[-1]) + 30.0
+            ready = os.path.join(tempfile.gettempdir(), 'bench_ready_%d_%d_%s' % (os.getpid(), k, mode))
+            if os.path.exists(ready):
+                os.unlink(ready)
+            e['BENCH_READY_FILE'] = ready
+            prev_limit = limit if limit is not None else 0.0
             t0 = time.perf_counter()
             p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if rank == 0 else sys.stderr, start_new_session=True)
             current['p'] = p
-            try:
-                stdout, _ = p.communicate(timeout=limit)
-                rc = p.returncode
-            except subprocess.TimeoutExpired:
+            t_ready, stdout, rc = None, b'', None
+            while True:
+                try:
+                    stdout, _ = p.communicate(timeout=0.5)
+                    rc = p.returncode
+                    break
+                except subprocess.TimeoutExpired:
+                    now = time.perf_counter()
+                    if t_ready is None and os.path.exists(ready):
+                        t_ready = now
+                    if limit is None:
+                        continue
+                    if now > (t_ready if t_ready is not None else t0 + lag) + limit:
+                        break
+            if rc is None:
                 try:
                     os.killpg(p.pid, signal.SIGTERM)
                     try:
@@ -533,7 +557,10 @@ def supervise_modes(modes, worker_argv, rank, world, timeout, out=None, env=None
                     pass
                 stdout, _ = p.communicate()
                 rc = 124
-                sys.stderr.write('bench.py rank %d: shard mode %s did not finish within %s s; killed\n' % (rank, mode, limit))
+                sys.stderr.write('bench.py rank %d: shard mode %s did not finish within %s s of %s; killed\n'
+                                 % (rank, mode, limit, 'its rendezvous' if t_ready is not None else 'its start (+ %.0f s for late peers)' % lag))
+            if os.path.exists(ready):
+                os.unlink(ready)
             current['p'] = None
             obj = None
             for ln in (stdout or b'').decode(errors='replace').splitlines():
@@ -700,6 +727,8 @@ def main():
             raise SystemExit('bench.py: %d ranks joined, --gpus %d asked for' % (dist.get_world_size(), args.gpus))
         dist.barrier()
         collective_timeout = 600.0
+        if os.environ.get('BENCH_READY_FILE'):           # the supervisor's per-mode limit starts now (supervise_modes)
+            open(os.environ['BENCH_READY_FILE'], 'w').close()
 
     from bayeslim_amd import ops, dist as rdist
 

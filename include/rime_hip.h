@@ -234,7 +234,9 @@ int rime_interp_scatter_bwd(int dtype, int is_complex, const void* goutT,
                             int R, int Npb, int P, int Nnn, void* gmT, void* stream);
 /* The same adjoint for a ONE-NODE stencil (Nnn = 1: the FoV cut, cut_sky_fov beam_model.py:1681-1698, and the redundant
  * inflation, rime_model.py:436-437) on ROW-MAJOR buffers -- no transposed copies:
- *   gout T [R, gout_stride] (complex: [R, gout_stride, 2]), gm T [R, Npb]; csr_src holds point indices q, wgts T [P]. */
+ *   gout T [R, gout_stride] (complex: [R, gout_stride, 2]), gm T [R, Npb]; csr_src holds point indices q, wgts T [P].
+ *   Any R (rows beyond one grid's reach take further launches); an EMPTY index (csr_ptr all zero: every weight 0) may pass
+ *   csr_src = NULL and yields gm = 0. */
 int rime_interp_scatter_rows_bwd(int dtype, int is_complex, const void* gout, long long gout_stride,
                                  const int* csr_ptr, const int* csr_src, const void* wgts, int R, int Npb,
                                  void* gm, void* stream);

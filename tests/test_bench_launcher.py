@@ -116,6 +116,9 @@ WORKER_STUB = """
     what = behave.get(mode, 'ok')
     if what == 'crash':
         sys.exit(7)
+    if what.startswith('late'):                          # waits at its rendezvous for a peer held by the previous mode
+        time.sleep(float(what[4:]))
+        open(os.environ['BENCH_READY_FILE'], 'w').close()
     if what == 'hang':
         time.sleep(600)
     ms = dict(freq=10.0, bl=30.0)[mode] if 'blfast' not in behave else dict(freq=30.0, bl=10.0)[mode]
@@ -157,6 +160,19 @@ def test_supervisor_keeps_the_first_result_when_the_second_mode_crashes(tmp_path
 def test_supervisor_keeps_the_first_result_when_the_second_mode_hangs(tmp_path):
     rc, res = _supervise(tmp_path, 'bl=hang', timeout=8)
     assert rc == 0 and res['dist']['shard'] == 'freq' and res['alt'] == [dict(shard='bl', failed=124)]
+
+
+def test_supervisor_starts_a_modes_limit_at_its_rendezvous_not_at_its_start(tmp_path):
+    """a rank whose first-mode worker aborted early (here: crashed at once) starts the second mode minutes before
+    a peer that is still held by the first; its second worker then WAITS at the rendezvous.  That wait must not count
+    against the mode's limit: with an 8-s limit the worker that becomes ready after 12 s and then finishes is kept (the
+    old code killed it at 8 s); one that never becomes ready is still killed -- after limit + the time a peer can lag"""
+    rc, res = _supervise(tmp_path, 'freq=crash,bl=late12', timeout=8)
+    assert rc == 0 and res['dist']['shard'] == 'bl' and res['alt'] == [dict(shard='freq', failed=7)]
+    import time
+    t0 = time.perf_counter()
+    rc, res = _supervise(tmp_path, 'freq=crash,bl=hang', timeout=4)
+    assert rc != 0 and res is None and time.perf_counter() - t0 < 4 + (4 + 30) + 25
 
 
 def test_supervisor_reports_the_second_mode_when_the_first_fails(tmp_path):

@@ -652,7 +652,10 @@ def test_astrometry_with_earth_orientation_parameters_reproduces_sofa_atco13(tmp
     c04.write_text('  # header line\n' + ''.join('2013   4   %d  %d  %.6f  %.6f  %.7f  0.001 0.0 0.0 0.0 0.0\n' % ((r[0] % 30,) + r) for r in rows))
     finals = tmp_path / 'finals2000A.all'
     finals.write_text(''.join('13 4 2 %8.2f I %9.6f 0.000040 %9.6f 0.000030  I%10.7f 0.0000050' % r + ' ' * 100 + '\n' for r in rows)
-                      + ' ' * 7 + '%8.2f' % 99999.0 + ' ' * 170 + '\n')              # a trailing row without values
+                      + ' ' * 7 + '%8.2f' % 99999.0 + ' ' * 170 + '\n'               # a trailing row without values
+                      # the date-only rows a real finals2000A.all ends with (no flags, no values; single-digit month and day
+                      # give FOUR tokens, which the plain-text branch used to read as a row at MJD 17: ADVICE r04)
+                      + '17 5 1 57874.00' + ' ' * 170 + '\n' + '17 5 2 57875.00\n' + '171231 58118.00' + ' ' * 60 + '\n')
     frac = jd - 2400000.5 - mjd0
     want_dut1 = rows[1][3] + frac * (rows[2][3] - rows[1][3])
     want_xp = (rows[1][1] + frac * (rows[2][1] - rows[1][1])) * A.AS2R

@@ -1060,9 +1060,9 @@ def test_alm2pix_packed_ylm_equals_unpacked(ops, R, lmax, Npix, monkeypatch):
         x = a.to(torch.complex64).cuda().requires_grad_(True)
         y = ops.alm2pix(x, Yd)
         (y * gv.float().cuda()).sum().backward()
-        assert (getattr(Yd, '_rime_packed', None) is not None) == packed
+        assert (ops.ylm_packed_state(Yd) is not None) == packed
         if packed:
-            assert set(Yd._rime_packed[3]) == {0, 1} and all(b is not False for b in Yd._rime_packed[3].values())
+            assert set(ops.ylm_packed_state(Yd)[3]) == {0, 1} and all(b is not False for b in ops.ylm_packed_state(Yd)[3].values())
         res[packed] = (y.detach(), x.grad.detach())
         assert relmax(y, ref) < 1e-5 and relmax(x.grad, ar.grad) < 1e-5
     assert torch.equal(res[False][0], res[True][0])
@@ -1105,11 +1105,11 @@ def test_alm2pix_packed_ylm_is_repacked_when_ylm_changes(ops, monkeypatch):
     Y = torch.as_tensor(orc.sph_Ylm(th, ph, l, m)).to(torch.complex64).cuda()
     a = torch.as_tensor(rng.normal(size=(8, len(l))) + 1j * rng.normal(size=(8, len(l)))).to(torch.complex64).cuda()
     y1 = ops.alm2pix(a, Y)
-    first = Y._rime_packed[3][0]
-    assert ops.alm2pix(a, Y) is not None and Y._rime_packed[3][0] is first          # second call: the cached copy
+    first = ops.ylm_packed_state(Y)[3][0]
+    assert ops.alm2pix(a, Y) is not None and ops.ylm_packed_state(Y)[3][0] is first          # second call: the cached copy
     Y.mul_(2.0)                                                                   # in place: version counter moves
     y2 = ops.alm2pix(a, Y)
-    assert Y._rime_packed[3][0] is not first
+    assert ops.ylm_packed_state(Y)[3][0] is not first
     assert relmax(y2, 2.0 * y1) < 1e-6
     Y2 = (Y * 0.25).contiguous()                                                  # another tensor
     y3 = ops.alm2pix(a, Y2)
@@ -1124,7 +1124,7 @@ def test_alm2pix_packed_ylm_is_repacked_when_ylm_changes(ops, monkeypatch):
     assert relmax(A(a), 3.0 * o1) < 1e-6
     # explicit release (two buffers of Ylm's size per matrix) and use from another stream: the pack kernel's event orders it
     ops.release_ylm_packed(Y2)
-    assert getattr(Y2, '_rime_packed', None) is None
+    assert ops.ylm_packed_state(Y2) is None
     side = torch.cuda.Stream()
     y4 = ops.alm2pix(a, Y2)                                                       # packs on the current stream
     side.wait_stream(torch.cuda.current_stream())
