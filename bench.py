@@ -647,6 +647,61 @@ def selfcheck_reference(inp, dev, bls, sample, first_times):
         torch.set_default_dtype(old)
 
 
+OTHER_WORKLOADS = (('c3', []), ('c2', ['--steps', '20', '--warmup', '5']), ('c5', ['--nf', '64', '--steps', '3', '--warmup', '2']))
+
+
+def other_workloads(budget_s, timeout_each=150.0):
+    """
+    VERDICT r04 item 2: the driver's one command times BASELINE configs[3] (C4).  After its timed region and the CPU baseline,
+    OUTSIDE both, the N = 1 run also measures configs[2] (C3), configs[1] (C2) and ONE RANK'S SHARE of configs[4] (C5: 64 of
+    the 512 channels, the channel partition at N = 8) -- each in a fresh child process of this same script (the C4 model is
+    freed first; a crash or hang there cannot touch the line already measured), a few steps each, and attaches
+    {workload, ms_per_step, value, steps, kernels: {fwd, bwd: {frac, useful_frac_of_pipe_peak, ms_per_step}}} to the ONE JSON
+    line.  Stops starting new ones when `budget_s` is used up, so that the whole command stays within minutes.
+    """
+    import subprocess
+    out, t0 = [], time.perf_counter()
+    for wl, extra in OTHER_WORKLOADS:
+        left = budget_s - (time.perf_counter() - t0)
+        if left < 20.0:
+            out.append(dict(workload=wl, skipped='time budget of the default run used up'))
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--no-cpu-baseline', '--no-other-workloads'] + \
+              (extra if extra else ['--steps', '5', '--warmup', '3'])
+        t1 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=min(timeout_each, left + 10.0))
+            rc, txt = r.returncode, r.stdout.decode(errors='replace')
+        except subprocess.TimeoutExpired:
+            rc, txt = 124, ''
+        line = None
+        for ln in txt.splitlines():
+            try:
+                o = json.loads(ln)
+            except ValueError:
+                continue
+            if isinstance(o, dict) and 'ms_per_step' in o:
+                line = o
+        if rc != 0 or line is None:
+            out.append(dict(workload=wl, failed=rc))
+            continue
+        ks = (line.get('roofline') or {}).get('kernels') or {}
+        steps = line['steps']
+
+        def kern(prefix):
+            hit = [(k, v) for k, v in ks.items() if k.startswith(prefix)]
+            if not hit:
+                return None
+            k, v = max(hit, key=lambda kv: kv[1]['total_ms'])
+            return dict(kernel=k, frac=v.get('frac'), useful_frac_of_pipe_peak=v.get('useful_frac_of_pipe_peak'),
+                        ms_per_step=round(v['total_ms'] / steps, 4))
+        out.append(dict(workload=wl, desc=line['config']['workload'], ms_per_step=round(line['ms_per_step'], 4),
+                        value=line['value'], unit=line['unit'], steps=steps, warmup=line['warmup'],
+                        kernels=dict(fwd=kern('fringe_ant_fwd') or kern('fringe_fwd'), bwd=kern('fringe_ant_bwd') or kern('fringe_bwd')),
+                        wall_s=round(time.perf_counter() - t1, 1)))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -657,6 +712,10 @@ def main():
     ap.add_argument('--nt', type=int, default=None, help='time steps per step (minibatch)')
     ap.add_argument('--nf', type=int, default=None, help='override the number of channels (e.g. one rank\'s share of c5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-workloads', action='store_true',
+                    help='N = 1, default workload: skip the short runs of BASELINE configs 3, 2 and the config-5 rank share that '
+                         'follow the timed region and the CPU baseline (`other_workloads` in the JSON line); also skipped '
+                         'with --no-cpu-baseline (kernel measurements, profiler runs)')
     ap.add_argument('--redundant', action='store_true',
                     help='NOT the headline configuration: simulate one baseline per redundant group and inflate to all '
                          'baselines (the reference\'s data_bls mechanism); N = 1 only')
@@ -1069,6 +1128,14 @@ def main():
             out['speedup_vs_cpu_baseline'] = out['value'] / cb['value']
             if cb.get('value_prep_amortised'):
                 out['speedup_vs_cpu_prep_amortised'] = out['value'] / cb['value_prep_amortised']
+            if (args.workload == 'c4' and not args.nf and not args.nt and not args.redundant and not distributed
+                    and not args.no_other_workloads):
+                # outside the timed region and the CPU baseline; the C4 model is gone (run_mode freed it)
+                torch.cuda.empty_cache()
+                out['other_workloads'] = other_workloads(float(os.environ.get('BENCH_OTHER_BUDGET', '95')))
+                out['other_workloads_note'] = ('BASELINE configs 3, 2 and one rank\'s share of config 5 (64 of 512 channels), each a '
+                                               'short run of this script in a child process after the timed region and the CPU '
+                                               'baseline; frac = executed f16 MFMA flops / 2.5 PFLOP/s of the fringe kernel named')
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
         if selfcheck is not None and not selfcheck['ok']:

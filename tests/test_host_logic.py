@@ -214,6 +214,48 @@ def test_module_attr_protocol_and_pickle():
     copy.deepcopy(sky)
 
 
+def test_rime_and_almmodel_leave_their_derived_caches_behind_when_copied():
+    """host side of tests/test_objects_gpu.py: RIME.__getstate__ / AlmModel.__getstate__ -- the derived caches hold ctypes
+    tables, device buffers and entries keyed on addresses of the ORIGINAL's tensors; pickle and deepcopy must succeed with
+    such (unpicklable) content attached and hand over a model whose caches are empty (io.py:50-66, optim.py:1517-1523)"""
+    import ctypes
+    from bayeslim_amd import rime_model, telescope_model, beam_model, sph_harm
+    freqs = torch.linspace(120e6, 130e6, 4)
+    ants, vecs = utils._make_hex(2, D=14.6)
+    arr = telescope_model.ArrayModel(utils.AntposDict(ants, vecs), freqs=freqs)
+    tel = telescope_model.TelescopeModel((21.42827, -30.72148))
+    sky = sky_model.PointSky(torch.ones(1, 1, 2, 5), torch.zeros(2, 5),
+                             R=sky_model.PointSkyResponse(freqs, freq_mode='powerlaw', f0=freqs[0]), name='pts')
+    beam = beam_model.PixelBeam(torch.ones(1, 1, 1, 1, 1) * 14.0, freqs, R=beam_model.AiryResponse(powerbeam=True), pol='e',
+                                powerbeam=True, fov=180, parameter=False)
+    bls = arr.get_bls(uniq_bls=False, keep_autos=False)
+    rime = rime_model.RIME(sky, tel, beam, arr, bls, np.array([2459861.0, 2459861.01]), freqs)
+    unpicklable = ctypes.pointer(ctypes.c_int(3))
+    with pytest.raises(Exception):
+        pickle.dumps(unpicklable)
+    rime._geom_cache[('k', 1)] = dict(geom=unpicklable)
+    rime._ant_like[(0, 1)] = unpicklable
+    rime._inflate_cache = {0: (None, unpicklable)}
+    rime._blnum_cache = {0: (rime.data_bls, np.arange(3))}
+    rime._zenaz_cache[('pts', 5, 1.0)] = (None, (torch.zeros(5), torch.zeros(5)))
+    for cl in (pickle.loads(pickle.dumps(rime, protocol=4)), copy.deepcopy(rime)):
+        for k in rime_model.RIME._DERIVED:
+            assert getattr(cl, k) == {}, k
+        assert cl.sim_bls == rime.sim_bls and cl.Nbatch == rime.Nbatch and torch.equal(cl.sim_blvecs, rime.sim_blvecs)
+        assert cl.sky is not rime.sky and torch.equal(cl.sky.params, rime.sky.params)
+    assert len(rime._geom_cache) == 1 and rime._ant_like[(0, 1)] is unpicklable          # the original keeps its caches
+    lm = sph_harm.gen_lm(4)
+    A = sph_harm.AlmModel(lm[0], lm[1], real_output=True)
+    A.setup_Ylm(np.linspace(10, 80, 7), np.linspace(0, 300, 7), generate=True)
+    A._Ylm_cast_cache = {id(A.Ylm): (A.Ylm, 0, unpicklable)}
+    A._Ylm_pack_cache = {id(A.Ylm): (A.Ylm, 0, unpicklable)}
+    A._inflated, A._inflated_key = unpicklable, 123
+    for B in (pickle.loads(pickle.dumps(A, protocol=4)), copy.deepcopy(A)):
+        assert not hasattr(B, '_Ylm_cast_cache') and not hasattr(B, '_Ylm_pack_cache') and B._inflated_key is None
+        assert torch.equal(B.Ylm, A.Ylm) and len(B.Ylm_cache) == 1
+    assert A._inflated is unpicklable
+
+
 def test_sky_and_beam_responses_cpu_pieces():
     """elementwise responses are plain torch ops and may be evaluated anywhere"""
     g = load_golden('responses')
