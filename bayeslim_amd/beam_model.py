@@ -366,6 +366,15 @@ class PixelResponse(utils.PixInterp):
     def clear_beam_cache(self):
         self.beam_cache = None
 
+    def __getstate__(self):
+        # pickle / deepcopy: the forwarded map is a graph tensor of the LAST forward (the reference clears it through
+        # clear_graph_tensors before the next one, utils.py:1306-1320); a copy starts without it -- torch refuses to
+        # deep-copy a non-leaf tensor, and RIME.forward rebuilds the map at its start anyway
+        sup = getattr(super(), '__getstate__', None)
+        state = dict(sup()) if sup is not None else dict(self.__dict__)
+        state['beam_cache'] = None
+        return state
+
     def set_beam_cache(self, params):
         self.beam_cache = self.forward(params)
         return self.beam_cache
