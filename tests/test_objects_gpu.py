@@ -128,7 +128,7 @@ def test_rime_push_dtype_and_device_round_trips(ba, f32):
     torch.set_default_dtype(torch.float64)
     try:
         gw = dict(g)
-        for k in ('freqs', 'sky_params', 'beam_params'):
+        for k in ('freqs', 'sky_params', 'beam_params', 'px_area'):      # what the float32 model holds in float32
             gw[k] = np.asarray(g[k]).astype(np.float32).astype(np.float64)
         ref, sky_w, beam_w = _c2_setup(ba, gw)
         vw, gw_grads = _step(ref, params_of, g)
