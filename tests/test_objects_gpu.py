@@ -122,11 +122,12 @@ def test_rime_push_dtype_and_device_round_trips(ba, f32):
 
     push_all(torch.float64)
     assert rime._geom_cache == {} and rime.sky.params.dtype == torch.float64 and rime.beam.params.dtype == torch.float64
-    vis64, gr64 = _step(rime, params_of, g)
-    assert vis64.dtype == torch.complex128 and relmax(vis64, g['vis']) < 2e-6      # float32-ROUNDED inputs, float64 arithmetic
-    # the yardstick: a float64 model constructed from the float32-rounded channels and parameters
+    # the yardstick: a float64 model constructed from the float32-rounded channels and parameters.  Both run under a float64
+    # default dtype (as in the reference, tensors made from Python numbers inside a forward take the default dtype)
     torch.set_default_dtype(torch.float64)
     try:
+        vis64, gr64 = _step(rime, params_of, g)
+        assert vis64.dtype == torch.complex128 and relmax(vis64, g['vis']) < 2e-6      # float32-ROUNDED inputs, float64 arithmetic
         gw = dict(g)
         for k in ('freqs', 'sky_params', 'beam_params', 'px_area'):      # what the float32 model holds in float32
             gw[k] = np.asarray(g[k]).astype(np.float32).astype(np.float64)
