@@ -39,13 +39,13 @@ SIGNATURES = {
     'rime_fringe_ant_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp, _vp, _sz, _vp]),
     'rime_fringe_ant_bwd_workspace': (_sz, [_i, _i, _i]),
     'rime_fringe_ant_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp, _vp, _sz, _vp]),
-    'rime_fringe_ant_fwd_block': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
+    'rime_fringe_ant_fwd_block': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
                                        _i, _vp, _sz, _vp]),
     'rime_fringe_row_scale': (_i, [_vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp]),
     'rime_fringe_row_scale_cplx': (_i, [_vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp, _vp]),
     'rime_fringe_ant_fwd_finish': (_i, [_vp, _sz, _vp, _i, _i, _i, _i, _vp]),
     'rime_fringe_ant_bwd_prepare': (_i, [_vp, _i, _i, _i, _vp, _sz, _vp]),
-    'rime_fringe_ant_bwd_block': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
+    'rime_fringe_ant_bwd_block': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
                                        _i, _i, _vp, _vp, _sz, _vp]),
     'rime_gen_fringe': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rime_comm_unique_id': (_i, [_vp]),

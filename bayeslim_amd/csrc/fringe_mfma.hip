@@ -49,6 +49,9 @@ struct AntArgs {
     long long st_t, st_f, st_p;   // element strides of psky: time, channel, pixel (2 = one plane of a complex buffer)
     double sign;
     float imsign;              // complex single-pass blocks: +1, or -1 to contract with conj(psky) (swapped groups)
+    int mirror;                // diagonal blocks, real psky: bit g set = rows 16 g + 8 .. 16 g + 15 hold the MIRROR antennas of rows
+                               // 16 g .. 16 g + 7 (r' - c = -(r - c) about the centre the positions are measured from): their
+                               // phasors are the complex conjugates and are not evaluated again (round 5, see MIRROR PAIRS below)
 };
 
 __device__ __forceinline__ uint32_t pack_rtz(float a, float b)
@@ -142,6 +145,19 @@ __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_
 // with separate L/B images, rot90 on the fly and whole-tile deal: 13.4 ms; this kernel: 10.7 ms
 // (matrix pipe busy 46 -> 55 %, 39 % operand generation on the VALU, ~5 % idle).
 // ---------------------------------------------------------------------------------------
+// MIRROR PAIRS (round 5).  Operand generation is the part of both kernels that nothing hides, and its count was at
+// its minimum -- one phasor per (antenna, pixel, channel, time).  Arrays with point symmetry (hexagonal cores, grids, rings:
+// the layouts simulations are run on) have more structure: for two antennas with r' - c = -(r - c) the phasors are complex
+// conjugates, E' = conj(E), whatever the direction and the channel.  The host (ops._mirror_order) finds such pairs, measures the
+// block's positions from their common centre c (visibilities only see position differences) and orders the rows so that rows
+// 16 g + 8 + i hold the mirror antennas of rows 16 g + i (i < 8) for the 16-row groups g named in `mirror`; the kernels then
+// evaluate the first octet and write / use its conjugate for the second: the weighted f16 hi / lo halves of the real plane as
+// they are, those of the imaginary plane with the sign bits flipped (the split rounds toward zero: exact).  Groups without the
+// bit, and antennas without a partner (placed in such groups), are evaluated as before.  Forward: the sweeps of a wave pair
+// now walk the octets of ONE 16-row group (rows 32 (u >> 1) + 16 p + 8 (u & 1) + i instead of 16 u + 8 p + i: the same octets,
+// dealt differently), so that an odd sweep is the conjugate of the sweep before it in the same lanes.  Backward: the two
+// octets of a K step are the jq = 0 / 1 halves of the fragment a lane generates.  Timing-only bound before it was built
+// (every second octet conjugated): C4 83.5 -> 73.0 ms/step, C3 19.5 -> 17.7, C2 0.837 -> 0.773 (profiles/r05/mirror_bound.txt).
 constexpr int MF_KP = 32;                       // pixels per panel (one barrier per panel); 16 per MFMA
 constexpr int MF_NH = MF_KP / 16;               // 16-pixel K steps per panel
 constexpr int MF_ROWB = 4 * MF_KP + 16;         // [re KP x f16][im KP x f16][pad]: odd number of 16-B granules
@@ -280,13 +296,19 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // (round 4) the rows of a sweep are one OCTET per wave pair -- rows 16 u + 8 (W >> 1) + 2 (ag & 3) + (ag >> 2), conflict-free
     // ds_write_b32 as before -- instead of the rows of one parity: the sweeps a wave skips are then whole octets of padding,
     // 19 antennas cost 2 + 1 sweeps per wave pair instead of 2 + 2, 37 antennas 3 + 2 instead of 3 + 3 (same bits)
-    const int orow = 8 * (W >> 1) + 2 * (ag & 3) + (ag >> 2);
-    const int nk = (OCT && !OCT8) ? min(NGEN, (A.Nant - 8 * (W >> 1) + 15) / 16) : NGEN;     // uniform
+    // (round 5) ... and the sweeps of a wave pair p = W >> 1 walk the octets of ONE 16-row group after the other: sweep u = rows
+    // 32 (u >> 1) + 16 p + 8 (u & 1) + i (before: 16 u + 8 p + i -- the same octets, dealt differently: same bits), so that
+    // the mirror antennas of a sweep's rows (AntArgs.mirror) are the next sweep's rows of the same lanes
+    const int orow = 16 * (W >> 1) + 2 * (ag & 3) + (ag >> 2);
+    auto octet_row = [&](int u) { return 32 * (u >> 1) + 8 * (u & 1) + orow; };
+    // sweeps whose octet starts below Nant (monotone in u): uniform
+    const int mrow = A.Nant - 16 * (W >> 1);
+    const int nk = (OCT && !OCT8) ? min(NGEN, (max(mrow, 0) + 31) / 32 + (max(mrow - 8, 0) + 31) / 32) : NGEN;
     const int growx = SH::NW == 8 ? 2 * ag + 16 * ((W >> 1) & 1) + (W >> 2) : 2 * ag + (W >> 1);
     double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
     for (int u = 0; u < NGEN; ++u) {
-        const int an = OCT8 ? 32 * u + growx : OCT ? 16 * u + orow : (OCTX ? SWX * u + growx : SH::GROWS * u + grow);
+        const int an = OCT8 ? 32 * u + growx : OCT ? octet_row(u) : (OCTX ? SWX * u + growx : SH::GROWS * u + grow);
         const bool ok = an < A.Nant;
         ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
         ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
@@ -346,18 +368,25 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
             if (SIGNED && W < 2 && lane < 8)
                 *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
                     ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
+            uint32_t m_rh = 0, m_rl = 0, m_ih = 0, m_il = 0;      // the sweep before: an odd sweep of a mirror group is its conjugate
 #pragma unroll
             for (int u = 0; u < NGEN; ++u) {
                 if (u < nk) {
-                    const double ph0 = phase3(ax[u], sx[hf].x, ay[u], sy[hf].x, az[u], sz[hf].x);
-                    const double ph1 = phase3(ax[u], sx[hf].y, ay[u], sy[hf].y, az[u], sz[hf].y);
-                    const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
-                    const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
-                    const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
                     uint32_t rh, rl, ih, il;
-                    split2(w0 * c0, w1 * c1, rh, rl);
-                    split2(w0 * s0, w1 * s1, ih, il);
-                    unsigned char* o = buf + (OCT8 ? 32 * u + growx : 16 * u + orow) * MF_ROWB + pp * 4 + 32 * hf;
+                    // (uniform: the group of this wave pair's sweeps u - 1, u is 2 (u >> 1) + p)
+                    if (!OCT8 && (u & 1) && ((A.mirror >> (2 * (u >> 1) + (W >> 1))) & 1)) {
+                        rh = m_rh; rl = m_rl; ih = m_ih ^ 0x80008000u; il = m_il ^ 0x80008000u;
+                    } else {
+                        const double ph0 = phase3(ax[u], sx[hf].x, ay[u], sy[hf].x, az[u], sz[hf].x);
+                        const double ph1 = phase3(ax[u], sx[hf].y, ay[u], sy[hf].y, az[u], sz[hf].y);
+                        const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
+                        const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
+                        const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+                        split2(w0 * c0, w1 * c1, rh, rl);
+                        split2(w0 * s0, w1 * s1, ih, il);
+                    }
+                    if (!OCT8 && !(u & 1)) { m_rh = rh; m_rl = rl; m_ih = ih; m_il = il; }
+                    unsigned char* o = buf + (OCT8 ? 32 * u + growx : octet_row(u)) * MF_ROWB + pp * 4 + 32 * hf;
                     *reinterpret_cast<uint32_t*>(o) = rh;
                     *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
                     *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
@@ -702,12 +731,18 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
     const int pp = lane & 7, ag = lane >> 3;
     constexpr int hf = W & 1;
     constexpr int NGEN = 3;
-    const int grow = 8 * (W >> 1) + 2 * (ag & 3) + (ag >> 2);     // row inside a sweep of 16: one octet per wave pair
-    const int nk = min(NGEN, (A.Nant - 8 * (W >> 1) + 15) / 16);  // uniform: 37 antennas -> 3 sweeps (waves 0, 1), 2 (waves 2, 3)
+    // (round 5) first row tile: the two sweeps of a wave pair p are the two octets of ONE 16-row group (rows 16 p + 8 u + i; before:
+    // 16 u + 8 p + i), so that a mirror group's second octet is the conjugate of the sweep before it in the same lanes
+    // (AntArgs.mirror bit p); second row tile: rows 32 + 8 p + i as before (no mirror pairs there)
+    const int oct = 2 * (ag & 3) + (ag >> 2);                     // row inside an octet
+    auto sweep_row = [&](int u) { return u < 2 ? 16 * (W >> 1) + 8 * u + oct : 32 + 8 * (W >> 1) + oct; };
+    const int grow = 8 * (W >> 1) + oct;                          // row inside the second row tile's sweep of 16
+    // sweeps whose octet starts below Nant (monotone in u; uniform): 37 antennas -> 3 sweeps (waves 0, 1), 2 (waves 2, 3)
+    const int nk = (16 * (W >> 1) < A.Nant) + (16 * (W >> 1) + 8 < A.Nant) + (32 + 8 * (W >> 1) < A.Nant);
     double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
     for (int u = 0; u < NGEN; ++u) {
-        const int an = 16 * u + grow;
+        const int an = sweep_row(u);
         const bool ok = an < A.Nant;
         ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
         ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
@@ -749,19 +784,25 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
         if (SIGNED && W < 2 && lane < 8)
             *reinterpret_cast<uint32_t*>(buf + 2 * PK::IMG + 4 * (8 * hf + pp)) =
                 ((__float_as_uint(av.x) >> 16) & 0x8000u) | (__float_as_uint(av.y) & 0x80000000u);
+        uint32_t m_rh = 0, m_rl = 0, m_ih = 0, m_il = 0;          // sweep 0: sweep 1 of a mirror group is its conjugate
 #pragma unroll
         for (int u = 0; u < NGEN; ++u) {
             if (u < nk) {
-                const double ph0 = phase3(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
-                const double ph1 = phase3(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
-                const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
-                const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
-                const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
                 uint32_t rh, rl, ih, il;
-                split2(w0 * c0, w1 * c1, rh, rl);
-                split2(w0 * s0, w1 * s1, ih, il);
+                if (u == 1 && ((A.mirror >> (W >> 1)) & 1)) {          // uniform
+                    rh = m_rh; rl = m_rl; ih = m_ih ^ 0x80008000u; il = m_il ^ 0x80008000u;
+                } else {
+                    const double ph0 = phase3(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
+                    const double ph1 = phase3(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
+                    const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
+                    const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
+                    const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+                    split2(w0 * c0, w1 * c1, rh, rl);
+                    split2(w0 * s0, w1 * s1, ih, il);
+                }
+                if (u == 0) { m_rh = rh; m_rl = rl; m_ih = ih; m_il = il; }
                 if (u < 2) {
-                    unsigned char* o = buf + (16 * u + grow) * PK::ROWB0 + pp * 4 + 32 * hf;
+                    unsigned char* o = buf + sweep_row(u) * PK::ROWB0 + pp * 4 + 32 * hf;
                     *reinterpret_cast<uint32_t*>(o) = rh;
                     *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
                     *reinterpret_cast<uint32_t*>(o + PK::IMG) = rl;
@@ -976,6 +1017,7 @@ struct AntBwdArgs {
     long long st_t, st_f, st_p;
     double sign;
     float imsign;              // complex psky: sign of the imaginary-plane gradient (-1: block contracted conj(psky))
+    int mirror;                // as in AntArgs: bit g = (row tile, K step) whose second octet is the conjugate of its first
 };
 
 constexpr int MB_TILES = 10;                        // upper-triangular 32x32 tiles of a 128x128 matrix
@@ -1110,6 +1152,10 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                     uint4 Erh, Erl, Eih, Eil;
                     uint32_t* erh = reinterpret_cast<uint32_t*>(&Erh); uint32_t* erl = reinterpret_cast<uint32_t*>(&Erl);
                     uint32_t* eih = reinterpret_cast<uint32_t*>(&Eih); uint32_t* eil = reinterpret_cast<uint32_t*>(&Eil);
+                    // mirror group (round 5, MIRROR PAIRS at the top of the file): the second octet of this K step holds the mirror
+                    // antennas of the first -- conjugate phasors, not evaluated again, and their f16 halves are those of the
+                    // first octet with the imaginary plane's sign bits flipped (uniform branch)
+                    const bool mir = (A.mirror >> (2 * tj + ks)) & 1;
 #pragma unroll
                     for (int jq = 0; jq < 2; ++jq) {
                         // the 8 antennas of this half K step (4 per half wave) are all padding: uniform skip -- 19 antennas
@@ -1118,6 +1164,11 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                         if (32 * tj + 16 * ks + 8 * jq >= A.Nant) {
 #pragma unroll
                             for (int u = 0; u < 4; ++u) { ec[8 * ks + 4 * jq + u] = 0.f; es[8 * ks + 4 * jq + u] = 0.f; }
+                            continue;
+                        }
+                        if (jq == 1 && mir) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { ec[8 * ks + 4 + u] = ec[8 * ks + u]; es[8 * ks + 4 + u] = -es[8 * ks + u]; }
                             continue;
                         }
 #pragma unroll
@@ -1131,9 +1182,22 @@ fringe_ant_bwd_kernel(AntBwdArgs A)
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < 2; ++q) {
                         split2_plain(ec[8 * ks + 2 * q], ec[8 * ks + 2 * q + 1], erh[q], erl[q]);
                         split2_plain(es[8 * ks + 2 * q], es[8 * ks + 2 * q + 1], eih[q], eil[q]);
+                    }
+                    if (mir && 32 * tj + 16 * ks + 8 < A.Nant) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            erh[q + 2] = erh[q]; erl[q + 2] = erl[q];
+                            eih[q + 2] = eih[q] ^ 0x80008000u; eil[q + 2] = eil[q] ^ 0x80008000u;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 2; q < 4; ++q) {
+                            split2_plain(ec[8 * ks + 2 * q], ec[8 * ks + 2 * q + 1], erh[q], erl[q]);
+                            split2_plain(es[8 * ks + 2 * q], es[8 * ks + 2 * q + 1], eih[q], eil[q]);
+                        }
                     }
 #pragma unroll
                     for (int ti = 0; ti < TAMAX; ++ti) {
@@ -1588,7 +1652,7 @@ static void launch_fwd_cross(const AntArgs& A, dim3 grid, hipStream_t st, bool h
     if (has_rowmin) hipLaunchKernelGGL((fringe_ant_fwd_cross_kernel<TI, TJ, false, false>), grid, dim3(SH::NW * 64), SH::LDS, st, A);
 }
 
-extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
+extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, int mirror, const double* sdir,
                                          const double* freqs, const float* psky, const float* scale,
                                          const float* rowmin, const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf,
                                          int Pstride, long long st_t, long long st_f, long long st_p, int sign,
@@ -1602,6 +1666,10 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
     A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.vis = nullptr; A.ws = (float*)workspace;
     A.Nant = Nrows; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
     A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign; A.imsign = psky_complex < 0 ? -1.f : 1.f;
+    // mirror groups: diagonal blocks on a real plane, shapes whose generation walks octet pairs (1, 2, 4 row tiles; the packed
+    // shape: first row tile only); anything else evaluates every row (the mask is a licence, not an obligation)
+    if (mirror < 0 || (Nrows > 0 && Nrows <= MF_NA && (mirror >> ((Nrows + 15) / 16)) != 0)) return RIME_EINVAL;
+    A.mirror = (!cross && !psky_complex && (Nrows + 31) / 32 != 3) ? mirror : 0;
     ant_split_plan(Nt, Nf, Pstride, A.S, A.panels_per_split);
     if (!workspace || workspace_bytes < rime_fringe_ant_workspace(Nbl, Nt, Nf, Pstride)) return RIME_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1637,6 +1705,7 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
         case 1: RIME_FWD_PAIR(1); break;
         case 2:
             if (Nrows <= 48 && fwd_packed_enabled()) {        // <= 16 antennas in the second row tile: packed planes
+                A.mirror &= 3;                                // (no mirror pairs in the packed second row tile)
                 hipLaunchKernelGGL((fringe_ant_fwd_packed_kernel<true>), grid, dim3(PK::NW * 64), PK::LDS, st, A);
                 if (rowmin) hipLaunchKernelGGL((fringe_ant_fwd_packed_kernel<false>), grid, dim3(PK::NW * 64), PK::LDS, st, A);
                 break;
@@ -1695,7 +1764,7 @@ extern "C" int rime_fringe_ant_fwd(const double* antpos, const double* sdir, con
                                    void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!vis) return RIME_EINVAL;
-    const int rc = rime_fringe_ant_fwd_block(antpos, Nant, 0, sdir, freqs, psky, scale, rowmin, pair_direct, pair_conj,
+    const int rc = rime_fringe_ant_fwd_block(antpos, Nant, 0, 0, sdir, freqs, psky, scale, rowmin, pair_direct, pair_conj,
                                              Nbl, Nt, Nf, Pstride, st_t, st_f, st_p, sign, 0, workspace,
                                              workspace_bytes, stream);
     if (rc != RIME_OK) return rc;
@@ -1717,7 +1786,7 @@ extern "C" int rime_fringe_ant_bwd_prepare(const float* gvis, int Nbl, int Nt, i
     return check_launch();
 }
 
-extern "C" int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
+extern "C" int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cross, int mirror, const double* sdir,
                                          const double* freqs, const float* gscale, const int* pair_direct,
                                          const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
                                          long long st_t, long long st_f, long long st_p, int sign,
@@ -1733,6 +1802,8 @@ extern "C" int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cr
     A.Nant = Nrows; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
     A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign; A.accumulate = accumulate ? 1 : 0;
     A.rows_i = cross; A.imsign = psky_complex < 0 ? -1.f : 1.f;
+    if (mirror < 0 || (Nrows > 0 && Nrows <= MF_NA && (mirror >> ((Nrows + 15) / 16)) != 0)) return RIME_EINVAL;
+    A.mirror = cross ? 0 : mirror;                       // diagonal blocks, real or complex psky
     // pixel ranges are independent outputs: split freely for parallelism (>= 256 pixel tiles/block
     // amortise the G staging; fewer when the grid would otherwise be small)
     const int ntile = Pstride / 32;
@@ -1766,6 +1837,6 @@ extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, con
 {
     const int rc = rime_fringe_ant_bwd_prepare(gvis, Nbl, Nt, Nf, workspace, workspace_bytes, stream);
     if (rc != RIME_OK) return rc;
-    return rime_fringe_ant_bwd_block(antpos, Nant, 0, sdir, freqs, gscale, pair_direct, pair_conj, Nbl, Nt, Nf,
+    return rime_fringe_ant_bwd_block(antpos, Nant, 0, 0, sdir, freqs, gscale, pair_direct, pair_conj, Nbl, Nt, Nf,
                                      Pstride, st_t, st_f, st_p, sign, 0, 0, gpsky, workspace, workspace_bytes, stream);
 }

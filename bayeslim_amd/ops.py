@@ -243,6 +243,131 @@ def _antenna_blocks(bl_ants, Nant, bl_mp=None, ant_model=None, group=MFMA_GROUP)
     return blocks
 
 
+# MIRROR PAIRS (round 5; csrc/fringe_mfma.hip, "MIRROR PAIRS"): antennas with r' - c = -(r - c) have conjugate phasors.
+MIRROR = _env_int('RIME_MIRROR', 1) != 0        # RIME_MIRROR=0: no search (every row evaluated, rounds 1-4)
+MIRROR_TOL = 1e-9                               # [m] mismatch allowed in r + r' = 2 c (7e-10 turn of phase at 200 MHz)
+
+
+def _mirror_pairs(P, tol=MIRROR_TOL):
+    """
+    Point symmetry of a set of antenna positions P (n, 3): the centre c shared by the largest number of pairs
+    (r_a + r_b = 2 c within `tol`, all three coordinates) and a maximal pairing about it.  Returns (c, pairs, singles) --
+    pairs of row indices (a, b), singles the rows without a partner (an antenna AT the centre is its own mirror: a single) --
+    or None when fewer than two pairs exist.  O(n^2) on the host, n <= 128 per block.
+    """
+    P = np.asarray(P, dtype=np.float64)
+    n = len(P)
+    if n < 4:
+        return None
+    ia, ib = np.triu_indices(n, 1)
+    sums = P[ia] + P[ib]
+    # vote for 2 c on a 1-micrometre grid (a symmetric set of m antennas puts ~m / 2 of its n (n - 1) / 2 pair sums in one cell;
+    # twice, with the grid shifted by half a cell, so that sums sitting on a cell edge are not split)
+    best = None
+    for shift in (0.0, 0.5):
+        q = np.floor(sums * 1e6 + shift).astype(np.int64)
+        cells, inv, cnt = np.unique(q, axis=0, return_inverse=True, return_counts=True)
+        k = int(np.argmax(cnt))
+        if best is None or cnt[k] > best[0]:
+            best = (int(cnt[k]), sums[np.asarray(inv).reshape(-1) == k].mean(axis=0))
+    if best[0] < 2:
+        return None
+    c2 = best[1]
+    D = np.abs(P[:, None, :] + P[None, :, :] - c2).max(-1) <= tol
+    partner = -np.ones(n, dtype=np.int64)
+    for a in range(n):
+        if partner[a] >= 0:
+            continue
+        for b in np.nonzero(D[a])[0]:
+            if b != a and partner[b] < 0:
+                partner[a], partner[b] = b, a
+                break
+    pairs = [(a, int(partner[a])) for a in range(n) if partner[a] > a]
+    singles = [a for a in range(n) if partner[a] < 0]
+    if len(pairs) < 2:
+        return None
+    # the centre the pairs actually share (mean of their sums: the kernels use E' = conj(E) EXACTLY for a pair)
+    c = np.mean([P[a] + P[b] for a, b in pairs], axis=0) / 2
+    if max(np.abs(P[a] + P[b] - 2 * c).max() for a, b in pairs) > tol:
+        return None
+    return c, pairs, singles
+
+
+def _mirror_order(P, packed=None):
+    """
+    Row order of a diagonal block that puts mirror pairs into the octet pairs of 16-row groups: rows 16 g + i (i < 8) and
+    16 g + 8 + i of the groups g < Gm hold the two antennas of a pair (or a single and an empty row); the other antennas
+    fill plain groups behind them.  Returns (rows, mask, centre): rows[r] = index into P or -1 (empty row), mask = bit per
+    mirror group -- or None when no order with at least one mirror group fits into the block's row capacity
+    32 ceil(n / 32) (the kernel shape of the plain order must not grow).  `packed`: 33..48 antennas on the packed forward
+    kernel -- 48 rows, mirror groups in the first row tile only.
+    """
+    found = _mirror_pairs(P)
+    if found is None:
+        return None
+    c, pairs, singles = found
+    n = len(P)
+    packed = (32 < n <= 48 and FWD_PACKED) if packed is None else packed
+    G = 3 if packed else (32 * ((n + 31) // 32)) // 16              # 16-row groups available
+    Gcap = 2 if packed else G                                       # groups that may be mirror groups
+    for Gm in range(min(Gcap, (len(pairs) + 7) // 8), 0, -1):
+        slots = 8 * Gm
+        pin = min(len(pairs), slots)
+        sin = min(len(singles), slots - pin)
+        if n - 2 * pin - sin <= 16 * (G - Gm):
+            break
+    else:
+        return None
+    rows = [-1] * (16 * G)
+    for k, (a, b) in enumerate(pairs[:pin]):
+        rows[16 * (k // 8) + k % 8], rows[16 * (k // 8) + 8 + k % 8] = a, b
+    for k, a in enumerate(singles[:sin], start=pin):
+        rows[16 * (k // 8) + k % 8] = a                             # its mirror row stays empty
+    rest = [x for ab in pairs[pin:] for x in ab] + list(singles[sin:])
+    rows[16 * Gm:16 * Gm + len(rest)] = rest
+    while rows and rows[-1] < 0:
+        rows.pop()
+    return rows, (1 << Gm) - 1, c
+
+
+def _mirror_block(blk, P, dev):
+    """the mirrored form of a built diagonal block (see _mirror_order): positions measured from the centre of symmetry in
+    the new row order, pair tables rebuilt for it, `mirror` mask; None when the block has no usable symmetry"""
+    n = int(blk['nrows'])
+    if blk['cross'] != 0 or n < 4:
+        return None
+    found = _mirror_order(P)
+    if found is None:
+        return None
+    rows, mask, c = found
+    newrow = -np.ones(n, dtype=np.int64)
+    for r, a in enumerate(rows):
+        if a >= 0:
+            newrow[a] = r
+    assert (newrow >= 0).all() and len(rows) <= 32 * ((n + 31) // 32)
+    pos = np.zeros((len(rows), 3))
+    for r, a in enumerate(rows):
+        if a >= 0:
+            pos[r] = P[a] - c
+    direct = np.full((MFMA_GROUP, MFMA_GROUP), -1, dtype=np.int32)
+    conj = np.full((MFMA_GROUP, MFMA_GROUP), -1, dtype=np.int32)
+    od, oc = blk['direct'].reshape(MFMA_GROUP, MFMA_GROUP).cpu().numpy(), blk['conj'].reshape(MFMA_GROUP, MFMA_GROUP).cpu().numpy()
+    # direct[i, j] = b: baseline b runs from antenna i to antenna j; conj[i, j] = b: from j to i (_antenna_blocks)
+    for tab, swap in ((od, False), (oc, True)):
+        for i, j in zip(*np.nonzero(tab >= 0)):
+            a1, a2 = (j, i) if swap else (i, j)
+            r1, r2 = newrow[a1], newrow[a2]
+            if r1 // 32 <= r2 // 32:
+                direct[r1, r2] = tab[i, j]
+            else:
+                conj[r2, r1] = tab[i, j]
+    nd, nc = int((direct >= 0).sum()), int((conj >= 0).sum())
+    assert nd + nc == int((od >= 0).sum()) + int((oc >= 0).sum())
+    return dict(blk, pos=torch.as_tensor(pos, device=dev).contiguous(), nrows=len(rows), mirror=int(mask), rows=list(rows),
+                cpass=(1 if nc == 0 else (-1 if nd == 0 else 0)), fwd_cpass=0, self_pos=None, mf_self=0,
+                direct=torch.as_tensor(direct.reshape(-1), device=dev), conj=torch.as_tensor(conj.reshape(-1), device=dev))
+
+
 def _dense_strides(t):
     """element strides (time, model pair, pol product, channel) of a (Nt,Nmp,Npp,Nf,P) tensor whose
     pixel axis is contiguous, or None when the tensor cannot be passed as is"""
@@ -274,7 +399,7 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
     others take one pass per real plane.  Returns the MFMA flops executed.
     """
     a = geom.ant
-    blocks = a['blocks']
+    blocks = a['blocks'] if cplx else a.get('blocks_mirror', a['blocks'])
     m = 2 if cplx else 1                                     # floats per psky element
     st_t, st_mp, st_pp, st_f = (int(strides[k]) * m for k in range(4))
     Nbl, Nt, Nf, Nmp = geom.Nbl, geom.Nt, geom.Nf, geom.Nmp
@@ -320,12 +445,12 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
             src = ctypes.c_void_p(inp.data_ptr() + 4 * (mp * st_mp + pp * st_pp + c))
             if cflag != 0 and blk['cross'] == 0:             # diagonal block, complex single pass: self block
                 n = int(blk['self_pos'].shape[0])
-                rc = lib.rime_fringe_ant_fwd_block(_ptr(blk['self_pos']), n, n, *geo, src, _ptr(scale[mp, pp]),
+                rc = lib.rime_fringe_ant_fwd_block(_ptr(blk['self_pos']), n, n, 0, *geo, src, _ptr(scale[mp, pp]),
                                                    _ptr(rowmin[c][mp, pp]), _ptr(blk['direct']), _ptr(blk['conj']),
                                                    *shape, cflag, _ptr(ws), ws.numel(), _stream())
                 check(rc, 'rime_fringe_ant_fwd_block')
                 return blk['mf_self']
-            rc = lib.rime_fringe_ant_fwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], *geo, src,
+            rc = lib.rime_fringe_ant_fwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], blk['mirror'], *geo, src,
                                                _ptr(scale[mp, pp]), _ptr(rowmin[c][mp, pp]),
                                                _ptr(blk['direct']), _ptr(blk['conj']),
                                                *shape, cflag, _ptr(ws), ws.numel(), _stream())
@@ -376,7 +501,7 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
                     assert all((pl in written) == bool(acc) for pl in planes)
                     written.update(planes)
                     dst = ctypes.c_void_p(out.data_ptr() + 4 * (mp * st_mp + pp * st_pp + (0 if single else c)))
-                    rc = lib.rime_fringe_ant_bwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], *geo,
+                    rc = lib.rime_fringe_ant_bwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], blk['mirror'], *geo,
                                                        _ptr(scale_pp), _ptr(blk['direct']), _ptr(blk['conj']),
                                                        *shape, blk['cpass'] if single else 0, acc, dst,
                                                        _ptr(ws), ws.numel(), _stream())
@@ -455,7 +580,7 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
         if fwd_cpass == 0:
             slots = np.concatenate([blk['direct'][blk['direct'] >= 0], blk['conj'][blk['conj'] >= 0]])
             two_pass_mask[torch.as_tensor(slots, dtype=torch.int64, device=dev)] = 1.0
-        blocks.append(dict(pos=rows, nrows=int(rows.shape[0]), cross=int(cross), mp=blk['mp'],
+        blocks.append(dict(pos=rows, nrows=int(rows.shape[0]), cross=int(cross), mp=blk['mp'], mirror=0,
                            cpass=blk['cpass'], fwd_cpass=fwd_cpass, mf_fwd=mf_fwd, mf_bwd=mf_bwd, mf_bwd_real=mf_bwd_real,
                            self_pos=self_pos, mf_self=mf_self,
                            direct=torch.as_tensor(blk['direct'].reshape(-1), device=dev),
@@ -469,6 +594,15 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
     self.ant = dict(blocks=blocks, Nant=Nant, mfma_fwd=mfma_fwd, mfma_bwd=mfma_bwd, two_pass_mask=two_pass_mask,
                     mfma_flops_fwd=per16 * mfma_fwd, mfma_flops_bwd=per16 * mfma_bwd,
                     multi_model=ant_model is not None)
+    # arrays with point symmetry: the REAL-psky passes run on mirrored forms of the diagonal blocks (conjugate phasors are
+    # not evaluated twice); complex psky keeps the plain blocks (its single-pass forms depend on the pair orientation, which
+    # a re-ordering of the rows changes)
+    if MIRROR:
+        posh = pos.cpu().numpy()
+        mb = [(_mirror_block(b, posh[np.asarray(r['ants_i'])], dev) if r['ants_j'] is None else None) for b, r in zip(blocks, raw)]
+        if any(m is not None for m in mb):
+            self.ant['blocks_mirror'] = [m if m is not None else b for m, b in zip(mb, blocks)]
+            self.ant['mirror_groups'] = [(bin(m['mirror']).count('1'), (m['nrows'] + 15) // 16) for m in mb if m is not None]
 
 
 FringeGeometry._setup_antenna_path = _setup_antenna_path

@@ -155,11 +155,18 @@ int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* 
  *       RIME_EUNSUPPORTED and takes one call per real plane; the block must hold direct entries only); -1 = as +1 but the
  *       block contracts conj(psky) (a block built with its groups swapped: conj entries only).  The
  *       backward writes both gradient planes from one pass for either block kind.
+ *   mirror: bit mask over the 16-row groups g of a DIAGONAL block (0 = none; round 5).  Bit g set: rows 16 g + 8 + i hold the
+ *       MIRROR antennas of rows 16 g + i, i < 8 -- antpos[16 g + 8 + i] = -antpos[16 g + i] (the block's positions are
+ *       measured from the centre of symmetry; visibilities depend on position differences only), rows without an antenna
+ *       in either octet zero.  Their phasors are complex conjugates: the kernels evaluate the first octet and conjugate
+ *       it for the second (forward: real-plane passes of blocks of 1, 2 or 4 row tiles and the first row tile of the
+ *       33..48-row shape; backward: every diagonal block).  A licence, not an obligation: other block kinds evaluate
+ *       every row.  Bits at or beyond ceil(Nrows / 16) -> RIME_EINVAL.
  * Forward blocks fill disjoint baseline slots of the slab workspace (every baseline must belong
  * to exactly one block); _finish sums the pixel splits and writes vis [Nbl, Nt, Nf].  Backward:
  * _prepare transposes gvis into the workspace once, every block reads it; blocks after the first that
  * write the same gpsky plane pass accumulate = 1 (stream order makes the sum deterministic). */
-int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
+int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cross, int mirror, const double* sdir,
                               const double* freqs, const float* psky, const float* scale,
                               const float* rowmin, const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf,
                               int Pstride, long long st_t, long long st_f, long long st_p, int sign,
@@ -182,7 +189,7 @@ int rime_fringe_ant_fwd_finish(const void* workspace, size_t workspace_bytes, fl
                                int Nbl, int Nt, int Nf, int Pstride, void* stream);
 int rime_fringe_ant_bwd_prepare(const float* gvis, int Nbl, int Nt, int Nf,
                                 void* workspace, size_t workspace_bytes, void* stream);
-int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cross, const double* sdir,
+int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cross, int mirror, const double* sdir,
                               const double* freqs, const float* gscale, const int* pair_direct,
                               const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
                               long long st_t, long long st_f, long long st_p, int sign,

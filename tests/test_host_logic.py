@@ -434,6 +434,51 @@ def test_healpix_pinned_to_docstring_and_hand_derived_vectors():
         assert np.abs(dense - want).max() < 1e-14, c['tag']
 
 
+def test_mirror_pairs_and_row_order():
+    """round 5, host side of the conjugate-phasor pairing (ops._mirror_pairs / _mirror_order): hexagons (with an outrigger),
+    an explicitly mirrored random set with a 3-D centre, sets without symmetry, a set whose symmetry holds in x, y but not in
+    z; the row order puts the two antennas of a pair 8 rows apart inside mirror groups and keeps the block's row capacity"""
+    from bayeslim_amd import ops
+    rng = np.random.default_rng(1)
+    hex7 = utils._make_hex(7, D=14.6)[1]
+    c, pairs, singles = ops._mirror_pairs(hex7)
+    assert len(pairs) == 63 and len(singles) == 1 and np.abs(c).max() < 1e-9 and np.abs(hex7[singles[0]]).max() < 1e-9
+    ant = np.vstack([hex7, [[250.0, 0.0, 0.0]]]) + [5.0, -3.0, 1.0]
+    c, pairs, singles = ops._mirror_pairs(ant)
+    assert len(pairs) == 63 and len(singles) == 2 and np.abs(c - [5.0, -3.0, 1.0]).max() < 1e-9
+    for a, b in pairs:
+        assert np.abs(ant[a] + ant[b] - 2 * c).max() < 1e-9
+    rows, mask, c2 = ops._mirror_order(ant)
+    assert len(rows) == 128 and mask == 0x7f and sorted(rows) == list(range(128))      # 7 mirror groups + one plain group of 16
+    for g in range(7):
+        for i in range(8):
+            assert np.abs(ant[rows[16 * g + i]] + ant[rows[16 * g + 8 + i]] - 2 * c2).max() < 1e-9
+    # HERA-19 / HERA-37 (the packed shape: mirror groups in the first row tile only, <= 48 rows)
+    rows, mask, _ = ops._mirror_order(utils._make_hex(3, D=14.6)[1])
+    assert mask == 3 and len(rows) <= 32 and sorted(r for r in rows if r >= 0) == list(range(19))
+    rows, mask, _ = ops._mirror_order(utils._make_hex(4, D=14.6)[1])
+    assert mask == 3 and len(rows) == 37 and sorted(rows) == list(range(37))
+    # mirrored random set, tilted, centre off the origin, shuffled; singles fill the last slots / a plain group
+    h = rng.normal(0, 60.0, (20, 3))
+    ant = np.vstack([h, -h, rng.normal(0, 60.0, (5, 3))])[rng.permutation(45)] + [100.0, 20.0, -7.0]
+    c, pairs, singles = ops._mirror_pairs(ant)
+    assert len(pairs) == 20 and len(singles) == 5 and np.abs(c - [100.0, 20.0, -7.0]).max() < 1e-9
+    rows, mask, _ = ops._mirror_order(ant)
+    assert mask == 3 and len(rows) <= 48
+    # no symmetry: nothing; symmetry in the plane only: nothing
+    assert ops._mirror_pairs(rng.normal(0, 60.0, (40, 3))) is None
+    flat = np.vstack([h, -h])
+    flat[:, 2] = rng.normal(0, 1.0, 40)
+    assert ops._mirror_pairs(flat) is None
+    # a mismatch above the tolerance breaks a pair, one below it does not
+    ant = np.vstack([h, -h])
+    ant[3] += [2e-9, 0, 0]
+    assert len(ops._mirror_pairs(ant)[1]) == 19
+    ant = np.vstack([h, -h])
+    ant[3] += [2e-10, 0, 0]
+    assert len(ops._mirror_pairs(ant)[1]) == 20
+
+
 def test_antenna_block_tables():
     """pair tables of the matrix-core path: groups of <= 128 antennas, diagonal + cross blocks"""
     from bayeslim_amd import ops

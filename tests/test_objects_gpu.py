@@ -109,15 +109,17 @@ def test_rime_pickle_and_deepcopy_after_a_forward_reproduce_the_same_bits(ba, f3
 def test_rime_push_dtype_and_device_round_trips(ba, f32):
     """push(torch.float64) on every model of a float32 RIME that has run, then forward: equal (1e-12) to a float64 model BUILT
     from the same float32-rounded inputs -- nothing is left behind in float32, no stale cache is served -- and within the
-    rounding of those inputs of the reference's float64 output; push back to float32: the first result bit for bit; the same
-    through push('cpu') -> push('cuda') (rime_model.py:117-126 and the models' own push methods; derived caches are rebuilt,
-    never converted)"""
+    rounding of those inputs of the reference's float64 output; push back to float32: the first result to float32 accuracy;
+    push('cpu') -> push('cuda'): bit for bit (rime_model.py:117-126 and the models' own push methods; derived caches are
+    rebuilt, never converted)"""
     g, rime, params_of = _c2(ba)
     vis32, gr32 = _step(rime, params_of, g)
     assert vis32.dtype == torch.complex64
 
     def push_all(what):
-        for m in (rime.sky, rime.beam, rime.array, rime):
+        # (the antenna positions of the float32 model are float64, as everywhere in the tests and the bench: a dtype push
+        #  leaves the array alone -- ArrayModel.push(float32) would ROUND them, as the reference's does)
+        for m in (rime.sky, rime.beam, rime) + (() if isinstance(what, torch.dtype) else (rime.array,)):
             m.push(what)
 
     push_all(torch.float64)
@@ -138,16 +140,21 @@ def test_rime_push_dtype_and_device_round_trips(ba, f32):
     assert relmax(vis64, vw.cpu().numpy()) < 1e-12
     for a, b in zip(gr64, gw_grads):
         assert relmax(a, b.cpu().numpy()) < 1e-11
+    # back to float32: the parameters and channels return to their float32 values exactly, but a dtype push also ROUNDS what
+    # the float32 model kept in float64 (interpolation grids, sky angles -- as the reference's push does): float32 agreement
     push_all(torch.float32)
-    vis, gr = _step(rime, params_of, g)
-    assert torch.equal(vis, vis32) and all(torch.equal(a, b) for a, b in zip(gr, gr32))
+    vis32b, gr32b = _step(rime, params_of, g)
+    assert vis32b.dtype == torch.complex64 and relmax(vis32b, vis32.cpu().numpy()) < 1e-5
+    for a, b in zip(gr32b, gr32):
+        assert relmax(a, b.cpu().numpy()) < 1e-4
+    # a DEVICE round trip changes no value: bit for bit
     push_all('cpu')
     assert rime.sky.params.device.type == 'cpu'
     with pytest.raises(RuntimeError):
         rime()                                                   # no CPU path: loud, not a silent fallback
     push_all(DEV)
     vis, gr = _step(rime, params_of, g)
-    assert torch.equal(vis, vis32) and all(torch.equal(a, b) for a, b in zip(gr, gr32))
+    assert torch.equal(vis, vis32b) and all(torch.equal(a, b) for a, b in zip(gr, gr32b))
 
 
 @pytest.mark.parametrize('which', ['c2', 'pol40'])

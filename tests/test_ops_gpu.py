@@ -340,6 +340,68 @@ def _check_ant_path(ops, geom, psky, blvecs, zenaz, freqs, bl_mp, P, Ps, cplx, c
     return vis
 
 
+def _symmetric_array(kind, rng):
+    """antenna positions with point symmetry (and some antennas without a partner), centre away from the origin"""
+    from bayeslim_amd import utils
+    c = np.array([31.7, -12.3, 4.1])
+    if kind.startswith('hex'):
+        side, extra = {'hex19': (3, 0), 'hex37': (4, 0), 'hex61': (5, 0), 'hex91': (6, 0), 'hex127+1': (7, 1)}[kind]
+        ant = utils._make_hex(side, D=14.6)[1]
+        if extra:
+            ant = np.vstack([ant, [[250.0, 3.0, 0.0]]])
+    else:
+        # `half` random antennas, their mirror images, `single` antennas without a partner; tilted (z matters)
+        half, single = {'rand45': (20, 5), 'rand70': (33, 4), 'rand128': (60, 8)}[kind]
+        h = rng.normal(0, 70.0, (half, 3)) * [1, 1, 0.05]
+        ant = np.vstack([h, -h, rng.normal(0, 70.0, (single, 3)) * [1, 1, 0.05]])
+    ant = ant[rng.permutation(len(ant))] + c
+    return ant
+
+
+@pytest.mark.parametrize('kind,groups', [('hex19', (2, 2)), ('hex37', (2, 3)), ('hex61', (4, 4)), ('hex91', (6, 6)), ('hex127+1', (7, 8)),
+                                         ('rand45', (2, 3)), ('rand70', (5, 5)), ('rand128', (7, 8))])
+@pytest.mark.parametrize('conj', [False, True])
+def test_fringe_sum_mirror_pairs(ops, kind, groups, conj, monkeypatch):
+    """arrays with point symmetry (round 5): the antennas with r' - c = -(r - c) are found on the host, a diagonal block's rows
+    are ordered so that the second octet of a 16-row group holds the mirror antennas of the first, and the kernels use the
+    conjugate of the first octet's phasors instead of evaluating them -- forward (1 / 2 / 4 row tiles, the packed 33..48
+    shape; 65..96 antennas: backward only) and backward, against the float64 oracle of the baseline formulation; both pair
+    orientations, a partial pair set, autocorrelations, antennas without a partner, a centre away from the origin; equal
+    to 2e-6 -- not bitwise -- to the run without the pairing (RIME_MIRROR=0), whose geometry has no mirrored blocks"""
+    rng = np.random.default_rng(abs(hash(kind)) % 1000)
+    ant = _symmetric_array(kind, rng)
+    Nant, Nt, Nf, P = len(ant), 2, 7, 700
+    pairs = [(i, j) if rng.random() < 0.5 else (j, i) for i in range(Nant) for j in range(i + 1, Nant) if rng.random() < 0.9]
+    pairs += [(a, a) for a in range(3)]
+    pairs = [pairs[k] for k in rng.permutation(len(pairs))]
+    blvecs = T64(np.stack([ant[b] - ant[a] for a, b in pairs]))
+    freqs = T64(np.linspace(120e6, 180e6, Nf))
+    zenaz = T64(np.stack([np.rad2deg(np.arccos(rng.uniform(0, 1, (Nt, P)))), rng.uniform(0, 360, (Nt, P))], axis=1))
+    psky = torch.as_tensor(rng.normal(size=(Nt, 1, 1, Nf, P)) * np.exp(-9.0 * rng.uniform(size=(Nt, 1, 1, Nf, P))))
+    Ps = ops.pad_to_tile(P)
+    sdir = torch.zeros(Nt, 3, Ps, dtype=torch.float64)
+    for t in range(Nt):
+        sdir[t, :, :P] = orc.pointing_vectors(zenaz[t, 0], zenaz[t, 1])
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, 'MIRROR', on)
+        geom = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, conj=conj, antpos=T64(ant).cuda(), bl_ants=pairs, mfma=True)
+        assert geom.ant is not None and ('blocks_mirror' in geom.ant) == on
+        if on:
+            assert geom.ant['mirror_groups'] == [groups], geom.ant['mirror_groups']
+            blk = geom.ant['blocks_mirror'][0]
+            pos, n = blk['pos'].cpu().numpy(), blk['nrows']
+            rows = blk['rows'] + [-1] * 16
+            for g in range((n + 15) // 16):                      # the layout the kernels rely on
+                if (blk['mirror'] >> g) & 1:
+                    for i in range(8):
+                        a, b = rows[16 * g + i], rows[16 * g + 8 + i]
+                        assert b < 0 or (a >= 0 and np.abs(pos[16 * g + i] + pos[16 * g + 8 + i]).max() < 1e-9)
+        res[on] = _check_ant_path(ops, geom, psky, blvecs, zenaz, freqs, [0] * len(pairs), P, Ps, False, conj=conj).detach()
+    assert not torch.equal(res[True], res[False])
+    assert relmax(res[True], res[False].cpu().numpy()) < 2e-6
+
+
 @pytest.mark.parametrize('Nant,group,frac', [(128, 32, 1.0), (100, 32, 0.7), (128, 64, 1.0), (90, 64, 0.8), (40, 32, 1.0)])
 def test_fringe_sum_matrix_core_small_groups(ops, Nant, group, frac):
     """groups of 32 / 64 antennas (rank-local tile shards): one-tile diagonal blocks with the K-split
