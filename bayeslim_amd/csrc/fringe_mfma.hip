@@ -156,8 +156,10 @@ __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_
 // bit, and antennas without a partner (placed in such groups), are evaluated as before.  Forward: the sweeps of a wave pair
 // now walk the octets of ONE 16-row group (rows 32 (u >> 1) + 16 p + 8 (u & 1) + i instead of 16 u + 8 p + i: the same octets,
 // dealt differently), so that an odd sweep is the conjugate of the sweep before it in the same lanes.  Backward: the two
-// octets of a K step are the jq = 0 / 1 halves of the fragment a lane generates.  Timing-only bound before it was built
-// (every second octet conjugated): C4 83.5 -> 73.0 ms/step, C3 19.5 -> 17.7, C2 0.837 -> 0.773 (profiles/r05/mirror_bound.txt).
+// octets of a K step are the jq = 0 / 1 halves of the fragment a lane generates.  Measured, mirror pairs on / off on one box:
+// C4 (127-antenna hexagon + outrigger: 7 of 8 groups) 85.4 -> 79.4 ms/step, C3 20.3 -> 18.1, C2 0.861 -> 0.825
+// (profiles/r05/mirror_pairs.txt; a timing-only build had promised twice as much for the forward -- an artefact: its
+// duplicated image rows lowered the matrix pipe's switching power, and the chip is power-limited under these kernels).
 constexpr int MF_KP = 32;                       // pixels per panel (one barrier per panel); 16 per MFMA
 constexpr int MF_NH = MF_KP / 16;               // 16-pixel K steps per panel
 constexpr int MF_ROWB = 4 * MF_KP + 16;         // [re KP x f16][im KP x f16][pad]: odd number of 16-B granules
@@ -255,7 +257,13 @@ __device__ __forceinline__ void static_for(F&& f)
 // weighting -- group I rows hold L = 2^7 E, group J rows hold B = (psky scale / 2^7) E (a complex product,
 // two more FMAs per generated value), so V = L^H B needs the same MFMAs as one real plane and no sign
 // masks.  (Diagonal blocks would need two images of the same antennas; they take the two real passes.)
-template <class SH, int W, bool SIGNED, bool CPLX>
+// MIR: the block has mirror groups (AntArgs.mirror != 0): a kernel instantiation of its own, so that the one which serves arrays
+// without symmetry carries no test.  An odd sweep of a mirror group stores the conjugate of the sweep before it (wave-uniform
+// test of the mask); every sweep's coordinates stay in registers.  Three leaner forms were measured on one box and lost
+// (profiles/r05/mirror_pairs.txt): odd-sweep coordinates fetched from memory on demand (the compiler then drains the panel
+// prefetch at the branch: the whole gain gone), from an LDS table (- 5.3 % against - 5.7 %), and a two-phase form with ONE
+// rolled copy of the plain odd sweeps (- 3.6 %).
+template <class SH, int W, bool SIGNED, bool CPLX, bool MIR = false>
 __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* smem)
 {
     static_assert(!CPLX || (SH::CROSS && !SIGNED), "complex single pass: cross blocks, no sign masks");
@@ -305,6 +313,7 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     const int mrow = A.Nant - 16 * (W >> 1);
     const int nk = (OCT && !OCT8) ? min(NGEN, (max(mrow, 0) + 31) / 32 + (max(mrow - 8, 0) + 31) / 32) : NGEN;
     const int growx = SH::NW == 8 ? 2 * ag + 16 * ((W >> 1) & 1) + (W >> 2) : 2 * ag + (W >> 1);
+    static_assert(!MIR || (OCT && !OCT8), "mirror groups: diagonal blocks with the half-panel generation mapping");
     double ax[NGEN], ay[NGEN], az[NGEN];
 #pragma unroll
     for (int u = 0; u < NGEN; ++u) {
@@ -368,29 +377,44 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
             if (SIGNED && W < 2 && lane < 8)
                 *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
                     ((__float_as_uint(av[hf].x) >> 16) & 0x8000u) | (__float_as_uint(av[hf].y) & 0x80000000u);
-            uint32_t m_rh = 0, m_rl = 0, m_ih = 0, m_il = 0;      // the sweep before: an odd sweep of a mirror group is its conjugate
+            // one evaluated sweep: the weighted f16 halves of this lane's pixel pair for the antenna at (bx, by, bz)
+            auto sweep = [&](double bx, double by, double bz, uint32_t& rh, uint32_t& rl, uint32_t& ih, uint32_t& il) {
+                const double ph0 = phase3(bx, sx[hf].x, by, sy[hf].x, bz, sz[hf].x);
+                const double ph1 = phase3(bx, sx[hf].y, by, sy[hf].y, bz, sz[hf].y);
+                const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
+                const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
+                const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+                split2(w0 * c0, w1 * c1, rh, rl);
+                split2(w0 * s0, w1 * s1, ih, il);
+            };
+            auto store = [&](int row, uint32_t rh, uint32_t rl, uint32_t ih, uint32_t il) {
+                unsigned char* o = buf + row * MF_ROWB + pp * 4 + 32 * hf;
+                *reinterpret_cast<uint32_t*>(o) = rh;
+                *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+            };
+            if constexpr (MIR) {
+                uint32_t m_rh = 0, m_rl = 0, m_ih = 0, m_il = 0;
 #pragma unroll
-            for (int u = 0; u < NGEN; ++u) {
-                if (u < nk) {
-                    uint32_t rh, rl, ih, il;
-                    // (uniform: the group of this wave pair's sweeps u - 1, u is 2 (u >> 1) + p)
-                    if (!OCT8 && (u & 1) && ((A.mirror >> (2 * (u >> 1) + (W >> 1))) & 1)) {
-                        rh = m_rh; rl = m_rl; ih = m_ih ^ 0x80008000u; il = m_il ^ 0x80008000u;
-                    } else {
-                        const double ph0 = phase3(ax[u], sx[hf].x, ay[u], sy[hf].x, az[u], sz[hf].x);
-                        const double ph1 = phase3(ax[u], sx[hf].y, ay[u], sy[hf].y, az[u], sz[hf].y);
-                        const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
-                        const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
-                        const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
-                        split2(w0 * c0, w1 * c1, rh, rl);
-                        split2(w0 * s0, w1 * s1, ih, il);
+                for (int u = 0; u < NGEN; ++u) {
+                    if (u < nk) {
+                        uint32_t rh, rl, ih, il;
+                        if ((u & 1) && ((A.mirror >> (2 * (u >> 1) + (W >> 1))) & 1)) {
+                            rh = m_rh; rl = m_rl; ih = m_ih ^ 0x80008000u; il = m_il ^ 0x80008000u;
+                        } else sweep(ax[u], ay[u], az[u], rh, rl, ih, il);
+                        if (!(u & 1)) { m_rh = rh; m_rl = rl; m_ih = ih; m_il = il; }
+                        store(octet_row(u), rh, rl, ih, il);
                     }
-                    if (!OCT8 && !(u & 1)) { m_rh = rh; m_rl = rl; m_ih = ih; m_il = il; }
-                    unsigned char* o = buf + (OCT8 ? 32 * u + growx : octet_row(u)) * MF_ROWB + pp * 4 + 32 * hf;
-                    *reinterpret_cast<uint32_t*>(o) = rh;
-                    *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
-                    *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
-                    *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NGEN; ++u) {
+                    if (u < nk) {
+                        uint32_t rh, rl, ih, il;
+                        sweep(ax[u], ay[u], az[u], rh, rl, ih, il);
+                        store(OCT8 ? 32 * u + growx : octet_row(u), rh, rl, ih, il);
+                    }
                 }
             }
             fetch(next_panel, hf);
@@ -622,30 +646,30 @@ __device__ __forceinline__ bool row_is_signed(const AntArgs& A)
     return A.rowmin[t * A.Nf + f] < 0.f;
 }
 
-template <class SH, bool SIGNED, bool CPLX>
+template <class SH, bool SIGNED, bool CPLX, bool MIR = false>
 __device__ __forceinline__ void ant_fwd_dispatch(const AntArgs& A, unsigned char* smem)
 {
     if constexpr (!CPLX) { if (row_is_signed(A) != SIGNED) return; }        // uniform over the block
     switch (threadIdx.x >> 6) {                      // wave-uniform: every wave runs the same barriers
-        case 0: ant_fwd_body<SH, 0, SIGNED, CPLX>(A, smem); break;
-        case 1: ant_fwd_body<SH, 1, SIGNED, CPLX>(A, smem); break;
-        case 2: if constexpr (SH::NW > 2) ant_fwd_body<SH, 2, SIGNED, CPLX>(A, smem); break;
-        case 3: if constexpr (SH::NW > 2) ant_fwd_body<SH, 3, SIGNED, CPLX>(A, smem); break;
-        case 4: if constexpr (SH::NW > 4) ant_fwd_body<SH, 4, SIGNED, CPLX>(A, smem); break;
-        case 5: if constexpr (SH::NW > 4) ant_fwd_body<SH, 5, SIGNED, CPLX>(A, smem); break;
-        case 6: if constexpr (SH::NW > 4) ant_fwd_body<SH, 6, SIGNED, CPLX>(A, smem); break;
-        default: if constexpr (SH::NW > 4) ant_fwd_body<SH, 7, SIGNED, CPLX>(A, smem); break;
+        case 0: ant_fwd_body<SH, 0, SIGNED, CPLX, MIR>(A, smem); break;
+        case 1: ant_fwd_body<SH, 1, SIGNED, CPLX, MIR>(A, smem); break;
+        case 2: if constexpr (SH::NW > 2) ant_fwd_body<SH, 2, SIGNED, CPLX, MIR>(A, smem); break;
+        case 3: if constexpr (SH::NW > 2) ant_fwd_body<SH, 3, SIGNED, CPLX, MIR>(A, smem); break;
+        case 4: if constexpr (SH::NW > 4) ant_fwd_body<SH, 4, SIGNED, CPLX, MIR>(A, smem); break;
+        case 5: if constexpr (SH::NW > 4) ant_fwd_body<SH, 5, SIGNED, CPLX, MIR>(A, smem); break;
+        case 6: if constexpr (SH::NW > 4) ant_fwd_body<SH, 6, SIGNED, CPLX, MIR>(A, smem); break;
+        default: if constexpr (SH::NW > 4) ant_fwd_body<SH, 7, SIGNED, CPLX, MIR>(A, smem); break;
     }
 }
 
 template <int TA> constexpr int fwd_threads() { return FwdShape<TA, TA, false>::NW * 64; }
 
-template <int TA, bool SIGNED>
+template <int TA, bool SIGNED, bool MIR = false>
 __global__ void __launch_bounds__(fwd_threads<TA>(), 2)
 fringe_ant_fwd_kernel(AntArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    ant_fwd_dispatch<FwdShape<TA, TA, false>, SIGNED, false>(A, smem);
+    ant_fwd_dispatch<FwdShape<TA, TA, false>, SIGNED, false, MIR>(A, smem);
 }
 
 // cross blocks: TI x TJ tiles, (1,1) (1,2) (2,2) (4,4); 8 waves for the 16-tile shape
@@ -710,7 +734,7 @@ struct PK {
 };
 static_assert(MF_KP == 32, "the packed shape assumes 32-pixel panels (two K steps, one per wave of a pair)");
 
-template <int W, bool SIGNED>
+template <int W, bool SIGNED, bool MIR = false>
 __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned char* smem)
 {
     constexpr int KS = W & 1;                           // this wave's K step of every panel
@@ -789,7 +813,7 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
         for (int u = 0; u < NGEN; ++u) {
             if (u < nk) {
                 uint32_t rh, rl, ih, il;
-                if (u == 1 && ((A.mirror >> (W >> 1)) & 1)) {          // uniform
+                if (MIR && u == 1 && ((A.mirror >> (W >> 1)) & 1)) {   // uniform
                     rh = m_rh; rl = m_rl; ih = m_ih ^ 0x80008000u; il = m_il ^ 0x80008000u;
                 } else {
                     const double ph0 = phase3(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
@@ -800,7 +824,7 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
                     split2(w0 * c0, w1 * c1, rh, rl);
                     split2(w0 * s0, w1 * s1, ih, il);
                 }
-                if (u == 0) { m_rh = rh; m_rl = rl; m_ih = ih; m_il = il; }
+                if (MIR && u == 0) { m_rh = rh; m_rl = rl; m_ih = ih; m_il = il; }
                 if (u < 2) {
                     unsigned char* o = buf + sweep_row(u) * PK::ROWB0 + pp * 4 + 32 * hf;
                     *reinterpret_cast<uint32_t*>(o) = rh;
@@ -967,17 +991,17 @@ __device__ __forceinline__ void ant_fwd_packed_body(const AntArgs& A, unsigned c
     }
 }
 
-template <bool SIGNED>
+template <bool SIGNED, bool MIR = false>
 __global__ void __launch_bounds__(PK::NW * 64, 2)
 fringe_ant_fwd_packed_kernel(AntArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     if (row_is_signed(A) != SIGNED) return;              // uniform over the block
     switch (threadIdx.x >> 6) {                          // wave-uniform: every wave runs the same barriers
-        case 0: ant_fwd_packed_body<0, SIGNED>(A, smem); break;
-        case 1: ant_fwd_packed_body<1, SIGNED>(A, smem); break;
-        case 2: ant_fwd_packed_body<2, SIGNED>(A, smem); break;
-        default: ant_fwd_packed_body<3, SIGNED>(A, smem); break;
+        case 0: ant_fwd_packed_body<0, SIGNED, MIR>(A, smem); break;
+        case 1: ant_fwd_packed_body<1, SIGNED, MIR>(A, smem); break;
+        case 2: ant_fwd_packed_body<2, SIGNED, MIR>(A, smem); break;
+        default: ant_fwd_packed_body<3, SIGNED, MIR>(A, smem); break;
     }
 }
 
@@ -1698,6 +1722,11 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
 #define RIME_FWD_PAIR(TA)                                                                                      \
     do {                                                                                                       \
         using SH = FwdShape<TA, TA, false>;                                                                    \
+        if (A.mirror) {                                                                                        \
+            hipLaunchKernelGGL((fringe_ant_fwd_kernel<TA, true, (TA != 3)>), grid, dim3(SH::NW * 64), SH::LDS, st, A);  \
+            if (rowmin) hipLaunchKernelGGL((fringe_ant_fwd_kernel<TA, false, (TA != 3)>), grid, dim3(SH::NW * 64), SH::LDS, st, A); \
+            break;                                                                                             \
+        }                                                                                                      \
         hipLaunchKernelGGL((fringe_ant_fwd_kernel<TA, true>), grid, dim3(SH::NW * 64), SH::LDS, st, A);        \
         if (rowmin) hipLaunchKernelGGL((fringe_ant_fwd_kernel<TA, false>), grid, dim3(SH::NW * 64), SH::LDS, st, A); \
     } while (0)
@@ -1706,6 +1735,11 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
         case 2:
             if (Nrows <= 48 && fwd_packed_enabled()) {        // <= 16 antennas in the second row tile: packed planes
                 A.mirror &= 3;                                // (no mirror pairs in the packed second row tile)
+                if (A.mirror) {
+                    hipLaunchKernelGGL((fringe_ant_fwd_packed_kernel<true, true>), grid, dim3(PK::NW * 64), PK::LDS, st, A);
+                    if (rowmin) hipLaunchKernelGGL((fringe_ant_fwd_packed_kernel<false, true>), grid, dim3(PK::NW * 64), PK::LDS, st, A);
+                    break;
+                }
                 hipLaunchKernelGGL((fringe_ant_fwd_packed_kernel<true>), grid, dim3(PK::NW * 64), PK::LDS, st, A);
                 if (rowmin) hipLaunchKernelGGL((fringe_ant_fwd_packed_kernel<false>), grid, dim3(PK::NW * 64), PK::LDS, st, A);
                 break;

@@ -647,7 +647,11 @@ def selfcheck_reference(inp, dev, bls, sample, first_times):
         torch.set_default_dtype(old)
 
 
-OTHER_WORKLOADS = (('c3', []), ('c2', ['--steps', '20', '--warmup', '5']), ('c5', ['--nf', '64', '--steps', '3', '--warmup', '2']))
+OTHER_WORKLOADS = (('c3', [], None), ('c2', ['--steps', '20', '--warmup', '5'], None),
+                   ('c5', ['--nf', '64', '--steps', '3', '--warmup', '2'], None),
+                   # the headline array is a 127-antenna hexagon + outrigger: 63 mirror pairs.  The same workload with the pairing
+                   # switched off = what an array WITHOUT point symmetry of this size costs (every phasor evaluated)
+                   ('c4', ['--steps', '5', '--warmup', '3'], {'RIME_MIRROR': '0'}))
 
 
 def other_workloads(budget_s, timeout_each=150.0):
@@ -661,16 +665,18 @@ def other_workloads(budget_s, timeout_each=150.0):
     """
     import subprocess
     out, t0 = [], time.perf_counter()
-    for wl, extra in OTHER_WORKLOADS:
+    for wl, extra, env in OTHER_WORKLOADS:
         left = budget_s - (time.perf_counter() - t0)
+        tag = wl if env is None else wl + ' [' + ' '.join('%s=%s' % kv for kv in sorted(env.items())) + ']'
         if left < 20.0:
-            out.append(dict(workload=wl, skipped='time budget of the default run used up'))
+            out.append(dict(workload=tag, skipped='time budget of the default run used up'))
             continue
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--no-cpu-baseline', '--no-other-workloads'] + \
               (extra if extra else ['--steps', '5', '--warmup', '3'])
         t1 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=min(timeout_each, left + 10.0))
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=min(timeout_each, left + 10.0),
+                               env=None if env is None else dict(os.environ, **env))
             rc, txt = r.returncode, r.stdout.decode(errors='replace')
         except subprocess.TimeoutExpired:
             rc, txt = 124, ''
@@ -683,7 +689,7 @@ def other_workloads(budget_s, timeout_each=150.0):
             if isinstance(o, dict) and 'ms_per_step' in o:
                 line = o
         if rc != 0 or line is None:
-            out.append(dict(workload=wl, failed=rc))
+            out.append(dict(workload=tag, failed=rc))
             continue
         ks = (line.get('roofline') or {}).get('kernels') or {}
         steps = line['steps']
@@ -695,7 +701,8 @@ def other_workloads(budget_s, timeout_each=150.0):
             k, v = max(hit, key=lambda kv: kv[1]['total_ms'])
             return dict(kernel=k, frac=v.get('frac'), useful_frac_of_pipe_peak=v.get('useful_frac_of_pipe_peak'),
                         ms_per_step=round(v['total_ms'] / steps, 4))
-        out.append(dict(workload=wl, desc=line['config']['workload'], ms_per_step=round(line['ms_per_step'], 4),
+        out.append(dict(workload=tag, desc=line['config']['workload'], mirror_groups=line['config'].get('antenna_mirror_groups'),
+                        ms_per_step=round(line['ms_per_step'], 4),
                         value=line['value'], unit=line['unit'], steps=steps, warmup=line['warmup'],
                         kernels=dict(fwd=kern('fringe_ant_fwd') or kern('fringe_fwd'), bwd=kern('fringe_ant_bwd') or kern('fringe_bwd')),
                         wall_s=round(time.perf_counter() - t1, 1)))
@@ -942,7 +949,9 @@ def main():
             gsync.remove()
         grad_bytes = sum(p.numel() * p.element_size() for p in params)
         vis_bytes = len(bls) * nt * cfg['Nf'] * 8
-        res = dict(shard=shard, label=label, dt=dt, prof=list(prof), vis_bytes=vis_bytes, grad_bytes=grad_bytes,
+        mg = sorted({tuple(g) for bg in rime._geom_cache.values() if bg['geom'].ant is not None
+                     for g in bg['geom'].ant.get('mirror_groups', [])})
+        res = dict(shard=shard, label=label, dt=dt, prof=list(prof), vis_bytes=vis_bytes, grad_bytes=grad_bytes, mirror=mg,
                    plan_load=None if plan is None else [round(x, 1) for x in plan['load']],
                    hook_order=None if gsync is None else list(gsync.fired),
                    order_adapted=None if gsync is None else gsync.adapted, check=check)
@@ -1102,6 +1111,9 @@ def main():
                                Npix_sky=int(len(inp['ra'])), Npix_visible=int((inp['zenaz'][0, 0] < 90).sum()),
                                Npoint=cfg['Npt'], beam='Airy D=14m on 1deg rect grid, linear PixelBeam interp',
                                loss='sum |V|^2 (fused chi-square epilogue, rime_chisq_fwd / _bwd)',
+                               # (mirror groups, 16-row groups) of the antenna blocks: groups whose second octet of rows holds the
+                               # MIRROR antennas of the first (r' - c = -(r - c)): conjugate phasors, not evaluated again
+                               antenna_mirror_groups=[list(g) for g in best['mirror']] or None,
                                parallelism=best['label']),
                    roofline=roof)
         if selfcheck is not None and not distributed:
@@ -1132,9 +1144,10 @@ def main():
                     and not args.no_other_workloads):
                 # outside the timed region and the CPU baseline; the C4 model is gone (run_mode freed it)
                 torch.cuda.empty_cache()
-                out['other_workloads'] = other_workloads(float(os.environ.get('BENCH_OTHER_BUDGET', '95')))
-                out['other_workloads_note'] = ('BASELINE configs 3, 2 and one rank\'s share of config 5 (64 of 512 channels), each a '
-                                               'short run of this script in a child process after the timed region and the CPU '
+                out['other_workloads'] = other_workloads(float(os.environ.get('BENCH_OTHER_BUDGET', '100')))
+                out['other_workloads_note'] = ('BASELINE configs 3, 2, one rank\'s share of config 5 (64 of 512 channels) and the headline '
+                                               'workload with the mirror-pair search off (an array of this size without point symmetry), '
+                                               'each a short run of this script in a child process after the timed region and the CPU '
                                                'baseline; frac = executed f16 MFMA flops / 2.5 PFLOP/s of the fringe kernel named')
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
