@@ -1018,7 +1018,7 @@ def main():
         # the process; a committed summary of separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over this same
         # command is quoted when one exists for the workload (else null) and its path is given
         traffic, traffic_source, clock, clock_src = None, None, None, None
-        for rel in ('profiles/r04/pmc_summary.json', 'profiles/r03/pmc_summary.json'):
+        for rel in ('profiles/r05/pmc_summary.json', 'profiles/r04/pmc_summary.json', 'profiles/r03/pmc_summary.json'):
             cpath = os.path.join(ROOT, rel)
             if traffic is None and args.workload == 'c4' and not distributed and not args.nf and os.path.exists(cpath):
                 try:

@@ -2,7 +2,7 @@
 # Round profile set on ONE MI355X (run through gpurun from the repo root): bench lines, rocprofv3 kernel stats and PMC
 # passes of the same command.  Outputs under gpurun_out/$1/ (copy what is to be judged into profiles/).
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
