@@ -19,6 +19,14 @@ for trial in range(ntrial):
     Npp, cplx = [(1, False), (2, False), (1, True), (4, True), (4, False)][int(rng.integers(0, 5))]
     frac = float(rng.choice([1.0, 0.6, 0.15]))
     ant = rng.normal(0, 70.0, (Nant, 3)); ant[:, 2] *= 0.03
+    # round 5: half of the trials on arrays WITH point symmetry (mirror pairs: conjugate phasors) -- a random number of
+    # mirrored pairs about a centre off the origin, the rest without a partner, shuffled
+    sym = 'none'
+    if rng.random() < 0.5 and Nant >= 4:
+        npair = int(rng.integers(2, Nant // 2 + 1))
+        h = ant[:npair]
+        ant = np.vstack([h, -h, ant[2 * npair:]])[rng.permutation(Nant)] + rng.normal(0, 30.0, 3)
+        sym = '%d pairs' % npair
     pairs = [(i, j) for i in range(Nant) for j in range(i, Nant) if rng.random() < frac]
     if not pairs:
         pairs = [(0, Nant - 1)]
@@ -63,6 +71,8 @@ for trial in range(ntrial):
     eg = float((res[0][1] - res[1][1]).abs().max() / res[1][1].abs().max().clamp_min(1e-30))
     worst = [max(worst[0], ev), max(worst[1], eg)]
     flag = '' if (ev < 1e-5 and eg < 1e-4) else '   <-- FAIL'
-    print('trial %3d: Nant %3d Nbl %5d Nt %d Nf %2d P %4d Npp %d cplx %d conj %d uniform %d orient %-5s models %d (%d pairs) group %3d blocks %3d  vis %.1e grad %.1e%s' % (
-        trial, Nant, len(pairs), Nt, Nf, P, Npp, cplx, conj, uniform, orient, Nmod, Nmp, group, len(gm.ant['blocks']), ev, eg, flag), flush=True)
+    mg = gm.ant.get('mirror_groups', [])
+    print('trial %3d: Nant %3d Nbl %5d Nt %d Nf %2d P %4d Npp %d cplx %d conj %d uniform %d orient %-5s models %d (%d pairs) group %3d blocks %3d  sym %-9s mirror groups %-22s vis %.1e grad %.1e%s' % (
+        trial, Nant, len(pairs), Nt, Nf, P, Npp, cplx, conj, uniform, orient, Nmod, Nmp, group, len(gm.ant['blocks']), sym,
+        '+'.join('%d/%d' % g for g in mg) or '-', ev, eg, flag), flush=True)
 print('worst: vis %.2e grad %.2e' % tuple(worst))
