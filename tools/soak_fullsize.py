@@ -9,9 +9,18 @@ from bayeslim_amd import ops
 niter = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 T64 = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float64)
 worst = 0.0
-for Nant, P, Nf, group in ((128, 98304, 32, 128), (512, 393216, 2, 128), (128, 393216, 4, 32), (37, 24576, 64, 128), (96, 196608, 4, 128)):
-    rng = np.random.default_rng(Nant)
-    ant = rng.normal(0, 200.0, (Nant, 3)); ant[:, 2] = 0.0
+# (round 5) the first two cases are arrays WITH mirror pairs: the benchmark's HERA-128 (127-antenna hexagon + outrigger) and HERA-37
+for Nant, P, Nf, group in ((-128, 98304, 32, 128), (-37, 24576, 64, 128), (128, 98304, 32, 128), (512, 393216, 2, 128),
+                           (128, 393216, 4, 32), (37, 24576, 64, 128), (96, 196608, 4, 128)):
+    rng = np.random.default_rng(abs(Nant))
+    if Nant < 0:
+        from bayeslim_amd import utils
+        ant = utils._make_hex({128: 7, 37: 4}[-Nant], D=14.6)[1]
+        if Nant == -128:
+            ant = np.vstack([ant, [[250.0, 0.0, 0.0]]])
+        Nant = len(ant)
+    else:
+        ant = rng.normal(0, 200.0, (Nant, 3)); ant[:, 2] = 0.0
     pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
     antp = T64(ant).cuda()
     blvecs = antp[torch.as_tensor([b for _, b in pairs], device='cuda')] - antp[torch.as_tensor([a for a, _ in pairs], device='cuda')]
