@@ -1007,16 +1007,35 @@ def interp_gather(m, stencil, out_stride=None):
     return _InterpGather.apply(m, stencil, stencil.P if out_stride is None else int(out_stride))
 
 
-class _BeamSkyProduct(torch.autograd.Function):
-    """psky[r, q] = interp(bmap)[r, q] * sky[r, cut[q]] in one pass (see rime_beam_sky_fwd)"""
+class _NodeMajor(torch.autograd.Function):
+    """(R, Npix_beam) beam map -> node-major (Npix_beam, R) copy, the layout the fused psky builder gathers from (a node's value
+    for 4 channels is one vector load), as an autograd node of its own: a forward with several sky components (C4: diffuse +
+    point sources) transposes the map ONCE, and the components' node-major gradients are summed before the ONE transposition
+    back (round 5: one 34-MB transposing copy less each way per C4 step)"""
     @staticmethod
-    def forward(ctx, bmap, sky, st, cut, pos, Nt, Ps):
-        _require_cuda(bmap, sky)
-        R, Npb = bmap.shape
+    def forward(ctx, bmap):
+        return bmap.detach().t().contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        # one explicit transposition: everything upstream (the |.| of a power beam, the accumulation into .grad) then runs on a
+        # contiguous tensor instead of a transposed view
+        return g.t().contiguous()
+
+
+def node_major(bmap):
+    return _NodeMajor.apply(bmap)
+
+
+class _BeamSkyProduct(torch.autograd.Function):
+    """psky[r, q] = interp(bmap)[r, q] * sky[r, cut[q]] in one pass (see rime_beam_sky_fwd); bmapT = the NODE-MAJOR map"""
+    @staticmethod
+    def forward(ctx, bmapT, sky, st, cut, pos, Nt, Ps):
+        _require_cuda(bmapT, sky)
+        Npb, R = bmapT.shape
         Npix = sky.shape[1]
-        assert sky.shape[0] == R and Npb == st.Npb and st.P == Nt * Ps and bmap.dtype == sky.dtype
-        # the kernels gather from a node-major map [Npix_beam, R]: a node's value for 4 channels is one vector load
-        b, k = bmap.detach().t().contiguous(), sky.detach().contiguous()
+        assert sky.shape[0] == R and Npb == st.Npb and st.P == Nt * Ps and bmapT.dtype == sky.dtype
+        b, k = bmapT.detach().contiguous(), sky.detach().contiguous()
         code, rdt = _real_dtype(b)
         out = torch.empty((R, Nt * Ps), dtype=b.dtype, device=b.device)
         rc = lib.rime_beam_sky_fwd(code, _ptr(b), _ptr(k), _ptr(st.inds), _ptr(st.weights(rdt)), _ptr(cut),
@@ -1047,19 +1066,19 @@ class _BeamSkyProduct(torch.autograd.Function):
         rc = lib.rime_interp_scatter_bwd(code, 0, _ptr(T1), _ptr(st.csr_ptr), _ptr(st.csr_src), _ptr(st.weights(rdt)),
                                          R, Npb, Q, st.Nnn, _ptr(gmT), _stream())
         check(rc, 'rime_interp_scatter_bwd')
-        # one explicit transposition: everything upstream (the |.| of a power beam, the sum of the sky components' beam
-        # gradients, the accumulation into .grad) then runs on a contiguous tensor instead of a transposed view
-        return gmT.t().contiguous(), gsky, None, None, None, None, None
+        return gmT, gsky, None, None, None, None, None
 
 
-def beam_sky_product(bmap, sky, stencil, cut, pos, Nt, Ps):
+def beam_sky_product(bmap, sky, stencil, cut, pos, Nt, Ps, node_major_map=None):
     """
     Fused interpolate-cut-multiply of the 1-pol power-beam case: bmap (R, Npix_beam) and sky (R, Npix)
     real, same dtype; stencil an InterpStencil over the Nt*Ps (padded) pointing angles; cut int32
     (Nt*Ps) sky-pixel index per point (Npix = padding); pos int32 (Nt, Npix) its inverse per time step
     (-1 = not visible).  Returns psky (R, Nt*Ps).  Differentiable w.r.t. bmap and sky.
+    `node_major_map`: ops.node_major(bmap) made by the caller (shared by several calls on the same map); bmap is then ignored.
     """
-    return _BeamSkyProduct.apply(bmap, sky, stencil, cut, pos, int(Nt), int(Ps))
+    bT = node_major(bmap) if node_major_map is None else node_major_map
+    return _BeamSkyProduct.apply(bT, sky, stencil, cut, pos, int(Nt), int(Ps))
 
 
 class _Chisq(torch.autograd.Function):

@@ -292,6 +292,7 @@ class RIME(utils.Module):
         start = datetime.now().timestamp()
 
         vis = None
+        node_major = {}
         for i, comp in enumerate(comps):
             sky = comp.data
             dev = self._compute_device(sky)
@@ -313,7 +314,12 @@ class RIME(utils.Module):
                 # leading axes of length 1 are dropped by reshape (a view in the backward too: indexing them away
                 # costs a zero-fill + copy of the whole map / sky gradient per axis, 0.5 ms per C4 step)
                 b2 = bc.reshape(bc.shape[-2:]) if bc.numel() == bc.shape[-2] * bc.shape[-1] else bc[0, 0, 0]
-                ps = ops.beam_sky_product(b2, sky.reshape(sky.shape[-2:]), st, bg['cut32'], bg['pos'], Nt, Ps)
+                # the node-major copy the builder gathers from: made once per forward and shared by the sky components (the
+                # beam cache is one tensor object for the whole forward)
+                if node_major.get('of') is not bc:
+                    node_major.update(of=bc, bT=ops.node_major(b2))
+                ps = ops.beam_sky_product(b2, sky.reshape(sky.shape[-2:]), st, bg['cut32'], bg['pos'], Nt, Ps,
+                                          node_major_map=node_major['bT'])
                 ps = ps.reshape(1, 1, 1, ps.shape[0], Nt * Ps)
             else:
                 # beam at the FoV-cut angles of ALL time steps: one response evaluation / gather launch
