@@ -242,6 +242,52 @@ def all_gather_vis(vis_local, counts=None, group=None, dim=2, inverse=None):
     return PendingGather(vis_local, _GatherHandle(vis_local, counts, dim, group, async_op=False), inverse).wait()
 
 
+class _ReduceWait(torch.autograd.Function):
+    """autograd node of an all-reduce (sum) of partial visibilities: forward = wait; backward = the upstream gradient as it
+    is (d sum / d part = 1 on every rank: no communication)"""
+    @staticmethod
+    def forward(ctx, x, pending):
+        return pending._finish()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class PendingReduce:
+    """an all-reduce (sum) of this rank's PARTIAL visibilities in flight (pixel partition, SURVEY 8e: every rank contracts its
+    slice of the sky pixels for ALL baselines, times and channels; the visibility is the sum of the slices)"""
+    def __init__(self, x, group, async_op):
+        self.x = x
+        self.complex = x.is_complex()
+        buf = x.detach().contiguous().clone()
+        self.buf = torch.view_as_real(buf) if self.complex else buf
+        self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+    def _finish(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return torch.view_as_complex(self.buf) if self.complex else self.buf
+
+    def wait(self):
+        """summed tensor, connected to the autograd graph of the local partial sum"""
+        return _ReduceWait.apply(self.x, self)
+
+
+def all_reduce_vis_start(vis_partial, group=None):
+    """
+    Pixel partition: start the (async) sum of the ranks' partial visibilities -- the same tensor shape on every rank;
+    `.wait()` returns the full visibilities; differentiable (backward: the upstream gradient, unchanged).  Deterministic for
+    a given backend and world size (the backend's reduction order), not bit-identical to the unsharded sum.
+    """
+    return PendingReduce(vis_partial, group, async_op=True)
+
+
+def all_reduce_vis(vis_partial, group=None):
+    return PendingReduce(vis_partial, group, async_op=False).wait()
+
+
 # ---------------------------------------------------------------------------------------------
 # gradient exchange
 # ---------------------------------------------------------------------------------------------

@@ -132,13 +132,17 @@ def build_inputs(wl, nt, seed=0):
     return inp
 
 
-def build_model(inp, dev, bls, seed=0, fblock=None, nchunks=1, redundant=False, dtype=torch.float32):
+def build_model(inp, dev, bls, seed=0, fblock=None, nchunks=1, redundant=False, dtype=torch.float32, pblock=None):
     """
     The drop-in modules on the GPU for this rank's shard: the baseline list `bls` and, when
     `fblock = (f0, f1)` is given, the channel block [f0, f1).  Parameters are created FULL-SIZE
     and identical on every rank (same seed); a channel-sharded rank feeds its modules views of
     them, re-attached before every forward by the returned `attach()` (the reference's own
     parameter protocol: params may be non-leaf graph tensors that are re-set each forward).
+    `pblock = (r, w)`: the PIXEL partition -- this rank contracts the sky pixels r, r + w, r + 2 w, ... of the
+    diffuse component (its a_lm transform: those columns of Ylm) and the point sources r, r + w, ...; a strided deal, so that
+    every rank sees the same mix of declinations (contiguous HEALPix blocks are declination bands, some never above the
+    horizon); the visibilities of the ranks are partial sums.
     Returns (rime, leaf parameters, attach, per-channel parameter descriptors).
     dtype: float32 (the benchmark) or float64 (parity runs of the SAME model: the random parameters are drawn in
     float32 and widened, so both precisions see identical values; set the default dtype to match).
@@ -154,40 +158,53 @@ def build_model(inp, dev, bls, seed=0, fblock=None, nchunks=1, redundant=False, 
                                      freqs=freqs, device=dev, skip_reds=not redundant)
     tel = telescope_model.TelescopeModel((LON, LAT))
     gen = torch.Generator(device='cpu').manual_seed(seed)
-    Npix = len(inp['ra'])
-    angs = torch.as_tensor(np.stack([inp['ra'], inp['dec']]), device=dev)
+    psel = slice(None) if pblock is None else slice(int(pblock[0]), None, int(pblock[1]))
+    ra, dec, zenaz = inp['ra'][psel], inp['dec'][psel], inp['zenaz'][..., psel]
+    Npix = len(ra)
+    angs = torch.as_tensor(np.stack([ra, dec]), device=dev)
     if cfg.get('lmax'):
         # a_lm sky: params (1, 1, Nf, Ncoeff) complex -> map through AlmModel (HIP alm2pix kernels)
         from bayeslim_amd import sph_harm
         l, m = sph_harm.gen_lm(cfg['lmax'], real_field=True)
         A = sph_harm.AlmModel(l, m, real_output=True)
         A.device = dev
-        A.setup_Ylm(90.0 - inp['dec'], inp['ra'], generate=True)
+        A.setup_Ylm(90.0 - dec, ra, generate=True)
         amp = (1.0 / (1.0 + torch.as_tensor(np.asarray(l), dtype=draw)))[None, None, None, :]
         re = (torch.randn(1, 1, cfg['Nf'], len(l), generator=gen, dtype=draw) * amp).to(f32)
         im = (torch.randn(1, 1, cfg['Nf'], len(l), generator=gen, dtype=draw) * amp).to(f32)
         skyp = torch.nn.Parameter(torch.complex(re, im).to(dev))
         Rsky = sky_model.PixelSkyResponse(freqs, spatial_mode='alm', spat_LM=A, comp_params=False, device=dev)
     else:
-        skyp = torch.nn.Parameter(torch.randn(1, 1, cfg['Nf'], Npix, generator=gen, dtype=draw).to(dev, f32))
+        skyp = torch.nn.Parameter(torch.randn(1, 1, cfg['Nf'], len(inp['ra']), generator=gen, dtype=draw).to(dev, f32))
         Rsky = sky_model.PixelSkyResponse(freqs, device=dev)
-    diffuse = sky_model.PixelSky(skyp.detach()[:, :, f0:f1], angs, inp['px_area'], R=Rsky,
+    pixel_sky = not cfg.get('lmax')
+    sky_view = (lambda: skyp[:, :, f0:f1][..., psel]) if pixel_sky else (lambda: skyp[:, :, f0:f1])
+    diffuse = sky_model.PixelSky(sky_view().detach(), angs, inp['px_area'], R=Rsky,
                                  parameter=False, name='diffuse')
     leaves = [skyp]
     per_channel = [(skyp, 2)]                      # (parameter, channel axis)
     models = {'diffuse': diffuse}
-    for t, za in zip(inp['times'], inp['zenaz']):
-        tel.conv_cache[('diffuse', Npix, float(t))] = torch.as_tensor(za)
+    for t, za in zip(inp['times'], zenaz):
+        tel.conv_cache[('diffuse', Npix, float(t))] = torch.as_tensor(np.ascontiguousarray(za))
+    ptp = None
     if cfg['Npt'] > 0:
         pp = torch.ones(1, 1, 2, cfg['Npt'], dtype=f32)
         pp[..., 1, :] = -2.2
         R = sky_model.PointSkyResponse(freqs, freq_mode='powerlaw', f0=freqs_full[0], device=dev)
-        pts = sky_model.PointSky(pp.to(dev), torch.as_tensor(np.stack([inp['pt_ra'], inp['pt_dec']]), device=dev),
-                                 R=R, parameter=True, name='points')
+        if pblock is None:
+            pts = sky_model.PointSky(pp.to(dev), torch.as_tensor(np.stack([inp['pt_ra'], inp['pt_dec']]), device=dev),
+                                     R=R, parameter=True, name='points')
+            leaves.append(pts.params)              # power-law params are shared by all channels
+        else:
+            # pixel partition: a full-size leaf, this rank's sources as a view of it (re-attached before every forward)
+            ptp = torch.nn.Parameter(pp.to(dev))
+            pts = sky_model.PointSky(ptp.detach()[..., psel], torch.as_tensor(np.stack([inp['pt_ra'][psel], inp['pt_dec'][psel]]),
+                                                                          device=dev), R=R, parameter=False, name='points')
+            leaves.append(ptp)
         models['points'] = pts
-        leaves.append(pts.params)                  # power-law params are shared by all channels
-        for t, za in zip(inp['times'], inp['pt_zenaz']):
-            tel.conv_cache[('points', cfg['Npt'], float(t))] = torch.as_tensor(za)
+        npt = len(inp['pt_ra'][psel])
+        for t, za in zip(inp['times'], inp['pt_zenaz'][..., psel]):
+            tel.conv_cache[('points', npt, float(t))] = torch.as_tensor(np.ascontiguousarray(za))
     sky = sky_model.CompositeModel(models) if len(models) > 1 else diffuse
     if cfg.get('pol') == 4:
         # Stokes I map + fixed fractional Q, U, V -> (2, 2) coherency sky (complex): sky_model.Stokes2Coherency
@@ -240,8 +257,10 @@ def build_model(inp, dev, bls, seed=0, fblock=None, nchunks=1, redundant=False, 
 
     def attach():
         """(re-)attach this rank's views of the replicated leaf parameters (new graph each step)"""
-        diffuse.params = skyp[:, :, f0:f1]
+        diffuse.params = sky_view()
         beam.params = beamp[..., f0:f1, :]
+        if ptp is not None:
+            models['points'].params = ptp[..., psel]
 
     return rime, leaves, attach, per_channel
 
@@ -726,7 +745,7 @@ def main():
     ap.add_argument('--redundant', action='store_true',
                     help='NOT the headline configuration: simulate one baseline per redundant group and inflate to all '
                          'baselines (the reference\'s data_bls mechanism); N = 1 only')
-    ap.add_argument('--shard', default='auto', choices=['auto', 'freq', 'bl'],
+    ap.add_argument('--shard', default='auto', choices=['auto', 'freq', 'bl', 'pix'],
                     help='multi-GPU partition: channel blocks or baseline (tile) blocks; auto measures both, each in a '
                          'fresh worker process, and reports the faster one as `value`, the other under `alt`')
     ap.add_argument('--chunks', type=int, default=2,
@@ -827,11 +846,18 @@ def main():
     def run_mode(shard):
         """build this rank's shard, warm up, time `steps` steps; returns the measurements"""
         nonlocal collective_timeout
-        plan = None
+        plan, pblock = None, None
         if shard == 'freq':
             bounds = rdist.shard_bounds(cfg['Nf'], world)
             my_bls, fblock, gdim, counts, inverse = bls, bounds[rank], 4, [e - s for s, e in bounds], None
             label = 'channel-sharded x%d' % world
+        elif shard == 'pix':
+            # SURVEY 8(e)'s third axis (round 5; NOT in the default `auto` pair): every rank contracts every w-th sky pixel /
+            # point source for ALL baselines, times and channels; forward = all-reduce (sum) of the partial visibilities,
+            # backward = all-reduce of the gradients (a rank's sky gradient is non-zero on its own pixels only)
+            bounds, fblock, gdim, counts, inverse, my_bls = None, None, None, None, None, bls
+            pblock = (rank, world) if distributed else None
+            label = 'pixel-sharded x%d (every %d-th sky pixel / point source per rank)' % (world, world)
         else:
             bounds, fblock, gdim = None, None, 2
             if mfma_array and distributed:
@@ -852,7 +878,7 @@ def main():
                 my_bls, counts, inverse = bls[bb[rank][0]:bb[rank][1]], [e - s for s, e in bb], None
                 label = 'baseline-sharded x%d' % world
         rime, params, attach, per_channel = build_model(inp, dev, my_bls, fblock=fblock, nchunks=nchunks,
-                                                        redundant=args.redundant and not distributed)
+                                                        redundant=args.redundant and not distributed, pblock=pblock)
         if args.redundant and not distributed:
             label += '; %d of %d baselines simulated (one per redundant group), inflated through data_bls' % (
                 rime.Nsim_bls, len(my_bls))
@@ -893,6 +919,8 @@ def main():
                 return rime().data
 
             def gather_start(v):
+                if shard == 'pix':
+                    return rdist.all_reduce_vis_start(v)                                     # sum of the ranks' partial sums
                 return rdist.all_gather_vis_start(v, counts, dim=gdim, inverse=inverse)     # RCCL, async, differentiable
 
             trace = None

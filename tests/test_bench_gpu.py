@@ -47,6 +47,21 @@ def test_two_ranks_both_partitions_match_the_unsharded_float64_model(args, tiles
         assert plan is not None and len(plan) == 2
 
 
+@pytest.mark.parametrize('args', [
+    ['--workload', 'c2', '--nt', '4', '--steps', '2', '--warmup', '1'],
+    ['--workload', 'c4', '--nf', '8', '--nt', '2', '--steps', '1', '--warmup', '1'],
+])
+def test_two_ranks_pixel_partition_matches_the_unsharded_float64_model(args):
+    """`--shard pix` (round 5; SURVEY 8e's third axis, not in the default pair of modes): every rank contracts every second sky
+    pixel / point source for all baselines, times and channels, the partial visibilities are summed by a differentiable
+    all-reduce per time chunk and the gradients by all-reduce; same self-check, same tolerances"""
+    rc, res = _run(args + ['--shard', 'pix'])
+    assert rc == 0 and res is not None
+    assert res['n_gpus'] == 2 and res['dist']['shard'] == 'pix' and 'pixel-sharded x2' in res['config']['parallelism']
+    ck = res['dist']['selfcheck']
+    assert ck['ok'] and ck['vis_relmax'] < 1e-5 and ck['grad_relmax'] < 1e-4, ck
+
+
 def test_a_wrong_gather_order_fails_the_selfcheck_and_the_other_mode_survives():
     """the self-check is not decorative: with the tile shards' inverse permutation left out (BENCH_BREAK_INVERSE=1, a
     test-only switch) the gathered baselines are in rank order, the `bl` worker fails its self-check (exit code 5) and the

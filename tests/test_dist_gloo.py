@@ -239,6 +239,61 @@ def _worker_noncontig(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_pix(rank, world, port, q):
+    """pixel partition (SURVEY 8e): every rank contracts every world-th sky pixel for ALL baselines, times and channels;
+    forward = differentiable all-reduce of the partial visibilities (async, per time chunk), backward = all-reduce of the
+    gradients (full-size leaves, each rank's sky gradient non-zero on its own pixels only)"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        blvecs, freqs, zen, az, sky, beam = _problem()
+        sky = sky.clone().requires_grad_(True)
+        beam = beam.clone().requires_grad_(True)
+        sel = slice(rank, None, world)
+        Nt = zen.shape[0]
+        w = torch.as_tensor(np.random.default_rng(9).normal(size=(1, 1, len(blvecs), Nt, len(freqs))))
+        sync = rdist.GradSync(shared=[sky, beam])
+
+        def forward_chunk(k):
+            return _simulate(blvecs, freqs, zen[k:k + 1, sel], az[k:k + 1, sel], sky[..., sel], beam[..., sel])
+
+        def loss_fn(full, k):
+            return (w[:, :, :, k:k + 1] * (full.real ** 2 + full.imag ** 2)).sum()
+
+        tot = rdist.pipelined_step(forward_chunk, Nt, loss_fn, rdist.all_reduce_vis_start, sync)
+        sync.remove()
+        blocking = rdist.all_reduce_vis(forward_chunk(0).detach())
+        q.put((rank, float(tot), sky.grad.numpy(), beam.grad.numpy(), blocking.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_pixel_partition_equals_single_process(world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pix, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    blvecs, freqs, zen, az, sky, beam = _problem()
+    sky = sky.clone().requires_grad_(True)
+    beam = beam.clone().requires_grad_(True)
+    full = _simulate(blvecs, freqs, zen, az, sky, beam)
+    w = torch.as_tensor(np.random.default_rng(9).normal(size=tuple(full.shape)))
+    loss = (w * (full.real ** 2 + full.imag ** 2)).sum()
+    loss.backward()
+    for rank, tot, gs, gb, v0 in res:
+        assert abs(tot - float(loss)) < 1e-9 * abs(float(loss))
+        assert np.abs(v0 - full.detach().numpy()[:, :, :, :1]).max() < 1e-12 * np.abs(full.detach().numpy()).max()
+        assert np.abs(gs - sky.grad.numpy()).max() < 1e-9 * np.abs(sky.grad.numpy()).max()
+        assert np.abs(gb - beam.grad.numpy()).max() < 1e-9 * np.abs(beam.grad.numpy()).max()
+
+
 def test_all_reduce_grads_writes_back_through_noncontiguous_grads():
     """a transposed .grad (custom backwards return such views) must receive the reduced values"""
     world = 2

@@ -2,6 +2,7 @@
 (those are measured by the driver's multi-GPU runs): the slowest rank's shard of
   freq : contiguous channel blocks (rank 0's block; all blocks are equal)
   bl   : baseline-tile shards (dist.plan_tile_shards): the rank with the largest planned load
+  pix  : every world-th sky pixel / point source (round 5, SURVEY 8e's third axis): rank 0's share (all shares are equal)
 python tools/emulate_rank.py [workload] [nt] [nf]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -44,9 +45,12 @@ def timed(rime, params, attach):
 
 
 base = {}
-for mode in ('freq', 'bl'):
+for mode in ('freq', 'bl', 'pix'):
     for world in (1, 2, 4, 8):
-        if mode == 'freq':
+        if mode == 'pix':
+            rime, params, attach, _ = bench.build_model(inp, dev, bls, pblock=(0, world))
+            what = 'every %d-th sky pixel / point source' % world
+        elif mode == 'freq':
             fblock = rdist.shard_bounds(cfg['Nf'], world)[0]
             rime, params, attach, _ = bench.build_model(inp, dev, bls, fblock=fblock)
             what = 'channels %3d per rank' % (fblock[1] - fblock[0])
