@@ -56,11 +56,16 @@ for mode in ('freq', 'bl', 'pix'):
             what = 'channels %3d per rank' % (fblock[1] - fblock[0])
         else:
             plan = rdist.plan_tile_shards(bl_ants, len(inp['ants']), world)
-            r = int(np.argmax(plan['load']))
-            rime, params, attach, _ = bench.build_model(inp, dev, [bls[i] for i in plan['rank_bls'][r]])
-            rime.mfma_group, rime.mfma_mode = plan['group'], True
-            what = 'rank %d of the tile plan: groups of %d antennas, %d block(s), %d baselines, planned load %.0f of %.0f' % (
-                r, plan['group'], plan['nblocks'][r], len(plan['rank_bls'][r]), plan['load'][r], sum(plan['load']))
+            if plan is None:                                # fewer blocks than ranks (HERA-19): contiguous baseline blocks
+                s_, e_ = rdist.shard_bounds(len(bls), world)[0]
+                rime, params, attach, _ = bench.build_model(inp, dev, bls[s_:e_])
+                what = 'contiguous block of %d baselines' % (e_ - s_)
+            else:
+                r = int(np.argmax(plan['load']))
+                rime, params, attach, _ = bench.build_model(inp, dev, [bls[i] for i in plan['rank_bls'][r]])
+                rime.mfma_group, rime.mfma_mode = plan['group'], True
+                what = 'rank %d of the tile plan: groups of %d antennas, %d block(s), %d baselines, planned load %.0f of %.0f' % (
+                    r, plan['group'], plan['nblocks'][r], len(plan['rank_bls'][r]), plan['load'][r], sum(plan['load']))
         ms, enq = timed(rime, params, attach)
         base.setdefault(mode, ms)
         print('%-4s world %d: %s, %.2f ms/step (host enqueue %.2f ms), compute-only speedup %.2fx' % (
