@@ -295,7 +295,8 @@ __device__ __forceinline__ void ant_fwd_body(const AntArgs& A, unsigned char* sm
     // the result rows / columns of padding antennas, which have no baseline slot)
     // OCT8: the 8-wave real-psky cross blocks (arrays of more than 128 antennas, 1-pol): sweeps of 32 rows as OCTX below
     constexpr bool OCT8 = SH::CROSS && !SH::SELF && !CPLX && SH::NW == 8;
-    constexpr bool OCT = OCT8 || (!SH::CROSS && SH::TA != 3);     // three-row-tile blocks keep the two-half mapping (+ 0.5 % with this one)
+    // (three-row-tile blocks keep the two-half mapping -- + 0.5 % with this one -- unless they have mirror groups to gain from it)
+    constexpr bool OCT = OCT8 || (!SH::CROSS && (SH::TA != 3 || MIR));
     // the same idea for the 8-wave complex-psky blocks (128 x 128 cross blocks, 128-antenna self blocks; C5): a wave generates
     // one half of the panel for twice as many antennas per lane -- sweeps of 32 rows, rows 32 u + 2 ag + 16 ((W >> 1) & 1) + (W >> 2)
     constexpr bool OCTX = SH::CROSS && CPLX;
@@ -1690,10 +1691,10 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
     A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.vis = nullptr; A.ws = (float*)workspace;
     A.Nant = Nrows; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
     A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign; A.imsign = psky_complex < 0 ? -1.f : 1.f;
-    // mirror groups: diagonal blocks on a real plane, shapes whose generation walks octet pairs (1, 2, 4 row tiles; the packed
-    // shape: first row tile only); anything else evaluates every row (the mask is a licence, not an obligation)
+    // mirror groups: diagonal blocks on a real plane (the packed 33..48 shape: first row tile only); anything else evaluates
+    // every row (the mask is a licence, not an obligation)
     if (mirror < 0 || (Nrows > 0 && Nrows <= MF_NA && (mirror >> ((Nrows + 15) / 16)) != 0)) return RIME_EINVAL;
-    A.mirror = (!cross && !psky_complex && (Nrows + 31) / 32 != 3) ? mirror : 0;
+    A.mirror = (!cross && !psky_complex) ? mirror : 0;
     ant_split_plan(Nt, Nf, Pstride, A.S, A.panels_per_split);
     if (!workspace || workspace_bytes < rime_fringe_ant_workspace(Nbl, Nt, Nf, Pstride)) return RIME_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1723,8 +1724,8 @@ extern "C" int rime_fringe_ant_fwd_block(const double* antpos, int Nrows, int cr
     do {                                                                                                       \
         using SH = FwdShape<TA, TA, false>;                                                                    \
         if (A.mirror) {                                                                                        \
-            hipLaunchKernelGGL((fringe_ant_fwd_kernel<TA, true, (TA != 3)>), grid, dim3(SH::NW * 64), SH::LDS, st, A);  \
-            if (rowmin) hipLaunchKernelGGL((fringe_ant_fwd_kernel<TA, false, (TA != 3)>), grid, dim3(SH::NW * 64), SH::LDS, st, A); \
+            hipLaunchKernelGGL((fringe_ant_fwd_kernel<TA, true, true>), grid, dim3(SH::NW * 64), SH::LDS, st, A);  \
+            if (rowmin) hipLaunchKernelGGL((fringe_ant_fwd_kernel<TA, false, true>), grid, dim3(SH::NW * 64), SH::LDS, st, A); \
             break;                                                                                             \
         }                                                                                                      \
         hipLaunchKernelGGL((fringe_ant_fwd_kernel<TA, true>), grid, dim3(SH::NW * 64), SH::LDS, st, A);        \

@@ -159,9 +159,8 @@ int rime_fringe_ant_bwd(const double* antpos, const double* sdir, const double* 
  *       MIRROR antennas of rows 16 g + i, i < 8 -- antpos[16 g + 8 + i] = -antpos[16 g + i] (the block's positions are
  *       measured from the centre of symmetry; visibilities depend on position differences only), rows without an antenna
  *       in either octet zero.  Their phasors are complex conjugates: the kernels evaluate the first octet and conjugate
- *       it for the second (forward: real-plane passes of blocks of 1, 2 or 4 row tiles and the first row tile of the
- *       33..48-row shape; backward: every diagonal block).  A licence, not an obligation: other block kinds evaluate
- *       every row.  Bits at or beyond ceil(Nrows / 16) -> RIME_EINVAL.
+ *       it for the second (forward: the real-plane passes of every diagonal block -- the 33..48-row shape in its first row
+ *       tile only; backward: every diagonal block).  A licence, not an obligation: other block kinds evaluate every row.  Bits at or beyond ceil(Nrows / 16) -> RIME_EINVAL.
  * Forward blocks fill disjoint baseline slots of the slab workspace (every baseline must belong
  * to exactly one block); _finish sums the pixel splits and writes vis [Nbl, Nt, Nf].  Backward:
  * _prepare transposes gvis into the workspace once, every block reads it; blocks after the first that

@@ -364,8 +364,8 @@ def _symmetric_array(kind, rng):
 def test_fringe_sum_mirror_pairs(ops, kind, groups, conj, monkeypatch):
     """arrays with point symmetry (round 5): the antennas with r' - c = -(r - c) are found on the host, a diagonal block's rows
     are ordered so that the second octet of a 16-row group holds the mirror antennas of the first, and the kernels use the
-    conjugate of the first octet's phasors instead of evaluating them -- forward (1 / 2 / 4 row tiles, the packed 33..48
-    shape; 65..96 antennas: backward only) and backward, against the float64 oracle of the baseline formulation; both pair
+    conjugate of the first octet's phasors instead of evaluating them -- forward (1 / 2 / 3 / 4 row tiles, the packed 33..48
+    shape) and backward, against the float64 oracle of the baseline formulation; both pair
     orientations, a partial pair set, autocorrelations, antennas without a partner, a centre away from the origin; equal
     to 2e-6 -- not bitwise -- to the run without the pairing (RIME_MIRROR=0), whose geometry has no mirrored blocks"""
     rng = np.random.default_rng(abs(hash(kind)) % 1000)
