@@ -70,6 +70,11 @@ def test_bad_arguments_are_rejected_without_launching():
     assert lib.rime_fringe_row_scale_cplx(None, 1, 1, 1, 1, 0, 0, 0, 0, 64, one, None, None, None) == -1
     assert lib.rime_interp_scatter_rows_bwd(0, 0, one, 0, one, one, one, 4, 10, one, None) == -1           # row stride 0
     assert lib.rime_interp_scatter_rows_bwd(5, 0, one, 16, one, one, one, 4, 10, one, None) == -1          # unknown dtype
+    # round 5: the mirror mask of the block entry points -- a bit at or beyond ceil(Nrows / 16), or a negative mask
+    big = 1 << 20
+    assert lib.rime_fringe_ant_fwd_block(one, 40, 0, 8, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, one, big, None) == -1
+    assert lib.rime_fringe_ant_fwd_block(one, 40, 0, -1, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, one, big, None) == -1
+    assert lib.rime_fringe_ant_bwd_block(one, 128, 0, 256, one, one, one, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, 0, one, one, big, None) == -1
     # 16 384 pixels per forward block since round 4: the C4 diffuse launch (98 304 px, 8 x 256 rows) takes 6 slabs
     assert lib.rime_fringe_ant_workspace(8128, 8, 256, 98304) == 6 * 8128 * 8 * 256 * 8
     # workspace = S partial slabs of the vis tensor (forward) -- 0 when the grid is already large

@@ -37,11 +37,15 @@ int main()
     bad += rime_fringe_sum_fwd(0, d.data(), d.data(), d.data(), f.data(), off, nullptr, 1, 1, 1, 63, 1, 1, 0, 1, 1, 1e8, 1e6, 10.0, nullptr, f.data(), nullptr, 0, nullptr) != RIME_EINVAL;
     bad += rime_fringe_sum_fwd(0, d.data(), d.data(), d.data(), f.data(), off, nullptr, 1, 1, 1, 64, 1, 3, 0, 1, 1, 1e8, 1e6, 10.0, nullptr, f.data(), nullptr, 0, nullptr) != RIME_EINVAL;
     bad += rime_fringe_sum_fwd(0, d.data(), d.data(), d.data(), f.data(), off, nullptr, 1, 1, 1, 64, 1, 2, 1, 1, 1, 1e8, 1e6, 10.0, nullptr, f.data(), nullptr, 0, nullptr) != RIME_EUNSUPPORTED;
-    bad += rime_fringe_ant_fwd_block(d.data(), 129, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
-    bad += rime_fringe_ant_fwd_block(d.data(), 96, 64, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), 1 << 20, nullptr) != RIME_EINVAL;      // (64, 32): unsupported shape
-    bad += rime_fringe_ant_fwd_block(d.data(), 64, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 2, 1, 1, f.data(), 1 << 20, nullptr) != RIME_EUNSUPPORTED;  // complex pass on a diagonal block
-    bad += rime_fringe_ant_fwd_block(d.data(), 64, 32, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;       // complex needs st_p == 2
-    bad += rime_fringe_ant_bwd_block(d.data(), 64, 32, d.data(), d.data(), f.data(), tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 2, 1, 1, 0, f.data(), f.data(), 0, nullptr) != RIME_EWORKSPACE;
+    bad += rime_fringe_ant_fwd_block(d.data(), 129, 0, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
+    bad += rime_fringe_ant_fwd_block(d.data(), 96, 64, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), 1 << 20, nullptr) != RIME_EINVAL;      // (64, 32): unsupported shape
+    bad += rime_fringe_ant_fwd_block(d.data(), 64, 0, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 2, 1, 1, f.data(), 1 << 20, nullptr) != RIME_EUNSUPPORTED;  // complex pass on a diagonal block
+    bad += rime_fringe_ant_fwd_block(d.data(), 64, 32, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;       // complex needs st_p == 2
+    bad += rime_fringe_ant_bwd_block(d.data(), 64, 32, 0, d.data(), d.data(), f.data(), tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 2, 1, 1, 0, f.data(), f.data(), 0, nullptr) != RIME_EWORKSPACE;
+    // mirror mask (round 5): bits at or beyond ceil(Nrows / 16), or a negative mask -> RIME_EINVAL, before anything is launched
+    bad += rime_fringe_ant_fwd_block(d.data(), 40, 0, 8, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
+    bad += rime_fringe_ant_fwd_block(d.data(), 40, 0, -1, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
+    bad += rime_fringe_ant_bwd_block(d.data(), 128, 0, 256, d.data(), d.data(), f.data(), tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, 0, f.data(), f.data(), 1 << 20, nullptr) != RIME_EINVAL;
     bad += rime_eq2top(d.data(), d.data(), -1, d.data(), d.data(), 0.0, d.data(), d.data(), nullptr) != RIME_EINVAL;
     bad += rime_eq2top(d.data(), d.data(), 0, d.data(), d.data(), 0.0, d.data(), d.data(), nullptr) != RIME_OK;
     bad += rime_interp_gather_fwd(0, 0, nullptr, nullptr, nullptr, 1, 1, 1, 1, nullptr, 1, nullptr) == RIME_OK;
