@@ -673,7 +673,7 @@ OTHER_WORKLOADS = (('c3', [], None), ('c2', ['--steps', '20', '--warmup', '5'], 
                    ('c4', ['--steps', '5', '--warmup', '3'], {'RIME_MIRROR': '0'}))
 
 
-def other_workloads(budget_s, timeout_each=150.0):
+def other_workloads(budget_s, timeout_each=150.0, script=None):
     """
     VERDICT r04 item 2: the driver's one command times BASELINE configs[3] (C4).  After its timed region and the CPU baseline,
     OUTSIDE both, the N = 1 run also measures configs[2] (C3), configs[1] (C2) and ONE RANK'S SHARE of configs[4] (C5: 64 of
@@ -690,7 +690,7 @@ def other_workloads(budget_s, timeout_each=150.0):
         if left < 20.0:
             out.append(dict(workload=tag, skipped='time budget of the default run used up'))
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--no-cpu-baseline', '--no-other-workloads'] + \
+        cmd = [sys.executable, script or os.path.abspath(__file__), '--workload', wl, '--no-cpu-baseline', '--no-other-workloads'] + \
               (extra if extra else ['--steps', '5', '--warmup', '3'])
         t1 = time.perf_counter()
         try:

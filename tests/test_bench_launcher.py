@@ -93,6 +93,41 @@ def test_bench_main_becomes_the_launcher_before_touching_the_gpu(tmp_path):
     assert 'rank 0 needs GPU' in err or 'rank 1 needs GPU' in err or 'needs a GPU' in err, err[-2000:]
 
 
+def test_other_workloads_are_child_runs_that_cannot_lose_the_line(tmp_path):
+    """after the timed region the N = 1 default run measures configs 3, 2, the config-5 rank share and the
+    headline workload without mirror pairs in CHILD processes of the same script and attaches what they report; a child that
+    fails, prints nothing or hangs becomes an entry that says so, the budget stops further starts, the environment of the
+    no-mirror run reaches its child -- driven here with a stub in place of bench.py"""
+    stub = _stub(tmp_path, """
+        import argparse, json, os, sys, time
+        ap = argparse.ArgumentParser()
+        ap.add_argument('--workload'); ap.add_argument('--nf'); ap.add_argument('--steps', type=int, default=5)
+        ap.add_argument('--warmup', type=int, default=3)
+        ap.add_argument('--no-cpu-baseline', action='store_true'); ap.add_argument('--no-other-workloads', action='store_true')
+        a = ap.parse_args()
+        assert a.no_cpu_baseline and a.no_other_workloads
+        if a.workload == 'c2':
+            sys.exit(3)
+        if a.workload == 'c5':
+            print('no json here'); sys.exit(0)
+        k = dict(fringe_ant_fwd_kernel=dict(total_ms=10.0 * a.steps, frac=0.4, useful_frac_of_pipe_peak=0.1),
+                 fringe_ant_bwd_kernel=dict(total_ms=12.0 * a.steps, frac=0.5, useful_frac_of_pipe_peak=0.12),
+                 reduce_vis_kernel=dict(total_ms=0.1, frac=0.01))
+        print(json.dumps(dict(ms_per_step=23.0, value=1e8, unit='vis/s', steps=a.steps, warmup=a.warmup, roofline=dict(kernels=k),
+                              config=dict(workload='stub ' + a.workload, antenna_mirror_groups=None if os.environ.get('RIME_MIRROR') == '0' else [[7, 8]]))))
+        """)
+    res = bench.other_workloads(60.0, script=stub)
+    by = {r['workload']: r for r in res}
+    assert set(by) == {'c3', 'c2', 'c5', 'c4 [RIME_MIRROR=0]'}
+    assert by['c3']['ms_per_step'] == 23.0 and by['c3']['kernels']['fwd'] == dict(kernel='fringe_ant_fwd_kernel', frac=0.4,
+                                                                                useful_frac_of_pipe_peak=0.1, ms_per_step=10.0)
+    assert by['c3']['kernels']['bwd']['ms_per_step'] == 12.0 and by['c3']['mirror_groups'] == [[7, 8]]
+    assert by['c2'] == dict(workload='c2', failed=3) and by['c5'] == dict(workload='c5', failed=0)
+    assert by['c4 [RIME_MIRROR=0]']['mirror_groups'] is None            # the switch reached the child
+    res = bench.other_workloads(5.0, script=stub)                     # no budget: nothing is started
+    assert all('skipped' in r for r in res) and len(res) == 4
+
+
 def test_rank_process_refuses_a_world_size_other_than_gpus():
     env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], env=env, capture_output=True, timeout=300)
