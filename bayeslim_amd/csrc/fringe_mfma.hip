@@ -1007,6 +1007,315 @@ fringe_ant_fwd_packed_kernel(AntArgs A)
 }
 
 // ---------------------------------------------------------------------------------------
+// CONJUGATE-PAIR FORM (round 5): the pair matrix of a point-symmetric array from the phasors of HALF its antennas
+//
+// MIRROR PAIRS above stop evaluating the conjugate phasors but still CONTRACT them: the mirror rows sit in the operand images and
+// the matrix pipe multiplies the same numbers twice with a sign flipped.  With F "first" antennas (one of each pair; partner
+// i' of first i has E_i' = conj(E_i)) and X = sqrt(|psky| scale) E of the firsts only, ALL pairs of the 2 F antennas are
+//     A[i,j] = sum_p s_p conj(X_i) X_j = V[i , j]          V[i', j'] = conj(A[i,j])          (s_p = sign of psky)
+//     B[i,j] = sum_p s_p      X_i  X_j = V[i', j]          V[i , j'] = conj(B[i,j]),   B[i,i] = V[i', i]
+// and both come from the SAME three real products of the F-row images (Xr, Xi the planes):
+//     Pcc = Xr s Xr^T,  Pss = Xi s Xi^T,  Pcs = Xr s Xi^T:      A = (Pcc + Pss) + i (Pcs - Pcs^T),   B = (Pcc - Pss) + i (Pcs + Pcs^T)
+// i.e. the generic kernel's products of a 64-row block with the two halves of its real part kept in accumulators of their
+// own: 26 MFMAs per K step for up to 128 antennas instead of 100 (12 on the off-diagonal tile, 7 on each diagonal tile),
+// and 64 generated rows without the 64 conjugate copies.  Antennas without a partner take a row like a first (their B
+// entries towards a mirror that does not exist have no baseline slot).  CEN: when the firsts and singles fill all 64 rows,
+// ONE more antenna can still be served if it sits AT the centre of symmetry (the hub of a hexagon; the headline array is 63
+// pairs + an outrigger + the hub): its phasor is 1, so its visibilities V[c, j] = sum_p psky_p E_j are column sums of
+// the image, accumulated by the lanes that generate the rows (4 FMAs per generated pixel pair) and reduced in the epilogue.
+// The result goes out through the pair tables of a VIRTUAL 128-row block -- rows 0..63 the firsts, row 64 + i the mirror
+// of row i -- whose ten upper-triangular tiles are exactly A (tiles (0,0) (0,1) (1,1)), conj(A) ((2,2) (2,3) (3,3)) and
+// conj(B) ((0,2) (0,3) (1,2) (1,3)); the host (ops._pair_block) builds them with the rule of every diagonal block.
+// Deal: wave 0: Pcc, Pss of tile (0,1) (6 MFMAs per K step); wave 1: Pcs, Psc of tile (0,1) (6); wave 2: tile (0,0);
+// wave 3: tile (1,1) (7 each: hi x hi of Pcc and Pss, hi x lo of both -- the lo x hi products are their transposes --
+// and the three products of Pcs in the two accumulators of the generic kernel's diagonal form).
+// ---------------------------------------------------------------------------------------
+struct PairArgs : AntArgs {
+    const int* centre;         // CEN: [2][128] baseline slots receiving V[c, r] (first 128) / conj(V[c, r]) (last 128), r = virtual row
+};
+
+template <int W, bool SIGNED, bool CEN>
+__device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* smem)
+{
+    using SH = FwdShape<2, 2, false>;
+    constexpr int MF_IMG = SH::IMG, MF_BUF = SH::BUF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int f = __builtin_amdgcn_readfirstlane(blockIdx.x % A.Nf), ts = blockIdx.x / A.Nf;
+    const int t = __builtin_amdgcn_readfirstlane(ts / A.S), split = __builtin_amdgcn_readfirstlane(ts % A.S);
+
+    const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
+    const float scl = A.scale[t * A.Nf + f];
+    const float* arow = A.psky + (size_t)t * A.st_t + (size_t)f * A.st_f;
+    const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
+    const int st_p = __builtin_amdgcn_readfirstlane((int)A.st_p);
+
+    // generation: the half-panel mapping of the two-tile blocks -- lane = (pixel pair pp, row ag of an octet), this wave writes
+    // the 16-pixel half W & 1 for the octets of the wave pair W >> 1 (rows 32 (u >> 1) + 16 (W >> 1) + 8 (u & 1) + i)
+    const int pp = lane & 7, ag = lane >> 3;
+    constexpr int hf = W & 1;
+    constexpr int NGEN = 4;
+    const int orow = 16 * (W >> 1) + 2 * (ag & 3) + (ag >> 2);
+    auto octet_row = [&](int u) { return 32 * (u >> 1) + 8 * (u & 1) + orow; };
+    const int mrow = A.Nant - 16 * (W >> 1);
+    const int nk = min(NGEN, (max(mrow, 0) + 31) / 32 + (max(mrow - 8, 0) + 31) / 32);     // sweeps whose octet starts below Nant
+    double ax[NGEN], ay[NGEN], az[NGEN];
+#pragma unroll
+    for (int u = 0; u < NGEN; ++u) {
+        const int an = octet_row(u);
+        const bool ok = an < A.Nant;
+        ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
+        ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
+        az[u] = ok ? nu_c * A.antpos[3 * an + 2] : 0.0;
+    }
+
+    // waves 0, 1: acc[0], acc[1]; waves 2, 3: 0 cc hi x hi, 1 cc hi x lo, 2 ss hi x hi, 3 ss hi x lo, 4 cs (hi x hi + hi x lo), 5 sc (hi x lo)
+    constexpr int NACC = W < 2 ? 2 : 6;
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int s = 0; s < NACC; ++s)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
+    float cr[NGEN], ci[NGEN];                        // CEN: column sums of this lane's rows
+#pragma unroll
+    for (int u = 0; u < NGEN; ++u) { cr[u] = 0.f; ci[u] = 0.f; }
+
+    const int npanel = A.Pstride / MF_KP;
+    const int pbeg = __builtin_amdgcn_readfirstlane(split * A.panels_per_split);
+    const int pend = __builtin_amdgcn_readfirstlane(min(npanel, pbeg + A.panels_per_split));
+    if (pbeg >= pend) return;                        // uniform over the block
+
+    // panel fetch through buffer loads (see the generic kernel): descriptor in SGPRs + constant lane offset + scalar offset
+    double2 sx, sy, sz; float2 av;
+    const uint32_t lo_s = 16u * pp, lo_a0 = 8u * pp * (uint32_t)st_p, lo_a1 = lo_a0 + 4u * (uint32_t)st_p;
+    auto uniform_ptr = [](const void* q) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    };
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(sd), 0, __builtin_amdgcn_readfirstlane((int)min((long long)3 * A.Pstride * 8, 0x7fffffffLL)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(arow), 0, __builtin_amdgcn_readfirstlane((int)min((long long)A.Pstride * st_p * 4, 0x7fffffffLL)), 0x00020000);
+    auto fetch = [&](int panel) {
+        const int p0 = panel * MF_KP + 16 * hf;      // uniform
+        sx = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, p0 * 8, 0));
+        sy = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (A.Pstride + p0) * 8, 0));
+        sz = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (2 * A.Pstride + p0) * 8, 0));
+        const int so = p0 * st_p * 4;
+        av = make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a0, so, 0)),
+                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a1, so, 0)));
+    };
+    auto generate = [&](unsigned char* buf, int next_panel) {
+        const float w0 = __builtin_amdgcn_sqrtf(fabsf(av.x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av.y) * scl);
+        if (SIGNED && W < 2 && lane < 8)
+            *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
+                ((__float_as_uint(av.x) >> 16) & 0x8000u) | (__float_as_uint(av.y) & 0x80000000u);
+        // CEN: sum_p psky scale E = sum_p (+-w)(w E): the weight once more, with the sign of psky
+        float g0 = w0, g1 = w1;
+        if constexpr (CEN && SIGNED) {
+            g0 = __uint_as_float(__float_as_uint(w0) | (__float_as_uint(av.x) & 0x80000000u));
+            g1 = __uint_as_float(__float_as_uint(w1) | (__float_as_uint(av.y) & 0x80000000u));
+        }
+#pragma unroll
+        for (int u = 0; u < NGEN; ++u) {
+            if (u < nk) {
+                const double ph0 = phase3(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
+                const double ph1 = phase3(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
+                const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
+                const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
+                const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+                const float xr0 = w0 * c0, xr1 = w1 * c1, xi0 = w0 * s0, xi1 = w1 * s1;
+                uint32_t rh, rl, ih, il;
+                split2(xr0, xr1, rh, rl);
+                split2(xi0, xi1, ih, il);
+                if constexpr (CEN) {
+                    cr[u] = fmaf(g0, xr0, cr[u]); ci[u] = fmaf(g0, xi0, ci[u]);
+                    cr[u] = fmaf(g1, xr1, cr[u]); ci[u] = fmaf(g1, xi1, ci[u]);
+                }
+                unsigned char* o = buf + octet_row(u) * MF_ROWB + pp * 4 + 32 * hf;
+                *reinterpret_cast<uint32_t*>(o) = rh;
+                *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+            }
+        }
+        fetch(next_panel);
+    };
+
+    const int foff = (lane & 31) * MF_ROWB + (lane >> 5) * 16;   // fragment: row, k-half
+    auto contract = [&](const unsigned char* buf) {
+        auto frag = [&](int tile, int img, int im, int ks) {
+            return *reinterpret_cast<const uint4*>(buf + img * MF_IMG + tile * 32 * MF_ROWB + foff + im * 2 * MF_KP + 32 * ks);
+        };
+        auto sgn = [&](uint4 v, const uint4& sg) {
+            if constexpr (SIGNED) { v.x ^= sg.x; v.y ^= sg.y; v.z ^= sg.z; v.w ^= sg.w; }
+            return v;
+        };
+#pragma unroll
+        for (int ks = 0; ks < MF_NH; ++ks) {
+            uint4 sg = make_uint4(0, 0, 0, 0);
+            if constexpr (SIGNED) sg = *reinterpret_cast<const uint4*>(buf + 2 * MF_IMG + (2 * ks + (lane >> 5)) * 16);
+            if constexpr (W == 0) {                  // tile (0,1): Pcc -> acc[0], Pss -> acc[1]
+                const uint4 Lrh = sgn(frag(0, 0, 0, ks), sg), Lih = sgn(frag(0, 0, 1, ks), sg);
+                const uint4 Lrl = sgn(frag(0, 1, 0, ks), sg), Lil = sgn(frag(0, 1, 1, ks), sg);
+                const uint4 Brh = frag(1, 0, 0, ks), Bih = frag(1, 0, 1, ks), Brl = frag(1, 1, 0, ks), Bil = frag(1, 1, 1, ks);
+                acc[0] = RIME_MFMA(Lrh, Brh, acc[0]);
+                acc[1] = RIME_MFMA(Lih, Bih, acc[1]);
+                acc[0] = RIME_MFMA(Lrh, Brl, acc[0]);
+                acc[1] = RIME_MFMA(Lih, Bil, acc[1]);
+                acc[0] = RIME_MFMA(Lrl, Brh, acc[0]);
+                acc[1] = RIME_MFMA(Lil, Bih, acc[1]);
+            } else if constexpr (W == 1) {           // tile (0,1): Pcs = Lr.Bi -> acc[0], Psc = Li.Br -> acc[1]
+                const uint4 Lrh = sgn(frag(0, 0, 0, ks), sg), Lih = sgn(frag(0, 0, 1, ks), sg);
+                const uint4 Lrl = sgn(frag(0, 1, 0, ks), sg), Lil = sgn(frag(0, 1, 1, ks), sg);
+                const uint4 Brh = frag(1, 0, 0, ks), Bih = frag(1, 0, 1, ks), Brl = frag(1, 1, 0, ks), Bil = frag(1, 1, 1, ks);
+                acc[0] = RIME_MFMA(Lrh, Bih, acc[0]);
+                acc[1] = RIME_MFMA(Lih, Brh, acc[1]);
+                acc[0] = RIME_MFMA(Lrh, Bil, acc[0]);
+                acc[1] = RIME_MFMA(Lih, Brl, acc[1]);
+                acc[0] = RIME_MFMA(Lrl, Bih, acc[0]);
+                acc[1] = RIME_MFMA(Lil, Brh, acc[1]);
+            } else {                                 // diagonal tile W - 2: L and B are the same rows (up to the pixel sign)
+                constexpr int tt = W - 2;
+                const uint4 Brh = frag(tt, 0, 0, ks), Bih = frag(tt, 0, 1, ks), Brl = frag(tt, 1, 0, ks), Bil = frag(tt, 1, 1, ks);
+                const uint4 Lrh = sgn(Brh, sg), Lih = sgn(Bih, sg);
+                acc[0] = RIME_MFMA(Lrh, Brh, acc[0]);            // symmetric as it stands
+                acc[2] = RIME_MFMA(Lih, Bih, acc[2]);
+                acc[4] = RIME_MFMA(Lrh, Bih, acc[4]);
+                acc[1] = RIME_MFMA(Lrh, Brl, acc[1]);            // + its transpose = the lo x hi product
+                acc[3] = RIME_MFMA(Lih, Bil, acc[3]);
+                acc[5] = RIME_MFMA(Lih, Brl, acc[5]);            // its transpose = Lrl.Bih
+                acc[4] = RIME_MFMA(Lrh, Bil, acc[4]);
+            }
+        }
+    };
+
+    unsigned char* const buf0 = smem;
+    unsigned char* const buf1 = smem + MF_BUF;
+    fetch(pbeg);
+    generate(buf0, min(pbeg + 1, pend - 1));
+    __syncthreads();
+    for (int panel = pbeg; panel < pend; panel += 2) {
+        if (panel + 1 < pend) generate(buf1, min(panel + 2, pend - 1));
+        contract(buf0);
+        __syncthreads();
+        if (panel + 1 < pend) {
+            if (panel + 2 < pend) generate(buf0, min(panel + 3, pend - 1));
+            contract(buf1);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: slab ws[split][t][f][re|im][Nbl] as in the generic kernel, through the tables of the virtual 128-row block
+    float* dst = A.ws + (((size_t)split * A.Nt + t) * A.Nf + f) * 2 * A.Nbl;
+    const float inv = 1.0f / scl;
+    const int col = lane & 31, rb = 4 * (lane >> 5);
+    RIME_MFMA_SETTLE();
+    auto put = [&](int r, int c, float vr, float vi) {            // V[r, c] = vr + i vi
+        const int bd = A.pair_direct[r * MF_NA + c];
+        if (bd >= 0) { dst[bd] = vr; dst[(size_t)A.Nbl + bd] = vi; }
+        const int bc = A.pair_conj[r * MF_NA + c];
+        if (bc >= 0) { dst[bc] = vr; dst[(size_t)A.Nbl + bc] = -vi; }
+    };
+    auto put1 = [&](int r, int c, int im, float v) {              // one plane of V[r, c]
+        const int bd = A.pair_direct[r * MF_NA + c];
+        if (bd >= 0) dst[(size_t)im * A.Nbl + bd] = v;
+        const int bc = A.pair_conj[r * MF_NA + c];
+        if (bc >= 0) dst[(size_t)im * A.Nbl + bc] = im ? -v : v;
+    };
+    if constexpr (CEN) {
+        // the hub's visibilities: sum the column sums over the 8 pixel-pair lanes and the two half-panel waves of a row
+#pragma unroll
+        for (int u = 0; u < NGEN; ++u)
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { cr[u] += __shfl_xor(cr[u], o, 64); ci[u] += __shfl_xor(ci[u], o, 64); }
+        float* cs = reinterpret_cast<float*>(smem) + 4 * (32 * 33);          // [half][64 rows][re | im], behind the transposition tiles
+        if (pp == 0) {
+#pragma unroll
+            for (int u = 0; u < NGEN; ++u)
+                if (u < nk) { cs[(hf * 64 + octet_row(u)) * 2] = cr[u]; cs[(hf * 64 + octet_row(u)) * 2 + 1] = ci[u]; }
+        }
+        __syncthreads();
+        if (tid < A.Nant) {                          // (Nant <= 64: wave 0)
+            const float vr = (cs[tid * 2] + cs[(64 + tid) * 2]) * inv, vi = (cs[tid * 2 + 1] + cs[(64 + tid) * 2 + 1]) * inv;
+            // V[c, j] = sum psky E_j for the first in row j, its conjugate for the mirror in row 64 + j
+            int b = A.centre[tid];
+            if (b >= 0) { dst[b] = vr; dst[(size_t)A.Nbl + b] = vi; }
+            b = A.centre[MF_NA + tid];
+            if (b >= 0) { dst[b] = vr; dst[(size_t)A.Nbl + b] = -vi; }
+            b = A.centre[64 + tid];
+            if (b >= 0) { dst[b] = vr; dst[(size_t)A.Nbl + b] = -vi; }
+            b = A.centre[MF_NA + 64 + tid];
+            if (b >= 0) { dst[b] = vr; dst[(size_t)A.Nbl + b] = vi; }
+        }
+    }
+    if constexpr (W < 2) {
+        // tile (0,1), element (i, j): A[i,j] -> V[i, j] and conj -> V[i', j'];  conj(B[i,j]) -> V[j, i'] and V[i, j']
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = (e & 3) + 8 * (e >> 2) + rb, j = 32 + col;
+            const float s = (acc[0][e] + acc[1][e]) * inv, d = (acc[0][e] - acc[1][e]) * inv;
+            if constexpr (W == 0) {                  // real parts: Ar = Pcc + Pss, Br = Pcc - Pss
+                put1(i, j, 0, s); put1(64 + i, 64 + j, 0, s);
+                put1(j, 64 + i, 0, d); put1(i, 64 + j, 0, d);
+            } else {                                 // imaginary parts: Ai = Pcs - Psc, Bi = Pcs + Psc
+                put1(i, j, 1, d); put1(64 + i, 64 + j, 1, -d);
+                put1(j, 64 + i, 1, -s); put1(i, 64 + j, 1, -s);
+            }
+        }
+    } else {
+        constexpr int tt = W - 2;
+        // a private 32 x 33 float tile per wave takes the transposes (the image buffers are free after the loop's last barrier)
+        float* tr = reinterpret_cast<float*>(smem) + W * (32 * 33);
+        auto transposed = [&](const f32x16& v) {
+            f32x16 tv;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tr[((e & 3) + 8 * (e >> 2) + rb) * 33 + col] = v[e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tv[e] = tr[col * 33 + (e & 3) + 8 * (e >> 2) + rb];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            return tv;
+        };
+        // Pcc = hh + hl + hl^T (same for Pss);  Pcs = (acc4 + acc5^T),  Pcs^T = acc4^T + acc5
+        f32x16 ar, br, ai, bi, x, y;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { x[e] = acc[1][e] + acc[3][e]; y[e] = acc[1][e] - acc[3][e]; }
+        const f32x16 xt = transposed(x), yt = transposed(y);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            ar[e] = (acc[0][e] + acc[2][e]) + (x[e] + xt[e]);
+            br[e] = (acc[0][e] - acc[2][e]) + (y[e] + yt[e]);
+            x[e] = acc[4][e] - acc[5][e]; y[e] = acc[4][e] + acc[5][e];
+        }
+        const f32x16 xt2 = transposed(x), yt2 = transposed(y);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { ai[e] = x[e] - xt2[e]; bi[e] = y[e] + yt2[e]; }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = 32 * tt + (e & 3) + 8 * (e >> 2) + rb, j = 32 * tt + col;
+            put(i, j, ar[e] * inv, ai[e] * inv);
+            put(64 + i, 64 + j, ar[e] * inv, -ai[e] * inv);
+            put(j, 64 + i, br[e] * inv, -bi[e] * inv);
+        }
+    }
+}
+
+template <bool SIGNED, bool CEN>
+__global__ void __launch_bounds__(256, 2)
+fringe_pair_fwd_kernel(PairArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (row_is_signed(A) != SIGNED) return;              // uniform over the block
+    switch (threadIdx.x >> 6) {                          // wave-uniform: every wave runs the same barriers
+        case 0: pair_fwd_body<0, SIGNED, CEN>(A, smem); break;
+        case 1: pair_fwd_body<1, SIGNED, CEN>(A, smem); break;
+        case 2: pair_fwd_body<2, SIGNED, CEN>(A, smem); break;
+        default: pair_fwd_body<3, SIGNED, CEN>(A, smem); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // backward:  gpsky[t,f,p] = Re sum_{i,j} E_i(p) conj(E_j(p)) G[i,j]
 //                        = sum_i ( Er_i Tr_i + Ei_i Ti_i ),   T_i(p) = sum_j conj(G[i,j]) E_j(p)
 // G[i,j] (tile(i) <= tile(j)) collects gvis of pair (i -> j) and the conjugate of pair (j -> i)
@@ -1466,6 +1775,233 @@ fringe_ant_bwd_cross_kernel(AntBwdArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// CONJUGATE-PAIR FORM, backward (round 5; forward: fringe_pair_fwd_kernel).  With e = c + i s the phasors of the F firsts,
+//     gpsky[p] = Re sum_ij ( a_ij conj(e_i) e_j + b_ij e_i e_j ),     a = conj(G_A),  b = conj(G_B)
+// where G_A[i,j] / G_B[i,j] collect the visibility gradients of the baselines that received A[i,j] / B[i,j] (and their
+// conjugates) in the forward -- the four pairs {i, j}, {i', j'}, {i', j}, {i, j'} of two mirror pairs in ONE complex entry
+// each.  In real planes
+//     gpsky = sum_i c_i ( N1 c + N3 s )_i + s_i ( N2 s + N4 c )_i,   N1 = ar + br,  N2 = ar - br,  N3 = -(ai + bi),  N4 = ai - bi
+// block-upper-triangular like a and b, so this is the generic diagonal backward at HALF the rows -- 64 phasors per pixel and
+// 12 + 9 + 9 MFMAs per 16-antenna K step pair (four planes on the off-diagonal tile; on a diagonal tile N1, N2 are
+// symmetrised and c^T N3 s + s^T N4 c = c^T (N3 + N4^T) s: three) -- 60 MFMAs per 32 pixels instead of 216 for 128 antennas.
+// The hub (CEN, see the forward) adds sum_j u_j c_j + v_j s_j with two real vectors: they are the INITIAL values of the
+// accumulators.  G is scaled by gscale / 8: an entry sums up to eight gradients.
+// ---------------------------------------------------------------------------------------
+struct PairBwdArgs : AntBwdArgs {
+    const int* centre;         // CEN: [2][128] slots of the hub's baselines (as PairArgs::centre)
+};
+
+constexpr int PB_PLANE = 3 * 2 * 2 * 32 * 16;         // bytes per plane: (tile, ks, h, row) x 8 f16; tiles (0,0) (0,1) (1,1)
+constexpr size_t PB_LDS = 8 * (size_t)PB_PLANE + 64 * 3 * sizeof(double) + 2 * 64 * sizeof(float);
+
+template <bool CEN>
+__global__ void __launch_bounds__(512, 2)
+fringe_pair_bwd_kernel(PairBwdArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* g_img = smem;              // planes: 0 N1, 1 N3, 2 N2, 3 N4 (hi), 4..7 the same (lo)
+    double* ant_lds = reinterpret_cast<double*>(smem + 8 * PB_PLANE);      // [64][3]
+    float* cen_u = reinterpret_cast<float*>(smem + 8 * PB_PLANE + 64 * 3 * sizeof(double));
+    float* cen_v = cen_u + 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = blockIdx.x % A.Nf, ts = blockIdx.x / A.Nf;
+    const int t = ts / A.S, split = ts % A.S;
+    const int TA = (A.Nant + 31) / 32;
+
+    // ---- staging: antenna coordinates (x sign nu / c), the eight planes in A-fragment order, the hub's vectors
+    const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
+    for (int i = tid; i < 64 * 3; i += 512) ant_lds[i] = (i < A.Nant * 3) ? nu_c * A.antpos[i] : 0.0;
+    const float gs = A.gscale[t * A.Nf + f] * 0.125f;
+    const float* gre = A.gvt + ((size_t)t * A.Nf + f) * 2 * A.Nbl;
+    const float* gim = gre + A.Nbl;
+    // gradient with respect to V[r, c] of the virtual 128-row block: direct slot + conjugate of the conj slot
+    auto grad_of = [&](int r, int c, float& vr, float& vi) {
+        const int bd = A.pair_direct[r * MF_NA + c];
+        if (bd >= 0) { vr += gre[bd]; vi += gim[bd]; }
+        const int bc = A.pair_conj[r * MF_NA + c];
+        if (bc >= 0) { vr += gre[bc]; vi -= gim[bc]; }
+    };
+    // a[i,j] = conj(g V[i,j]) + g V[i',j'];  b[i,j] = g V[j,i'] (+ g V[i,j'] on the off-diagonal tile): what the forward wrote where
+    auto entry = [&](int i, int j, bool off, float& ar, float& ai, float& br, float& bi) {
+        float xr = 0.f, xi = 0.f, yr = 0.f, yi = 0.f;
+        grad_of(i, j, xr, xi);
+        grad_of(64 + i, 64 + j, yr, yi);
+        ar = xr + yr; ai = yi - xi;
+        br = 0.f; bi = 0.f;
+        grad_of(j, 64 + i, br, bi);
+        if (off) grad_of(i, 64 + j, br, bi);
+    };
+    for (int e = tid; e < 3 * 2 * 2 * 32 * 4; e += 512) {
+        const int jp = e & 3, row = (e >> 2) & 31, h = (e >> 7) & 1, ks = (e >> 8) & 1, tile = e >> 9;
+        const int ti = tile == 2 ? 1 : 0, tj = tile == 0 ? 0 : 1;
+        const int i = 32 * ti + row;
+        const int j0 = 32 * tj + ((2 * jp) & 3) + 8 * (2 * ks + (jp >> 1)) + 4 * h;
+        float n1[2] = {0.f, 0.f}, n2[2] = {0.f, 0.f}, n3[2] = {0.f, 0.f}, n4[2] = {0.f, 0.f};
+        if (tj < TA) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = j0 + q;
+                float ar, ai, br, bi;
+                entry(i, j, ti != tj, ar, ai, br, bi);
+                if (ti != tj) {
+                    n1[q] = ar + br; n2[q] = ar - br; n3[q] = -(ai + bi); n4[q] = ai - bi;
+                } else {
+                    float tr, ti_, ur, ui;                        // the (j, i) element of the same tile
+                    entry(j, i, false, tr, ti_, ur, ui);
+                    n1[q] = 0.5f * ((ar + br) + (tr + ur));
+                    n2[q] = 0.5f * ((ar - br) + (tr - ur));
+                    n3[q] = (ti_ - ui) - (ai + bi);               // N3[i,j] + N4[j,i]
+                }
+            }
+        }
+        uint32_t hi_, lo_;
+        const int off = ((((tile * 2 + ks) * 2 + h) * 32 + row) * 4 + jp) * 4;
+        split2(n1[0] * gs, n1[1] * gs, hi_, lo_);
+        *reinterpret_cast<uint32_t*>(g_img + 0 * PB_PLANE + off) = hi_; *reinterpret_cast<uint32_t*>(g_img + 4 * PB_PLANE + off) = lo_;
+        split2(n3[0] * gs, n3[1] * gs, hi_, lo_);
+        *reinterpret_cast<uint32_t*>(g_img + 1 * PB_PLANE + off) = hi_; *reinterpret_cast<uint32_t*>(g_img + 5 * PB_PLANE + off) = lo_;
+        split2(n2[0] * gs, n2[1] * gs, hi_, lo_);
+        *reinterpret_cast<uint32_t*>(g_img + 2 * PB_PLANE + off) = hi_; *reinterpret_cast<uint32_t*>(g_img + 6 * PB_PLANE + off) = lo_;
+        split2(n4[0] * gs, n4[1] * gs, hi_, lo_);
+        *reinterpret_cast<uint32_t*>(g_img + 3 * PB_PLANE + off) = hi_; *reinterpret_cast<uint32_t*>(g_img + 7 * PB_PLANE + off) = lo_;
+    }
+    if constexpr (CEN) {
+        if (tid < 64) {
+            // Re(conj(g) V[c, j]) with V[c, j] = e_j (row j) and conj(e_j) (row 64 + j): u c_j + v s_j
+            float u = 0.f, v = 0.f;
+            int b = A.centre[tid];
+            if (b >= 0) { u += gre[b]; v += gim[b]; }
+            b = A.centre[MF_NA + tid];
+            if (b >= 0) { u += gre[b]; v -= gim[b]; }
+            b = A.centre[64 + tid];
+            if (b >= 0) { u += gre[b]; v -= gim[b]; }
+            b = A.centre[MF_NA + 64 + tid];
+            if (b >= 0) { u += gre[b]; v += gim[b]; }
+            cen_u[tid] = u * gs; cen_v[tid] = v * gs;
+        }
+    }
+    __syncthreads();
+
+    const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
+    float* orow = A.gpsky + (size_t)t * A.st_t + (size_t)f * A.st_f;
+    const float inv = 1.0f / gs;
+    const int h = lane >> 5;
+    const int ntile = A.Pstride / 32;
+    const int tbeg = split * A.tiles_per_split;
+    const int tend = min(ntile, tbeg + A.tiles_per_split);
+
+    uint32_t gl0 = (h * 32 + (lane & 31)) * 16, gl1 = gl0 + 4 * PB_PLANE;
+    asm volatile("" : "+v"(gl1));                     // opaque: keeps gl1 a second base register
+    for (int pt = tbeg + wave; pt < tend; pt += 8) {
+        const int p = pt * 32 + (lane & 31);
+        const double sx = sd[p], sy = sd[A.Pstride + p], sz = sd[2 * (size_t)A.Pstride + p];
+        f32x16 accR[2], accI[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if constexpr (CEN) {
+                    accR[q][e] = cen_u[32 * q + (e & 3) + 8 * (e >> 2) + 4 * h];
+                    accI[q][e] = cen_v[32 * q + (e & 3) + 8 * (e >> 2) + 4 * h];
+                } else { accR[q][e] = 0.f; accI[q][e] = 0.f; }
+            }
+        float part = 0.f;
+#pragma unroll
+        for (int tjr = 0; tjr < 2; ++tjr) {
+            const int tj = 1 - tjr;                          // descending: row tile tj completes here
+            if (tj < TA) {
+                float ec[16], es[16];                        // E of antennas 32 tj + (e&3) + 8 (e>>2) + 4 h
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (32 * tj + 16 * ks >= A.Nant) {           // uniform: 16 padding rows (their G rows and columns are zero)
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) { ec[8 * ks + jj] = 0.f; es[8 * ks + jj] = 0.f; }
+                        continue;
+                    }
+                    uint4 Erh, Erl, Eih, Eil;
+                    uint32_t* erh = reinterpret_cast<uint32_t*>(&Erh); uint32_t* erl = reinterpret_cast<uint32_t*>(&Erl);
+                    uint32_t* eih = reinterpret_cast<uint32_t*>(&Eih); uint32_t* eil = reinterpret_cast<uint32_t*>(&Eil);
+#pragma unroll
+                    for (int jq = 0; jq < 2; ++jq) {
+                        if (32 * tj + 16 * ks + 8 * jq >= A.Nant) {  // uniform: 8 padding rows
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { ec[8 * ks + 4 * jq + u] = 0.f; es[8 * ks + 4 * jq + u] = 0.f; }
+                            continue;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int jj = 4 * jq + u;
+                            const int an = 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
+                            const double ph = phase3(ant_lds[3 * an], sx, ant_lds[3 * an + 1], sy, ant_lds[3 * an + 2], sz);
+                            const float rr = turn_frac(ph);
+                            ec[8 * ks + jj] = __builtin_amdgcn_cosf(rr);
+                            es[8 * ks + jj] = __builtin_amdgcn_sinf(rr);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        split2_plain(ec[8 * ks + 2 * q], ec[8 * ks + 2 * q + 1], erh[q], erl[q]);
+                        split2_plain(es[8 * ks + 2 * q], es[8 * ks + 2 * q + 1], eih[q], eil[q]);
+                    }
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti) {
+                        if (ti <= tj) {
+                            const int tk = ((ti + tj) * 2 + ks) * 1024;
+                            const uint4 N1h = *reinterpret_cast<const uint4*>(g_img + gl0 + 0 * PB_PLANE + tk);
+                            const uint4 N3h = *reinterpret_cast<const uint4*>(g_img + gl0 + 1 * PB_PLANE + tk);
+                            const uint4 N2h = *reinterpret_cast<const uint4*>(g_img + gl0 + 2 * PB_PLANE + tk);
+                            const uint4 N1l = *reinterpret_cast<const uint4*>(g_img + gl1 + 0 * PB_PLANE + tk);
+                            const uint4 N3l = *reinterpret_cast<const uint4*>(g_img + gl1 + 1 * PB_PLANE + tk);
+                            const uint4 N2l = *reinterpret_cast<const uint4*>(g_img + gl1 + 2 * PB_PLANE + tk);
+                            if (ti == tj) {                  // (compile-time after unrolling) diagonal tile: three planes
+                                accR[ti] = RIME_MFMA(N1h, Erh, accR[ti]);
+                                accI[ti] = RIME_MFMA(N2h, Eih, accI[ti]);
+                                accR[ti] = RIME_MFMA(N3h, Eih, accR[ti]);
+                                accI[ti] = RIME_MFMA(N2h, Eil, accI[ti]);
+                                accR[ti] = RIME_MFMA(N1h, Erl, accR[ti]);
+                                accI[ti] = RIME_MFMA(N2l, Eih, accI[ti]);
+                                accR[ti] = RIME_MFMA(N3h, Eil, accR[ti]);
+                                accR[ti] = RIME_MFMA(N1l, Erh, accR[ti]);
+                                accR[ti] = RIME_MFMA(N3l, Eih, accR[ti]);
+                                continue;
+                            }
+                            const uint4 N4h = *reinterpret_cast<const uint4*>(g_img + gl0 + 3 * PB_PLANE + tk);
+                            const uint4 N4l = *reinterpret_cast<const uint4*>(g_img + gl1 + 3 * PB_PLANE + tk);
+                            accR[ti] = RIME_MFMA(N1h, Erh, accR[ti]);
+                            accI[ti] = RIME_MFMA(N2h, Eih, accI[ti]);
+                            accR[ti] = RIME_MFMA(N3h, Eih, accR[ti]);
+                            accI[ti] = RIME_MFMA(N4h, Erh, accI[ti]);
+                            accR[ti] = RIME_MFMA(N1h, Erl, accR[ti]);
+                            accI[ti] = RIME_MFMA(N2h, Eil, accI[ti]);
+                            accR[ti] = RIME_MFMA(N3h, Eil, accR[ti]);
+                            accI[ti] = RIME_MFMA(N4h, Erl, accI[ti]);
+                            accR[ti] = RIME_MFMA(N1l, Erh, accR[ti]);
+                            accI[ti] = RIME_MFMA(N2l, Eih, accI[ti]);
+                            accR[ti] = RIME_MFMA(N3l, Eih, accR[ti]);
+                            accI[ti] = RIME_MFMA(N4l, Erh, accI[ti]);
+                        }
+                    }
+                }
+                // row tile tj is complete: contract with E_i of the same antennas (lane-local)
+                RIME_MFMA_SETTLE();
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    part = fmaf(ec[e], accR[tj][e], part);
+                    part = fmaf(es[e], accI[tj][e], part);
+                }
+            }
+        }
+        part += __shfl_xor(part, 32, 64);
+        if (h == 0) {
+            float* o = orow + (size_t)p * A.st_p;
+            *o = A.accumulate ? *o + part * inv : part * inv;
+        }
+    }
+}
+
+
 // Power-of-two pre-scale (and minimum) of the rows the matrix-core kernels contract: scale = 2^floor(log2(2^14 / max|x|))
 // (1 for an all-zero row), rowmin = min x.  One block per row; rows are enumerated (d0, d1, d2, d3) in OUTPUT order and
 // found through four element strides, so a strided psky view needs no copy.  Replaces a dozen elementwise / reduction
@@ -1874,4 +2410,67 @@ extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, con
     if (rc != RIME_OK) return rc;
     return rime_fringe_ant_bwd_block(antpos, Nant, 0, 0, sdir, freqs, gscale, pair_direct, pair_conj, Nbl, Nt, Nf,
                                      Pstride, st_t, st_f, st_p, sign, 0, 0, gpsky, workspace, workspace_bytes, stream);
+}
+
+// ---- conjugate-pair form (fringe_pair_fwd_kernel / fringe_pair_bwd_kernel): one block of up to 64 rows -------------------
+static bool pair_common_ok(int Nrows, int Nbl, int Nt, int Nf, int Pstride, long long st_p, int sign)
+{
+    return Nrows > 0 && Nrows <= 64 && ant_common_ok(Nrows, 0, Nbl, Nt, Nf, Pstride, st_p, sign, 0) && st_p == 1;
+}
+
+extern "C" int rime_fringe_pair_fwd_block(const double* antpos, int Nrows, const int* centre, const double* sdir,
+                                          const double* freqs, const float* psky, const float* scale, const float* rowmin,
+                                          const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
+                                          long long st_t, long long st_f, long long st_p, int sign,
+                                          void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!antpos || !sdir || !freqs || !psky || !scale || !pair_direct || !pair_conj) return RIME_EINVAL;
+    if (!pair_common_ok(Nrows, Nbl, Nt, Nf, Pstride, st_p, sign)) return RIME_EINVAL;
+    PairArgs A{};
+    A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.psky = psky; A.scale = scale; A.rowmin = rowmin;
+    A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.vis = nullptr; A.ws = (float*)workspace;
+    A.Nant = Nrows; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
+    A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign; A.imsign = 1.f; A.mirror = 0;
+    A.centre = centre;
+    ant_split_plan(Nt, Nf, Pstride, A.S, A.panels_per_split);
+    if (!workspace || workspace_bytes < rime_fringe_ant_workspace(Nbl, Nt, Nf, Pstride)) return RIME_EWORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
+    using SH = FwdShape<2, 2, false>;
+    static_assert(SH::LDS >= 4 * 33 * 32 * 4 + 2 * 64 * 2 * 4, "epilogue scratch: transposition tiles + the hub's column sums");
+    if (centre) {
+        hipLaunchKernelGGL((fringe_pair_fwd_kernel<true, true>), grid, dim3(256), SH::LDS, st, A);
+        if (rowmin) hipLaunchKernelGGL((fringe_pair_fwd_kernel<false, true>), grid, dim3(256), SH::LDS, st, A);
+    } else {
+        hipLaunchKernelGGL((fringe_pair_fwd_kernel<true, false>), grid, dim3(256), SH::LDS, st, A);
+        if (rowmin) hipLaunchKernelGGL((fringe_pair_fwd_kernel<false, false>), grid, dim3(256), SH::LDS, st, A);
+    }
+    return check_launch();
+}
+
+extern "C" int rime_fringe_pair_bwd_block(const double* antpos, int Nrows, const int* centre, const double* sdir,
+                                          const double* freqs, const float* gscale, const int* pair_direct,
+                                          const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
+                                          long long st_t, long long st_f, long long st_p, int sign, int accumulate,
+                                          float* gpsky, const void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!antpos || !sdir || !freqs || !gscale || !pair_direct || !pair_conj || !gpsky) return RIME_EINVAL;
+    if (!pair_common_ok(Nrows, Nbl, Nt, Nf, Pstride, st_p, sign)) return RIME_EINVAL;
+    if (!workspace || workspace_bytes < rime_fringe_ant_bwd_workspace(Nbl, Nt, Nf)) return RIME_EWORKSPACE;
+    PairBwdArgs A{};
+    A.antpos = antpos; A.sdir = sdir; A.freqs = freqs; A.gvis = nullptr; A.gscale = gscale;
+    A.pair_direct = pair_direct; A.pair_conj = pair_conj; A.gpsky = gpsky; A.gvt = (const float*)workspace;
+    A.Nant = Nrows; A.Nbl = Nbl; A.Nt = Nt; A.Nf = Nf; A.Pstride = Pstride;
+    A.st_t = st_t; A.st_f = st_f; A.st_p = st_p; A.sign = (double)sign; A.accumulate = accumulate ? 1 : 0;
+    A.rows_i = 0; A.imsign = 1.f; A.mirror = 0; A.centre = centre;
+    const int ntile = Pstride / 32;
+    int per = 256;
+    while (per > 8 && (long)Nt * Nf * ((ntile + per - 1) / per) < 1024) per /= 2;
+    A.tiles_per_split = per;
+    A.S = (ntile + per - 1) / per;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
+    if (centre) hipLaunchKernelGGL(fringe_pair_bwd_kernel<true>, grid, dim3(512), PB_LDS, st, A);
+    else hipLaunchKernelGGL(fringe_pair_bwd_kernel<false>, grid, dim3(512), PB_LDS, st, A);
+    return check_launch();
 }

@@ -368,6 +368,81 @@ def _mirror_block(blk, P, dev):
                 direct=torch.as_tensor(direct.reshape(-1), device=dev), conj=torch.as_tensor(conj.reshape(-1), device=dev))
 
 
+# CONJUGATE-PAIR FORM (round 5; csrc/fringe_mfma.hip, "CONJUGATE-PAIR FORM"): a diagonal block of a point-symmetric array
+# contracted from the phasors of one antenna of every mirror pair.
+PAIR = _env_int('RIME_PAIR', 1) != 0            # RIME_PAIR=0: such blocks keep the mirror-pair kernels (A/B measurements)
+PAIR_ROWS = 64                                  # rows of the pair kernels (firsts + antennas without a partner)
+
+
+def _pair_layout(P):
+    """
+    Rows of the conjugate-pair form for antenna positions P (n, 3): (firsts, partner, hub, centre) -- firsts[k] the antenna
+    of row k, partner[k] its mirror antenna or -1, hub the antenna AT the centre that is served outside the rows (or None)
+    -- or None when the set has no point symmetry or does not fit: at most 64 rows, plus the hub when the rows are full.
+    """
+    found = _mirror_pairs(P)
+    if found is None:
+        return None
+    c, pairs, singles = found
+    hub = None
+    if len(pairs) + len(singles) > PAIR_ROWS:
+        at_c = [a for a in singles if np.abs(np.asarray(P[a]) - c).max() <= MIRROR_TOL]
+        if not at_c or len(pairs) + len(singles) - 1 > PAIR_ROWS:
+            return None
+        hub = at_c[0]
+        singles = [a for a in singles if a != hub]
+    firsts = [a for a, _ in pairs] + list(singles)
+    partner = [b for _, b in pairs] + [-1] * len(singles)
+    return firsts, partner, hub, c
+
+
+def _pair_block(blk, P, dev):
+    """the conjugate-pair form of a built diagonal block (include/rime_hip.h, rime_fringe_pair_fwd_block): positions of the
+    rows from the centre of symmetry, the pair tables of the virtual 128-row block (row k: firsts[k], row 64 + k: its
+    mirror), the hub's slot table; None when the block does not qualify.  Blocks of up to 64 antennas keep their kernels:
+    those are bound by operand generation, which the mirror-pair kernels already halve."""
+    n = int(blk['nrows'])
+    if blk['cross'] != 0 or n <= 64:
+        return None
+    lay = _pair_layout(P)
+    if lay is None:
+        return None
+    firsts, partner, hub, c = lay
+    vrow = -np.ones(n, dtype=np.int64)
+    for k, (a, b) in enumerate(zip(firsts, partner)):
+        vrow[a] = k
+        if b >= 0:
+            vrow[b] = 64 + k
+    direct = np.full((MFMA_GROUP, MFMA_GROUP), -1, dtype=np.int32)
+    conj = np.full((MFMA_GROUP, MFMA_GROUP), -1, dtype=np.int32)
+    centre = np.full((2, MFMA_GROUP), -1, dtype=np.int32)
+    od, oc = blk['direct'].reshape(MFMA_GROUP, MFMA_GROUP).cpu().numpy(), blk['conj'].reshape(MFMA_GROUP, MFMA_GROUP).cpu().numpy()
+    # direct[i, j] = b: baseline b runs from antenna i to antenna j; conj[i, j] = b: from j to i (_antenna_blocks)
+    for tab, swap in ((od, False), (oc, True)):
+        for i, j in zip(*np.nonzero(tab >= 0)):
+            a1, a2 = (j, i) if swap else (i, j)
+            if a1 == hub and a2 == hub:
+                return None                                      # the hub's autocorrelation: not a column sum of the image
+            if a1 == hub:
+                centre[0, vrow[a2]] = tab[i, j]
+            elif a2 == hub:
+                centre[1, vrow[a1]] = tab[i, j]
+            else:
+                r1, r2 = vrow[a1], vrow[a2]
+                if r1 // 32 <= r2 // 32:
+                    direct[r1, r2] = tab[i, j]
+                else:
+                    conj[r2, r1] = tab[i, j]
+    nslots = int((direct >= 0).sum()) + int((conj >= 0).sum()) + int((centre >= 0).sum())
+    assert nslots == int((od >= 0).sum()) + int((oc >= 0).sum())
+    pos = np.asarray(P)[firsts] - c
+    return dict(blk, pos=torch.as_tensor(pos, device=dev).contiguous(), nrows=len(firsts), mirror=0, pair=1,
+                firsts=list(firsts), partner=list(partner), hub=hub,
+                centre=None if hub is None else torch.as_tensor(centre.reshape(-1), device=dev),
+                cpass=0, fwd_cpass=0, self_pos=None, mf_self=0, mf_fwd=26, mf_bwd_real=30,
+                direct=torch.as_tensor(direct.reshape(-1), device=dev), conj=torch.as_tensor(conj.reshape(-1), device=dev))
+
+
 def _dense_strides(t):
     """element strides (time, model pair, pol product, channel) of a (Nt,Nmp,Npp,Nf,P) tensor whose
     pixel axis is contiguous, or None when the tensor cannot be passed as is"""
@@ -399,7 +474,7 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
     others take one pass per real plane.  Returns the MFMA flops executed.
     """
     a = geom.ant
-    blocks = a['blocks'] if cplx else a.get('blocks_mirror', a['blocks'])
+    blocks = a['blocks'] if cplx else a.get('blocks_real', a['blocks'])
     m = 2 if cplx else 1                                     # floats per psky element
     st_t, st_mp, st_pp, st_f = (int(strides[k]) * m for k in range(4))
     Nbl, Nt, Nf, Nmp = geom.Nbl, geom.Nt, geom.Nf, geom.Nmp
@@ -450,6 +525,13 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
                                                    *shape, cflag, _ptr(ws), ws.numel(), _stream())
                 check(rc, 'rime_fringe_ant_fwd_block')
                 return blk['mf_self']
+            if blk.get('pair'):                              # conjugate-pair form (real psky only: `blocks_real`)
+                rc = lib.rime_fringe_pair_fwd_block(_ptr(blk['pos']), blk['nrows'], _ptr(blk['centre']), *geo, src,
+                                                    _ptr(scale[mp, pp]), _ptr(rowmin[c][mp, pp]),
+                                                    _ptr(blk['direct']), _ptr(blk['conj']),
+                                                    *shape, _ptr(ws), ws.numel(), _stream())
+                check(rc, 'rime_fringe_pair_fwd_block')
+                return blk['mf_fwd']
             rc = lib.rime_fringe_ant_fwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], blk['mirror'], *geo, src,
                                                _ptr(scale[mp, pp]), _ptr(rowmin[c][mp, pp]),
                                                _ptr(blk['direct']), _ptr(blk['conj']),
@@ -501,6 +583,13 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
                     assert all((pl in written) == bool(acc) for pl in planes)
                     written.update(planes)
                     dst = ctypes.c_void_p(out.data_ptr() + 4 * (mp * st_mp + pp * st_pp + (0 if single else c)))
+                    if blk.get('pair'):
+                        rc = lib.rime_fringe_pair_bwd_block(_ptr(blk['pos']), blk['nrows'], _ptr(blk['centre']), *geo,
+                                                            _ptr(scale_pp), _ptr(blk['direct']), _ptr(blk['conj']),
+                                                            *shape, acc, dst, _ptr(ws), ws.numel(), _stream())
+                        check(rc, 'rime_fringe_pair_bwd_block')
+                        flops += blk['mf_bwd_real']
+                        continue
                     rc = lib.rime_fringe_ant_bwd_block(_ptr(blk['pos']), blk['nrows'], blk['cross'], blk['mirror'], *geo,
                                                        _ptr(scale_pp), _ptr(blk['direct']), _ptr(blk['conj']),
                                                        *shape, blk['cpass'] if single else 0, acc, dst,
@@ -600,9 +689,20 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
     if MIRROR:
         posh = pos.cpu().numpy()
         mb = [(_mirror_block(b, posh[np.asarray(r['ants_i'])], dev) if r['ants_j'] is None else None) for b, r in zip(blocks, raw)]
-        if any(m is not None for m in mb):
+        # ... and, where a block of more than 64 antennas fits into 64 rows of firsts (+ the hub), on the conjugate-pair form,
+        # which does not contract the mirror rows either
+        pb = [(_pair_block(b, posh[np.asarray(r['ants_i'])], dev) if (PAIR and r['ants_j'] is None) else None)
+              for b, r in zip(blocks, raw)]
+        if any(m is not None for m in mb) or any(q is not None for q in pb):
             self.ant['blocks_mirror'] = [m if m is not None else b for m, b in zip(mb, blocks)]
-            self.ant['mirror_groups'] = [(bin(m['mirror']).count('1'), (m['nrows'] + 15) // 16) for m in mb if m is not None]
+            self.ant['blocks_real'] = [q if q is not None else m for q, m in zip(pb, self.ant['blocks_mirror'])]
+            self.ant['mirror_groups'] = [(bin(m['mirror']).count('1'), (m['nrows'] + 15) // 16)
+                                         for m, q in zip(mb, pb) if m is not None and q is None]
+            self.ant['pair_blocks'] = [(sum(1 for x in q['partner'] if x >= 0), q['nrows'], int(q['hub'] is not None))
+                                       for q in pb if q is not None]
+            self.ant['mfma_fwd'] = sum(b['mf_fwd'] for b in self.ant['blocks_real'])
+            self.ant['mfma_bwd'] = sum(b['mf_bwd_real'] for b in self.ant['blocks_real'])
+            self.ant['mfma_flops_fwd'], self.ant['mfma_flops_bwd'] = per16 * self.ant['mfma_fwd'], per16 * self.ant['mfma_bwd']
 
 
 FringeGeometry._setup_antenna_path = _setup_antenna_path

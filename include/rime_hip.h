@@ -195,6 +195,31 @@ int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cross, int mi
                               int psky_complex, int accumulate, float* gpsky, const void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* Conjugate-pair form of a diagonal block, real psky (round 5; csrc/fringe_mfma.hip, "CONJUGATE-PAIR FORM").  Replaces the same
+ * reference lines as the blocks above (telescope_model.py:310-358 + rime_model.py:423-429) for an array with POINT SYMMETRY:
+ * antennas that come in mirror pairs about a centre c, r' - c = -(r - c), have conjugate phasors, and all pairs of up to
+ * 128 (+ 1) antennas follow from the phasors of one antenna of each pair.
+ *   antpos [Nrows <= 64, 3]: positions MEASURED FROM c of the "firsts" -- one antenna of every mirror pair -- and of the
+ *       antennas without a partner, one per row.
+ *   pair_direct / pair_conj: the tables of a VIRTUAL diagonal block of 128 rows -- row i < 64 = the antenna of antpos row i,
+ *       row 64 + i = its mirror antenna (no antenna: no entries) -- built by the rule of every diagonal block
+ *       (pair_direct[i*128 + j] = slot of baseline i -> j for tile(i) <= tile(j), else pair_conj[j*128 + i]).
+ *   centre: NULL, or int32 [2][128] for ONE more antenna that sits at c itself (its phasor is 1; needed when the firsts and
+ *       singles already fill 64 rows): centre[r] = slot of the baseline (hub -> virtual row r), centre[128 + r] = slot of
+ *       (virtual row r -> hub), or -1.
+ *   st_p must be 1; the other arguments, the workspace and _finish / _prepare are those of rime_fringe_ant_fwd_block /
+ *   rime_fringe_ant_bwd_block, and pair blocks mix with other blocks of the same launch sequence. */
+int rime_fringe_pair_fwd_block(const double* antpos, int Nrows, const int* centre, const double* sdir,
+                               const double* freqs, const float* psky, const float* scale, const float* rowmin,
+                               const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
+                               long long st_t, long long st_f, long long st_p, int sign,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int rime_fringe_pair_bwd_block(const double* antpos, int Nrows, const int* centre, const double* sdir,
+                               const double* freqs, const float* gscale, const int* pair_direct,
+                               const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
+                               long long st_t, long long st_f, long long st_p, int sign, int accumulate,
+                               float* gpsky, const void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * ICRS (ra, dec) -> topocentric (zenith angle, azimuth East of North), degrees, float64.
  * Replaces the per-direction part of telescope_model.eq2top (telescope_model.py:469-502,

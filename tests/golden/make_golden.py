@@ -620,17 +620,24 @@ def gen_rime_mfma_large(ba):
     """
     Reference outputs for the kernels of the HEADLINE configuration and of arrays beyond one antenna group: 128 random
     antennas (8128 baselines: the four-row-tile forward / backward kernels of config 4) and 150 random antennas (11 175
-    baselines: group blocks, i.e. diagonal + cross kernels); diffuse pixel sky (signed), rect-linear interpolated
+    baselines: group blocks, i.e. diagonal + cross kernels), and the headline array itself (127-antenna hexagon + outrigger:
+    the mirror-pair variants of the same kernels); diffuse pixel sky (signed), rect-linear interpolated
     PixelBeam, visibilities + gradients w.r.t. sky pixels and beam map.  Small in every other dimension (2 channels,
     2 times, 600 / 400 directions) so that the files stay below 1.5 MB each.
     """
-    for tag, Nant, Nf, Npix, seed in [('rand128', 128, 2, 600, 24), ('rand150', 150, 2, 400, 25)]:
+    for tag, Nant, Nf, Npix, seed in [('rand128', 128, 2, 600, 24), ('rand150', 150, 2, 400, 25), ('hex128', 128, 2, 600, 26)]:
         freqs = torch.linspace(130e6, 170e6, Nf)
         times = 2459861.0 + np.arange(2) * 10.0 / 1440
         rng = np.random.default_rng(seed)
-        vecs = np.stack([rng.uniform(-200, 200, Nant), rng.uniform(-200, 200, Nant), rng.normal(0, 0.5, Nant)], 1)
-        arr = ba.telescope_model.ArrayModel(ba.utils.AntposDict(list(range(Nant)), vecs), freqs=freqs,
-                                            cache_s=True, redtol=1.0)
+        if tag == 'hex128':
+            # the headline ARRAY itself (bench.py::hera_array('hera128')): 127-antenna hexagon + one outrigger, i.e. 63
+            # point-symmetric antenna pairs + 2 singles -- the layout the mirror-pair kernels are built for
+            arr = hex_array(ba, 7, freqs, extra=[[250.0, 0.0, 0.0]])
+            assert len(arr.ants) == Nant
+        else:
+            vecs = np.stack([rng.uniform(-200, 200, Nant), rng.uniform(-200, 200, Nant), rng.normal(0, 0.5, Nant)], 1)
+            arr = ba.telescope_model.ArrayModel(ba.utils.AntposDict(list(range(Nant)), vecs), freqs=freqs,
+                                                cache_s=True, redtol=1.0)
         tel = ba.telescope_model.TelescopeModel((21.42827, LAT))
         ra, dec = fib_sky(Npix)
         px_area = 4 * np.pi / Npix

@@ -479,6 +479,108 @@ def test_mirror_pairs_and_row_order():
     assert len(ops._mirror_pairs(ant)[1]) == 20
 
 
+def _pair_form_emulated(P, seed):
+    """numpy emulation of the conjugate-pair kernels' table logic (csrc/fringe_mfma.hip, pair_fwd_body's epilogue and
+    fringe_pair_bwd_kernel's staging) on the block ops._pair_block builds for positions P, all pairs with random orientation:
+    returns (rows, hub, forward error, backward error) against the baseline formulation in float64"""
+    from bayeslim_amd import ops
+    n = len(P)
+    rng = np.random.default_rng(seed)
+    bls = [(i, j) if rng.random() < 0.5 else (j, i) for i in range(n) for j in range(i + 1, n)]
+    raw = ops._antenna_blocks(bls, n)
+    assert len(raw) == 1
+    blk = dict(nrows=n, cross=0, mp=0, direct=torch.as_tensor(raw[0]['direct'].reshape(-1)), conj=torch.as_tensor(raw[0]['conj'].reshape(-1)))
+    Pb = P[np.asarray(raw[0]['ants_i'])]
+    q = ops._pair_block(blk, Pb, 'cpu')
+    if q is None:
+        return None
+    F, pos, npx = q['nrows'], q['pos'].numpy(), 24
+    s, w = rng.normal(size=(npx, 3)), rng.normal(size=npx)
+    E = np.zeros((64, npx), complex)
+    E[:F] = np.exp(2j * np.pi * (pos @ s.T))
+    A, B = np.conj(E) @ np.diag(w) @ E.T, E @ np.diag(w) @ E.T
+    direct, conj = q['direct'].numpy().reshape(128, 128), q['conj'].numpy().reshape(128, 128)
+    cen = None if q['centre'] is None else q['centre'].numpy().reshape(2, 128)
+    vis, cnt = np.zeros(len(bls), complex), np.zeros(len(bls), int)
+
+    def put(r, c, v):
+        for tab, val in ((direct[r, c], v), (conj[r, c], np.conj(v))):
+            if tab >= 0:
+                vis[tab] = val
+                cnt[tab] += 1
+    tiles = [(0, 1), (0, 0), (1, 1)]
+    for ti, tj in tiles:
+        for i in range(32 * ti, 32 * ti + 32):
+            for j in range(32 * tj, 32 * tj + 32):
+                put(i, j, A[i, j]); put(64 + i, 64 + j, np.conj(A[i, j])); put(j, 64 + i, np.conj(B[i, j]))
+                if ti != tj:
+                    put(i, 64 + j, np.conj(B[i, j]))
+    if cen is not None:
+        col = E @ w
+        for r in range(64):
+            for tab, val in ((cen[0][r], col[r]), (cen[1][r], np.conj(col[r])), (cen[0][64 + r], np.conj(col[r])), (cen[1][64 + r], col[r])):
+                if tab >= 0:
+                    vis[tab] = val
+                    cnt[tab] += 1
+    assert (cnt == 1).all()                                     # every baseline written exactly once
+    Fb = np.array([np.exp(2j * np.pi * ((Pb[b] - Pb[a]) @ s.T)) for a, b in bls])
+    ref = Fb @ w
+    g = rng.normal(size=len(bls)) + 1j * rng.normal(size=len(bls))
+    gref = np.real(np.conj(g) @ Fb)
+
+    def grad_of(r, c):
+        return (g[direct[r, c]] if direct[r, c] >= 0 else 0) + (np.conj(g[conj[r, c]]) if conj[r, c] >= 0 else 0)
+
+    def entry(i, j, off):
+        return np.conj(grad_of(i, j)) + grad_of(64 + i, 64 + j), grad_of(j, 64 + i) + (grad_of(i, 64 + j) if off else 0)
+    N1, N2, N3, N4 = (np.zeros((64, 64)) for _ in range(4))
+    for ti, tj in tiles:
+        for i in range(32 * ti, 32 * ti + 32):
+            for j in range(32 * tj, 32 * tj + 32):
+                a, b = entry(i, j, ti != tj)
+                if ti != tj:
+                    N1[i, j], N2[i, j], N3[i, j], N4[i, j] = a.real + b.real, a.real - b.real, -(a.imag + b.imag), a.imag - b.imag
+                else:
+                    a2, b2 = entry(j, i, False)
+                    N1[i, j] = 0.5 * ((a.real + b.real) + (a2.real + b2.real))
+                    N2[i, j] = 0.5 * ((a.real - b.real) + (a2.real - b2.real))
+                    N3[i, j] = (a2.imag - b2.imag) - (a.imag + b.imag)
+    accR, accI = N1 @ E.real + N3 @ E.imag, N2 @ E.imag + N4 @ E.real
+    if cen is not None:
+        for r in range(64):
+            for tab, sv in ((cen[0][r], 1), (cen[1][r], -1), (cen[0][64 + r], -1), (cen[1][64 + r], 1)):
+                if tab >= 0:
+                    accR[r] += g[tab].real
+                    accI[r] += sv * g[tab].imag
+    gp = (E.real * accR + E.imag * accI).sum(0)
+    return F, q['hub'], np.abs(vis - ref).max() / np.abs(ref).max(), np.abs(gp - gref).max() / np.abs(gref).max()
+
+
+def test_conjugate_pair_form_tables_and_algebra():
+    """round 5, host side of the conjugate-pair form (ops._pair_layout / _pair_block) and the algebra its kernels implement,
+    emulated in numpy: the headline array (63 pairs + outrigger in 64 rows, the hub outside them), a bare 127-antenna hexagon
+    (the hub takes the 64th row), a 91-antenna hexagon; every baseline is written exactly once and both directions agree with
+    the baseline formulation to float64 rounding.  Blocks of up to 64 antennas, sets without symmetry and sets whose
+    firsts and singles exceed 64 rows without a hub keep their kernels"""
+    from bayeslim_amd import ops
+    hex7 = np.asarray(utils._make_hex(7, D=14.6)[1])
+    hera128 = np.vstack([hex7, [[250.0, 0.0, 0.0]]]) + [3.0, -2.0, 0.5]
+    F, hub, ef, eb = _pair_form_emulated(hera128, 0)
+    assert F == 64 and hub is not None and np.abs(hera128[hub] - [3.0, -2.0, 0.5]).max() < 1e-9 and ef < 1e-11 and eb < 1e-11
+    F, hub, ef, eb = _pair_form_emulated(hex7, 1)
+    assert F == 64 and hub is None and ef < 1e-11 and eb < 1e-11
+    F, hub, ef, eb = _pair_form_emulated(np.asarray(utils._make_hex(6, D=14.6)[1]), 2)
+    assert F == 46 and hub is None and ef < 1e-11 and eb < 1e-11
+    rng = np.random.default_rng(5)
+    assert _pair_form_emulated(np.asarray(utils._make_hex(4, D=14.6)[1]), 3) is None             # 37 antennas: mirror-pair kernels
+    assert _pair_form_emulated(rng.normal(0, 60.0, (100, 3)), 4) is None                         # no symmetry
+    h = rng.normal(0, 60.0, (60, 3))
+    assert _pair_form_emulated(np.vstack([h, -h, rng.normal(0, 60.0, (8, 3))]), 5) is None       # 68 rows, no hub
+    lay = ops._pair_layout(np.vstack([h, -h, np.zeros((1, 3)), rng.normal(0, 60.0, (4, 3))]))    # 60 pairs + 4 singles + hub
+    assert lay is not None and len(lay[0]) == 64 and lay[2] == 120
+    assert ops._pair_layout(np.vstack([h, -h, np.zeros((1, 3)), rng.normal(0, 60.0, (5, 3))])) is None   # 65 rows + hub
+
+
 def test_antenna_block_tables():
     """pair tables of the matrix-core path: groups of <= 128 antennas, diagonal + cross blocks"""
     from bayeslim_amd import ops

@@ -345,13 +345,13 @@ def _symmetric_array(kind, rng):
     from bayeslim_amd import utils
     c = np.array([31.7, -12.3, 4.1])
     if kind.startswith('hex'):
-        side, extra = {'hex19': (3, 0), 'hex37': (4, 0), 'hex61': (5, 0), 'hex91': (6, 0), 'hex127+1': (7, 1)}[kind]
+        side, extra = {'hex19': (3, 0), 'hex37': (4, 0), 'hex61': (5, 0), 'hex91': (6, 0), 'hex127': (7, 0), 'hex127+1': (7, 1)}[kind]
         ant = utils._make_hex(side, D=14.6)[1]
         if extra:
             ant = np.vstack([ant, [[250.0, 3.0, 0.0]]])
     else:
         # `half` random antennas, their mirror images, `single` antennas without a partner; tilted (z matters)
-        half, single = {'rand45': (20, 5), 'rand70': (33, 4), 'rand128': (60, 8)}[kind]
+        half, single = {'rand45': (20, 5), 'rand70': (33, 4), 'rand100': (45, 10), 'rand128': (60, 8)}[kind]
         h = rng.normal(0, 70.0, (half, 3)) * [1, 1, 0.05]
         ant = np.vstack([h, -h, rng.normal(0, 70.0, (single, 3)) * [1, 1, 0.05]])
     ant = ant[rng.permutation(len(ant))] + c
@@ -383,6 +383,7 @@ def test_fringe_sum_mirror_pairs(ops, kind, groups, conj, monkeypatch):
     for t in range(Nt):
         sdir[t, :, :P] = orc.pointing_vectors(zenaz[t, 0], zenaz[t, 1])
     res = {}
+    monkeypatch.setattr(ops, 'PAIR', False)                  # (the conjugate-pair form has a test of its own below)
     for on in (True, False):
         monkeypatch.setattr(ops, 'MIRROR', on)
         geom = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, conj=conj, antpos=T64(ant).cuda(), bl_ants=pairs, mfma=True)
@@ -399,6 +400,58 @@ def test_fringe_sum_mirror_pairs(ops, kind, groups, conj, monkeypatch):
                         assert b < 0 or (a >= 0 and np.abs(pos[16 * g + i] + pos[16 * g + 8 + i]).max() < 1e-9)
         res[on] = _check_ant_path(ops, geom, psky, blvecs, zenaz, freqs, [0] * len(pairs), P, Ps, False, conj=conj).detach()
     assert not torch.equal(res[True], res[False])
+    assert relmax(res[True], res[False].cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize('kind,pairs_rows_hub', [('hex91', (45, 46, 0)), ('hex127', (63, 64, 0)), ('hex127+1', (63, 64, 1)),
+                                                 ('rand70', (33, 37, 0)), ('rand100', (45, 55, 0)), ('rand128', None)])
+@pytest.mark.parametrize('conj', [False, True])
+@pytest.mark.parametrize('full', [False, True])
+def test_fringe_sum_conjugate_pairs(ops, kind, pairs_rows_hub, conj, full, monkeypatch):
+    """conjugate-pair form (round 5): blocks of more than 64 antennas of a point-symmetric array run on the images of ONE antenna
+    of every mirror pair -- A = X^H s X and B = X^T s X from the same three real products (forward), the four real planes
+    N1..N4 (backward), the hub of a full block on the vector ALU -- against the float64 oracle of the baseline formulation:
+    46 / 64 / 37 / 55 rows, with and without the hub path, both pair orientations and fringe signs, a partial pair set with
+    autocorrelations and the full set; an array whose firsts and singles do not fit into 64 rows (60 pairs + 8 singles)
+    keeps the mirror-pair kernels.  Equal to 2e-6 to the run on those kernels (RIME_PAIR=0)."""
+    rng = np.random.default_rng(abs(hash(kind)) % 1000 + 7)
+    ant = _symmetric_array(kind, rng)
+    Nant, Nt, Nf, P = len(ant), 2, 5, 700
+    if full:
+        pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
+    else:
+        pairs = [(i, j) if rng.random() < 0.5 else (j, i) for i in range(Nant) for j in range(i + 1, Nant) if rng.random() < 0.9]
+        hub = int(np.argmin(np.abs(ant - ant.mean(0)).sum(1))) if kind == 'hex127+1' else -1
+        pairs += [(a, a) for a in range(Nant) if a % 40 == 3 and a != hub]       # (the hub's autocorrelation declines the form)
+        pairs = [pairs[k] for k in rng.permutation(len(pairs))]
+    blvecs = T64(np.stack([ant[b] - ant[a] for a, b in pairs]))
+    freqs = T64(np.linspace(120e6, 180e6, Nf))
+    zenaz = T64(np.stack([np.rad2deg(np.arccos(rng.uniform(0, 1, (Nt, P)))), rng.uniform(0, 360, (Nt, P))], axis=1))
+    psky = rng.normal(size=(Nt, 1, 1, Nf, P)) * np.exp(-9.0 * rng.uniform(size=(Nt, 1, 1, Nf, P)))
+    psky[1, :, :, 2] = np.abs(psky[1, :, :, 2])              # a row without a negative value: the mask-free instantiation
+    psky = torch.as_tensor(psky)
+    Ps = ops.pad_to_tile(P)
+    sdir = torch.zeros(Nt, 3, Ps, dtype=torch.float64)
+    for t in range(Nt):
+        sdir[t, :, :P] = orc.pointing_vectors(zenaz[t, 0], zenaz[t, 1])
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, 'PAIR', on)
+        geom = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, conj=conj, antpos=T64(ant).cuda(), bl_ants=pairs, mfma=True)
+        assert geom.ant is not None
+        if on and pairs_rows_hub is not None:
+            assert geom.ant['pair_blocks'] == [pairs_rows_hub], geom.ant['pair_blocks']
+            blk = geom.ant['blocks_real'][0]
+            assert blk['pair'] == 1 and (blk['centre'] is not None) == bool(pairs_rows_hub[2]) and geom.ant['mirror_groups'] == []
+            pos = blk['pos'].cpu().numpy()                       # rows: firsts and singles, measured from the centre
+            for k, (a, b) in enumerate(zip(blk['firsts'], blk['partner'])):
+                if b >= 0:
+                    assert np.abs((ant[a] - pos[k]) - (ant[b] + pos[k])).max() < 1e-9
+        else:
+            assert not geom.ant.get('pair_blocks')
+        res[on] = _check_ant_path(ops, geom, psky, blvecs, zenaz, freqs, [0] * len(pairs), P, Ps, False, conj=conj).detach()
+    if pairs_rows_hub is not None:
+        assert not torch.equal(res[True], res[False])
     assert relmax(res[True], res[False].cpu().numpy()) < 2e-6
 
 

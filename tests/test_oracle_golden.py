@@ -294,9 +294,10 @@ def test_rime_arrays_served_by_matrix_cores():
 
 
 def test_rime_large_arrays_served_by_matrix_cores():
-    """128 random antennas (the four-row-tile kernels of the headline configuration) and 150 (group blocks: diagonal + cross
-    kernels): reference outputs of tests/golden/make_golden.py::gen_rime_mfma_large"""
-    for tag, nbl in [('rand128', 8128), ('rand150', 11175)]:
+    """128 random antennas (the four-row-tile kernels of the headline configuration), 150 (group blocks: diagonal + cross
+    kernels) and the headline array itself (127-antenna hexagon + outrigger: the mirror-pair kernels): reference outputs of
+    tests/golden/make_golden.py::gen_rime_mfma_large"""
+    for tag, nbl in [('rand128', 8128), ('rand150', 11175), ('hex128', 8128)]:
         g = load_golden('rime_%s_mini' % tag)
         freqs = T(g['freqs'])
         sp = T(g['sky_params']).clone().requires_grad_(True)
