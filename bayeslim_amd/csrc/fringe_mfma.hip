@@ -83,6 +83,20 @@ __device__ __forceinline__ void split2_plain(float a, float b, uint32_t& hi, uin
     lo = pack_rtz(ra, rb);
 }
 
+// the split of two PRODUCTS (a0 b0, a1 b1) that are also read as f32 (p0, p1): the residuals a b - hi as one mixed-precision FMA
+// each on the exact product -- what the compiler makes of split2(a0 * b0, a1 * b1, ..) when the products have no other reader
+// (with one, it subtracts the rounded product: v_cvt_f32_f16 + v_sub_f32, two instructions per value)
+__device__ __forceinline__ void split2_prod(float a0, float b0, float a1, float b1, float& p0, float& p1, uint32_t& hi, uint32_t& lo)
+{
+    p0 = a0 * b0;
+    p1 = a1 * b1;
+    hi = pack_rtz(p0, p1);
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a0), "v"(b0), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(a1), "v"(b1), "v"(hi));
+    lo = pack_rtz(ra, rb);
+}
+
 // Phase of a phasor in turns: a.s = ax sx + ay sy + az sz in float64 (antenna coordinates pre-multiplied by sign nu / c), reduced to
 // its fraction as a float32 for v_sin_f32 / v_cos_f32 (a fixed-point reduction in the low mantissa bits saves two instructions
 // per phasor for 2.2 x the phase noise: measured, not adopted -- profiles/r04/phase_magic_ab.txt, tools/lab/).
@@ -1027,8 +1041,9 @@ fringe_ant_fwd_packed_kernel(AntArgs A)
 // of row i -- whose ten upper-triangular tiles are exactly A (tiles (0,0) (0,1) (1,1)), conj(A) ((2,2) (2,3) (3,3)) and
 // conj(B) ((0,2) (0,3) (1,2) (1,3)); the host (ops._pair_block) builds them with the rule of every diagonal block.
 // Deal: wave 0: Pcc, Pss of tile (0,1) (6 MFMAs per K step); wave 1: Pcs, Psc of tile (0,1) (6); wave 2: tile (0,0);
-// wave 3: tile (1,1) (7 each: hi x hi of Pcc and Pss, hi x lo of both -- the lo x hi products are their transposes --
-// and the three products of Pcs in the two accumulators of the generic kernel's diagonal form).
+// wave 3: tile (1,1) (7 each: (hi / 2) x hi + hi x lo of Pcc and of Pss -- the other halves are their transposes --
+// and the three products of Pcs in the two accumulators of the generic kernel's diagonal form).  164 registers: three
+// blocks per CU.
 // ---------------------------------------------------------------------------------------
 struct PairArgs : AntArgs {
     const int* centre;         // CEN: [2][128] baseline slots receiving V[c, r] (first 128) / conj(V[c, r]) (last 128), r = virtual row
@@ -1068,8 +1083,8 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
         az[u] = ok ? nu_c * A.antpos[3 * an + 2] : 0.0;
     }
 
-    // waves 0, 1: acc[0], acc[1]; waves 2, 3: 0 cc hi x hi, 1 cc hi x lo, 2 ss hi x hi, 3 ss hi x lo, 4 cs (hi x hi + hi x lo), 5 sc (hi x lo)
-    constexpr int NACC = W < 2 ? 2 : 6;
+    // waves 0, 1: acc[0], acc[1]; waves 2, 3: 0 half of Pcc, 1 half of Pss, 2 cs (hi x hi + hi x lo), 3 sc (hi x lo)
+    constexpr int NACC = W < 2 ? 2 : 4;
     f32x16 acc[NACC];
 #pragma unroll
     for (int s = 0; s < NACC; ++s)
@@ -1124,11 +1139,14 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
                 const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
                 const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                 const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
-                const float xr0 = w0 * c0, xr1 = w1 * c1, xi0 = w0 * s0, xi1 = w1 * s1;
                 uint32_t rh, rl, ih, il;
-                split2(xr0, xr1, rh, rl);
-                split2(xi0, xi1, ih, il);
-                if constexpr (CEN) {
+                if constexpr (!CEN) {
+                    split2(w0 * c0, w1 * c1, rh, rl);
+                    split2(w0 * s0, w1 * s1, ih, il);
+                } else {
+                    float xr0, xr1, xi0, xi1;
+                    split2_prod(w0, c0, w1, c1, xr0, xr1, rh, rl);
+                    split2_prod(w0, s0, w1, s1, xi0, xi1, ih, il);
                     cr[u] = fmaf(g0, xr0, cr[u]); ci[u] = fmaf(g0, xi0, ci[u]);
                     cr[u] = fmaf(g1, xr1, cr[u]); ci[u] = fmaf(g1, xi1, ci[u]);
                 }
@@ -1179,13 +1197,17 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
                 constexpr int tt = W - 2;
                 const uint4 Brh = frag(tt, 0, 0, ks), Bih = frag(tt, 0, 1, ks), Brl = frag(tt, 1, 0, ks), Bil = frag(tt, 1, 1, ks);
                 const uint4 Lrh = sgn(Brh, sg), Lih = sgn(Bih, sg);
-                acc[0] = RIME_MFMA(Lrh, Brh, acc[0]);            // symmetric as it stands
-                acc[2] = RIME_MFMA(Lih, Bih, acc[2]);
-                acc[4] = RIME_MFMA(Lrh, Bih, acc[4]);
-                acc[1] = RIME_MFMA(Lrh, Brl, acc[1]);            // + its transpose = the lo x hi product
-                acc[3] = RIME_MFMA(Lih, Bil, acc[3]);
-                acc[5] = RIME_MFMA(Lih, Brl, acc[5]);            // its transpose = Lrl.Bih
-                acc[4] = RIME_MFMA(Lrh, Bil, acc[4]);
+                // Pcc = h + h^T with h = (Lrh / 2).Brh + Lrh.Brl (the lo x hi product is the transpose of hi x lo), Pss alike: the
+                // halved fragments cost 8 v_pk_mul_f16 per K step and save two accumulators -- 164 registers instead of 196, i.e.
+                // THREE blocks per CU instead of two, which is worth 6 % here (profiles/r05/pair_form.txt)
+                const uint4 Hr = half_frag(Lrh), Hi = half_frag(Lih);
+                acc[0] = RIME_MFMA(Hr, Brh, acc[0]);
+                acc[1] = RIME_MFMA(Hi, Bih, acc[1]);
+                acc[2] = RIME_MFMA(Lrh, Bih, acc[2]);
+                acc[0] = RIME_MFMA(Lrh, Brl, acc[0]);
+                acc[1] = RIME_MFMA(Lih, Bil, acc[1]);
+                acc[3] = RIME_MFMA(Lih, Brl, acc[3]);            // its transpose = Lrl.Bih
+                acc[2] = RIME_MFMA(Lrh, Bil, acc[2]);
             }
         }
     };
@@ -1277,16 +1299,16 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             return tv;
         };
-        // Pcc = hh + hl + hl^T (same for Pss);  Pcs = (acc4 + acc5^T),  Pcs^T = acc4^T + acc5
+        // Pcc = h + h^T (acc 0), Pss alike (acc 1);  Pcs = acc2 + acc3^T,  Pcs^T = acc2^T + acc3
         f32x16 ar, br, ai, bi, x, y;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { x[e] = acc[1][e] + acc[3][e]; y[e] = acc[1][e] - acc[3][e]; }
+        for (int e = 0; e < 16; ++e) { x[e] = acc[0][e] + acc[1][e]; y[e] = acc[0][e] - acc[1][e]; }
         const f32x16 xt = transposed(x), yt = transposed(y);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            ar[e] = (acc[0][e] + acc[2][e]) + (x[e] + xt[e]);
-            br[e] = (acc[0][e] - acc[2][e]) + (y[e] + yt[e]);
-            x[e] = acc[4][e] - acc[5][e]; y[e] = acc[4][e] + acc[5][e];
+            ar[e] = x[e] + xt[e];
+            br[e] = y[e] + yt[e];
+            x[e] = acc[2][e] - acc[3][e]; y[e] = acc[2][e] + acc[3][e];
         }
         const f32x16 xt2 = transposed(x), yt2 = transposed(y);
 #pragma unroll
@@ -1302,7 +1324,7 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
 }
 
 template <bool SIGNED, bool CEN>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)
 fringe_pair_fwd_kernel(PairArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1793,10 +1815,14 @@ struct PairBwdArgs : AntBwdArgs {
 };
 
 constexpr int PB_PLANE = 3 * 2 * 2 * 32 * 16;         // bytes per plane: (tile, ks, h, row) x 8 f16; tiles (0,0) (0,1) (1,1)
+// four waves per block and <= 168 registers: THREE blocks per CU (51 KB of LDS each) -- 12 % faster than one block of eight waves
+// at 172 registers (profiles/r05/pair_form.txt): with a third of the matrix work of the generic kernel a wave waits more often
+// for its own phasors, and only other waves fill those slots
+constexpr int PB_THREADS = 256;
 constexpr size_t PB_LDS = 8 * (size_t)PB_PLANE + 64 * 3 * sizeof(double) + 2 * 64 * sizeof(float);
 
 template <bool CEN>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(PB_THREADS, 3)
 fringe_pair_bwd_kernel(PairBwdArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1805,14 +1831,14 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
     float* cen_u = reinterpret_cast<float*>(smem + 8 * PB_PLANE + 64 * 3 * sizeof(double));
     float* cen_v = cen_u + 64;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f = blockIdx.x % A.Nf, ts = blockIdx.x / A.Nf;
     const int t = ts / A.S, split = ts % A.S;
     const int TA = (A.Nant + 31) / 32;
 
     // ---- staging: antenna coordinates (x sign nu / c), the eight planes in A-fragment order, the hub's vectors
     const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
-    for (int i = tid; i < 64 * 3; i += 512) ant_lds[i] = (i < A.Nant * 3) ? nu_c * A.antpos[i] : 0.0;
+    for (int i = tid; i < 64 * 3; i += PB_THREADS) ant_lds[i] = (i < A.Nant * 3) ? nu_c * A.antpos[i] : 0.0;
     const float gs = A.gscale[t * A.Nf + f] * 0.125f;
     const float* gre = A.gvt + ((size_t)t * A.Nf + f) * 2 * A.Nbl;
     const float* gim = gre + A.Nbl;
@@ -1833,7 +1859,7 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
         grad_of(j, 64 + i, br, bi);
         if (off) grad_of(i, 64 + j, br, bi);
     };
-    for (int e = tid; e < 3 * 2 * 2 * 32 * 4; e += 512) {
+    for (int e = tid; e < 3 * 2 * 2 * 32 * 4; e += PB_THREADS) {
         const int jp = e & 3, row = (e >> 2) & 31, h = (e >> 7) & 1, ks = (e >> 8) & 1, tile = e >> 9;
         const int ti = tile == 2 ? 1 : 0, tj = tile == 0 ? 0 : 1;
         const int i = 32 * ti + row;
@@ -1892,9 +1918,8 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
     const int tbeg = split * A.tiles_per_split;
     const int tend = min(ntile, tbeg + A.tiles_per_split);
 
-    uint32_t gl0 = (h * 32 + (lane & 31)) * 16, gl1 = gl0 + 4 * PB_PLANE;
-    asm volatile("" : "+v"(gl1));                     // opaque: keeps gl1 a second base register
-    for (int pt = tbeg + wave; pt < tend; pt += 8) {
+    const uint32_t gl0 = (h * 32 + (lane & 31)) * 16;    // one lane base + 16-bit immediates reach all eight planes (48 KB)
+    for (int pt = tbeg + wave; pt < tend; pt += PB_THREADS / 64) {
         const int p = pt * 32 + (lane & 31);
         const double sx = sd[p], sy = sd[A.Pstride + p], sz = sd[2 * (size_t)A.Pstride + p];
         f32x16 accR[2], accI[2];
@@ -1952,9 +1977,9 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
                             const uint4 N1h = *reinterpret_cast<const uint4*>(g_img + gl0 + 0 * PB_PLANE + tk);
                             const uint4 N3h = *reinterpret_cast<const uint4*>(g_img + gl0 + 1 * PB_PLANE + tk);
                             const uint4 N2h = *reinterpret_cast<const uint4*>(g_img + gl0 + 2 * PB_PLANE + tk);
-                            const uint4 N1l = *reinterpret_cast<const uint4*>(g_img + gl1 + 0 * PB_PLANE + tk);
-                            const uint4 N3l = *reinterpret_cast<const uint4*>(g_img + gl1 + 1 * PB_PLANE + tk);
-                            const uint4 N2l = *reinterpret_cast<const uint4*>(g_img + gl1 + 2 * PB_PLANE + tk);
+                            const uint4 N1l = *reinterpret_cast<const uint4*>(g_img + gl0 + 4 * PB_PLANE + tk);
+                            const uint4 N3l = *reinterpret_cast<const uint4*>(g_img + gl0 + 5 * PB_PLANE + tk);
+                            const uint4 N2l = *reinterpret_cast<const uint4*>(g_img + gl0 + 6 * PB_PLANE + tk);
                             if (ti == tj) {                  // (compile-time after unrolling) diagonal tile: three planes
                                 accR[ti] = RIME_MFMA(N1h, Erh, accR[ti]);
                                 accI[ti] = RIME_MFMA(N2h, Eih, accI[ti]);
@@ -1968,7 +1993,7 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
                                 continue;
                             }
                             const uint4 N4h = *reinterpret_cast<const uint4*>(g_img + gl0 + 3 * PB_PLANE + tk);
-                            const uint4 N4l = *reinterpret_cast<const uint4*>(g_img + gl1 + 3 * PB_PLANE + tk);
+                            const uint4 N4l = *reinterpret_cast<const uint4*>(g_img + gl0 + 7 * PB_PLANE + tk);
                             accR[ti] = RIME_MFMA(N1h, Erh, accR[ti]);
                             accI[ti] = RIME_MFMA(N2h, Eih, accI[ti]);
                             accR[ti] = RIME_MFMA(N3h, Eih, accR[ti]);
@@ -2470,7 +2495,7 @@ extern "C" int rime_fringe_pair_bwd_block(const double* antpos, int Nrows, const
     A.S = (ntile + per - 1) / per;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
-    if (centre) hipLaunchKernelGGL(fringe_pair_bwd_kernel<true>, grid, dim3(512), PB_LDS, st, A);
-    else hipLaunchKernelGGL(fringe_pair_bwd_kernel<false>, grid, dim3(512), PB_LDS, st, A);
+    if (centre) hipLaunchKernelGGL(fringe_pair_bwd_kernel<true>, grid, dim3(PB_THREADS), PB_LDS, st, A);
+    else hipLaunchKernelGGL(fringe_pair_bwd_kernel<false>, grid, dim3(PB_THREADS), PB_LDS, st, A);
     return check_launch();
 }
