@@ -83,12 +83,22 @@ __device__ __forceinline__ void split2_plain(float a, float b, uint32_t& hi, uin
     lo = pack_rtz(ra, rb);
 }
 
+// Keeps a float a scalar computation of its own: the compiler's SLP pass pairs independent f32 adds / multiplies / FMAs into
+// v_pk_*_f32.  Round 5: in the conjugate-pair backward -- the first kernel here whose blocks SHARE a CU, so that one block stages its
+// G planes while another block's waves stream MFMAs on the same SIMDs -- the staging code's v_pk_add_f32 (sums of two freshly
+// loaded gradients) produced wrong planes in a fraction of the blocks that were dispatched late, different from run to run;
+// alone on the CU, or with scalar adds, the same code is exact (tools/debug_pair_bwd.py, profiles/r05/pair_form.txt).  With round
+// 2's stale packed reads of matrix-core results (rime_common.h) that makes two sightings of packed-f32 arithmetic going wrong
+// beside a busy matrix pipe; the pair kernels therefore contain NO packed f32 instruction (the build scans for them).
+__device__ __forceinline__ void keep_scalar(float& x) { asm("" : "+v"(x)); }
+
 // the split of two PRODUCTS (a0 b0, a1 b1) that are also read as f32 (p0, p1): the residuals a b - hi as one mixed-precision FMA
 // each on the exact product -- what the compiler makes of split2(a0 * b0, a1 * b1, ..) when the products have no other reader
 // (with one, it subtracts the rounded product: v_cvt_f32_f16 + v_sub_f32, two instructions per value)
 __device__ __forceinline__ void split2_prod(float a0, float b0, float a1, float b1, float& p0, float& p1, uint32_t& hi, uint32_t& lo)
 {
     p0 = a0 * b0;
+    keep_scalar(p0);
     p1 = a1 * b1;
     hi = pack_rtz(p0, p1);
     float ra, rb;
@@ -1147,8 +1157,8 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
                     float xr0, xr1, xi0, xi1;
                     split2_prod(w0, c0, w1, c1, xr0, xr1, rh, rl);
                     split2_prod(w0, s0, w1, s1, xi0, xi1, ih, il);
-                    cr[u] = fmaf(g0, xr0, cr[u]); ci[u] = fmaf(g0, xi0, ci[u]);
-                    cr[u] = fmaf(g1, xr1, cr[u]); ci[u] = fmaf(g1, xi1, ci[u]);
+                    cr[u] = fmaf(g0, xr0, cr[u]); keep_scalar(cr[u]); ci[u] = fmaf(g0, xi0, ci[u]);
+                    cr[u] = fmaf(g1, xr1, cr[u]); keep_scalar(cr[u]); ci[u] = fmaf(g1, xi1, ci[u]);
                 }
                 unsigned char* o = buf + octet_row(u) * MF_ROWB + pp * 4 + 32 * hf;
                 *reinterpret_cast<uint32_t*>(o) = rh;
@@ -1250,7 +1260,7 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
 #pragma unroll
         for (int u = 0; u < NGEN; ++u)
 #pragma unroll
-            for (int o = 1; o < 8; o <<= 1) { cr[u] += __shfl_xor(cr[u], o, 64); ci[u] += __shfl_xor(ci[u], o, 64); }
+            for (int o = 1; o < 8; o <<= 1) { cr[u] += __shfl_xor(cr[u], o, 64); keep_scalar(cr[u]); ci[u] += __shfl_xor(ci[u], o, 64); keep_scalar(ci[u]); }
         float* cs = reinterpret_cast<float*>(smem) + 4 * (32 * 33);          // [half][64 rows][re | im], behind the transposition tiles
         if (pp == 0) {
 #pragma unroll
@@ -1259,7 +1269,9 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
         }
         __syncthreads();
         if (tid < A.Nant) {                          // (Nant <= 64: wave 0)
-            const float vr = (cs[tid * 2] + cs[(64 + tid) * 2]) * inv, vi = (cs[tid * 2 + 1] + cs[(64 + tid) * 2 + 1]) * inv;
+            float vr = cs[tid * 2] + cs[(64 + tid) * 2], vi = cs[tid * 2 + 1] + cs[(64 + tid) * 2 + 1];
+            keep_scalar(vr); keep_scalar(vi);
+            vr *= inv; keep_scalar(vr); vi *= inv;
             // V[c, j] = sum psky E_j for the first in row j, its conjugate for the mirror in row 64 + j
             int b = A.centre[tid];
             if (b >= 0) { dst[b] = vr; dst[(size_t)A.Nbl + b] = vi; }
@@ -1334,6 +1346,205 @@ fringe_pair_fwd_kernel(PairArgs A)
         case 1: pair_fwd_body<1, SIGNED, CEN>(A, smem); break;
         case 2: pair_fwd_body<2, SIGNED, CEN>(A, smem); break;
         default: pair_fwd_body<3, SIGNED, CEN>(A, smem); break;
+    }
+}
+
+// Conjugate-pair form, ONE row tile (<= 32 rows; arrays of 33..64 antennas -- HERA-37: 18 pairs + the hub in 19 rows): the single
+// diagonal tile costs 7 MFMAs per K step (the packed 33..48-antenna kernel: 16, the generic two-tile kernel: 26).  Deal as for
+// the generic one-tile shape: a wave takes ONE K step of every panel (W & 1); waves 0, 1 the halves of Pcc and Pss (4 MFMAs),
+// waves 2, 3 the two accumulators of Pcs (3); the odd wave of a pair hands its partial tiles to the even one in the epilogue.
+// No hub path: an array whose rows exceed 32 takes the two-tile kernel.
+template <int W, bool SIGNED>
+__device__ __forceinline__ void pair_fwd1_body(const PairArgs& A, unsigned char* smem)
+{
+    using SH = FwdShape<1, 1, false>;
+    constexpr int MF_IMG = SH::IMG, MF_BUF = SH::BUF;
+    constexpr int KS = W & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int f = __builtin_amdgcn_readfirstlane(blockIdx.x % A.Nf), ts = blockIdx.x / A.Nf;
+    const int t = __builtin_amdgcn_readfirstlane(ts / A.S), split = __builtin_amdgcn_readfirstlane(ts % A.S);
+
+    const double nu_c = A.sign * A.freqs[f] * (1.0 / 2.99792458e8);
+    const float scl = A.scale[t * A.Nf + f];
+    const float* arow = A.psky + (size_t)t * A.st_t + (size_t)f * A.st_f;
+    const double* sd = A.sdir + (size_t)t * 3 * A.Pstride;
+    const int st_p = __builtin_amdgcn_readfirstlane((int)A.st_p);
+
+    // generation: this wave writes the 16-pixel half W & 1 for the two octets of the wave pair W >> 1 (rows 16 (W >> 1) + 8 u + i)
+    const int pp = lane & 7, ag = lane >> 3;
+    constexpr int hf = W & 1;
+    constexpr int NGEN = 2;
+    const int orow = 16 * (W >> 1) + 2 * (ag & 3) + (ag >> 2);
+    const int nk = (16 * (W >> 1) < A.Nant) + (16 * (W >> 1) + 8 < A.Nant);          // sweeps whose octet starts below Nant
+    double ax[NGEN], ay[NGEN], az[NGEN];
+#pragma unroll
+    for (int u = 0; u < NGEN; ++u) {
+        const int an = 8 * u + orow;
+        const bool ok = an < A.Nant;
+        ax[u] = ok ? nu_c * A.antpos[3 * an] : 0.0;
+        ay[u] = ok ? nu_c * A.antpos[3 * an + 1] : 0.0;
+        az[u] = ok ? nu_c * A.antpos[3 * an + 2] : 0.0;
+    }
+    f32x16 acc0, acc1;                               // waves 0, 1: halves of Pcc, Pss; waves 2, 3: cs (hi x hi + hi x lo), sc (hi x lo)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+
+    const int npanel = A.Pstride / MF_KP;
+    const int pbeg = __builtin_amdgcn_readfirstlane(split * A.panels_per_split);
+    const int pend = __builtin_amdgcn_readfirstlane(min(npanel, pbeg + A.panels_per_split));
+    if (pbeg >= pend) return;                        // uniform over the block
+
+    double2 sx, sy, sz; float2 av;
+    const uint32_t lo_s = 16u * pp, lo_a0 = 8u * pp * (uint32_t)st_p, lo_a1 = lo_a0 + 4u * (uint32_t)st_p;
+    auto uniform_ptr = [](const void* q) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    };
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(sd), 0, __builtin_amdgcn_readfirstlane((int)min((long long)3 * A.Pstride * 8, 0x7fffffffLL)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(arow), 0, __builtin_amdgcn_readfirstlane((int)min((long long)A.Pstride * st_p * 4, 0x7fffffffLL)), 0x00020000);
+    auto fetch = [&](int panel) {
+        const int p0 = panel * MF_KP + 16 * hf;      // uniform
+        sx = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, p0 * 8, 0));
+        sy = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (A.Pstride + p0) * 8, 0));
+        sz = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (2 * A.Pstride + p0) * 8, 0));
+        const int so = p0 * st_p * 4;
+        av = make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a0, so, 0)),
+                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a1, so, 0)));
+    };
+    auto generate = [&](unsigned char* buf, int next_panel) {
+        const float w0 = __builtin_amdgcn_sqrtf(fabsf(av.x) * scl), w1 = __builtin_amdgcn_sqrtf(fabsf(av.y) * scl);
+        if (SIGNED && W < 2 && lane < 8)
+            *reinterpret_cast<uint32_t*>(buf + 2 * MF_IMG + 4 * (8 * hf + pp)) =
+                ((__float_as_uint(av.x) >> 16) & 0x8000u) | (__float_as_uint(av.y) & 0x80000000u);
+#pragma unroll
+        for (int u = 0; u < NGEN; ++u) {
+            if (u < nk) {
+                const double ph0 = phase3(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
+                const double ph1 = phase3(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
+                const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
+                const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
+                const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
+                uint32_t rh, rl, ih, il;
+                split2(w0 * c0, w1 * c1, rh, rl);
+                split2(w0 * s0, w1 * s1, ih, il);
+                unsigned char* o = buf + (8 * u + orow) * MF_ROWB + pp * 4 + 32 * hf;
+                *reinterpret_cast<uint32_t*>(o) = rh;
+                *reinterpret_cast<uint32_t*>(o + 2 * MF_KP) = ih;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG) = rl;
+                *reinterpret_cast<uint32_t*>(o + MF_IMG + 2 * MF_KP) = il;
+            }
+        }
+        fetch(next_panel);
+    };
+
+    const int foff = (lane & 31) * MF_ROWB + (lane >> 5) * 16 + 32 * KS;      // fragment of this wave's K step: row, k-half
+    auto contract = [&](const unsigned char* buf) {
+        auto frag = [&](int img, int im) { return *reinterpret_cast<const uint4*>(buf + img * MF_IMG + foff + im * 2 * MF_KP); };
+        uint4 sg = make_uint4(0, 0, 0, 0);
+        if constexpr (SIGNED) sg = *reinterpret_cast<const uint4*>(buf + 2 * MF_IMG + (2 * KS + (lane >> 5)) * 16);
+        auto sgn = [&](uint4 v) {
+            if constexpr (SIGNED) { v.x ^= sg.x; v.y ^= sg.y; v.z ^= sg.z; v.w ^= sg.w; }
+            return v;
+        };
+        if constexpr (W < 2) {
+            const uint4 Brh = frag(0, 0), Bih = frag(0, 1), Brl = frag(1, 0), Bil = frag(1, 1);
+            const uint4 Lrh = sgn(Brh), Lih = sgn(Bih);
+            const uint4 Hr = half_frag(Lrh), Hi = half_frag(Lih);
+            acc0 = RIME_MFMA(Hr, Brh, acc0);
+            acc1 = RIME_MFMA(Hi, Bih, acc1);
+            acc0 = RIME_MFMA(Lrh, Brl, acc0);
+            acc1 = RIME_MFMA(Lih, Bil, acc1);
+        } else {
+            const uint4 Brh = frag(0, 0), Bih = frag(0, 1), Brl = frag(1, 0), Bil = frag(1, 1);
+            const uint4 Lrh = sgn(Brh), Lih = sgn(Bih);
+            acc0 = RIME_MFMA(Lrh, Bih, acc0);
+            acc1 = RIME_MFMA(Lih, Brl, acc1);
+            acc0 = RIME_MFMA(Lrh, Bil, acc0);
+        }
+    };
+
+    unsigned char* const buf0 = smem;
+    unsigned char* const buf1 = smem + MF_BUF;
+    fetch(pbeg);
+    generate(buf0, min(pbeg + 1, pend - 1));
+    __syncthreads();
+    for (int panel = pbeg; panel < pend; panel += 2) {
+        if (panel + 1 < pend) generate(buf1, min(panel + 2, pend - 1));
+        contract(buf0);
+        __syncthreads();
+        if (panel + 1 < pend) {
+            if (panel + 2 < pend) generate(buf0, min(panel + 3, pend - 1));
+            contract(buf1);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: the odd wave of a pair hands its K step's partial tiles to the even one ([e][lane] floats behind the transposition
+    // tiles); wave 0 finishes the real parts, wave 2 the imaginary parts
+    float* dst = A.ws + (((size_t)split * A.Nt + t) * A.Nf + f) * 2 * A.Nbl;
+    const float inv = 1.0f / scl;
+    const int col = lane & 31, rb = 4 * (lane >> 5);
+    RIME_MFMA_SETTLE();
+    float* ex = reinterpret_cast<float*>(smem) + 4 * (32 * 33) + (W >> 1) * (2 * 16 * 64);
+    if constexpr ((W & 1) == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { ex[e * 64 + lane] = acc0[e]; ex[(16 + e) * 64 + lane] = acc1[e]; }
+    }
+    __syncthreads();
+    if constexpr ((W & 1) == 1) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] += ex[e * 64 + lane]; acc1[e] += ex[(16 + e) * 64 + lane]; }
+    float* tr = reinterpret_cast<float*>(smem) + W * (32 * 33);
+    auto transposed = [&](const f32x16& v) {
+        f32x16 tv;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tr[((e & 3) + 8 * (e >> 2) + rb) * 33 + col] = v[e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tv[e] = tr[col * 33 + (e & 3) + 8 * (e >> 2) + rb];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return tv;
+    };
+    auto put1 = [&](int r, int c, int im, float v) {              // one plane of V[r, c] of the virtual 128-row block
+        const int bd = A.pair_direct[r * MF_NA + c];
+        if (bd >= 0) dst[(size_t)im * A.Nbl + bd] = v;
+        const int bc = A.pair_conj[r * MF_NA + c];
+        if (bc >= 0) dst[(size_t)im * A.Nbl + bc] = im ? -v : v;
+    };
+    f32x16 x, y;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if constexpr (W == 0) { x[e] = acc0[e] + acc1[e]; y[e] = acc0[e] - acc1[e]; }     // halves of Pcc + Pss, Pcc - Pss
+        else { x[e] = acc0[e] - acc1[e]; y[e] = acc0[e] + acc1[e]; }                      // Pcs -+ Pcs^T before the transposes
+    }
+    const f32x16 xt = transposed(x), yt = transposed(y);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = (e & 3) + 8 * (e >> 2) + rb, j = col;
+        if constexpr (W == 0) {
+            const float ar = (x[e] + xt[e]) * inv, br = (y[e] + yt[e]) * inv;
+            put1(i, j, 0, ar); put1(64 + i, 64 + j, 0, ar); put1(j, 64 + i, 0, br);
+        } else {
+            const float ai = (x[e] - xt[e]) * inv, bi = (y[e] + yt[e]) * inv;
+            put1(i, j, 1, ai); put1(64 + i, 64 + j, 1, -ai); put1(j, 64 + i, 1, -bi);
+        }
+    }
+}
+
+template <bool SIGNED>
+__global__ void __launch_bounds__(256, 2)
+fringe_pair_fwd1_kernel(PairArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (row_is_signed(A) != SIGNED) return;              // uniform over the block
+    switch (threadIdx.x >> 6) {                          // wave-uniform: every wave runs the same barriers
+        case 0: pair_fwd1_body<0, SIGNED>(A, smem); break;
+        case 1: pair_fwd1_body<1, SIGNED>(A, smem); break;
+        case 2: pair_fwd1_body<2, SIGNED>(A, smem); break;
+        default: pair_fwd1_body<3, SIGNED>(A, smem); break;
     }
 }
 
@@ -1845,16 +2056,16 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
     // gradient with respect to V[r, c] of the virtual 128-row block: direct slot + conjugate of the conj slot
     auto grad_of = [&](int r, int c, float& vr, float& vi) {
         const int bd = A.pair_direct[r * MF_NA + c];
-        if (bd >= 0) { vr += gre[bd]; vi += gim[bd]; }
+        if (bd >= 0) { vr += gre[bd]; keep_scalar(vr); vi += gim[bd]; keep_scalar(vi); }      // (scalar adds: see keep_scalar)
         const int bc = A.pair_conj[r * MF_NA + c];
-        if (bc >= 0) { vr += gre[bc]; vi -= gim[bc]; }
+        if (bc >= 0) { vr += gre[bc]; keep_scalar(vr); vi -= gim[bc]; keep_scalar(vi); }
     };
     // a[i,j] = conj(g V[i,j]) + g V[i',j'];  b[i,j] = g V[j,i'] (+ g V[i,j'] on the off-diagonal tile): what the forward wrote where
     auto entry = [&](int i, int j, bool off, float& ar, float& ai, float& br, float& bi) {
         float xr = 0.f, xi = 0.f, yr = 0.f, yi = 0.f;
         grad_of(i, j, xr, xi);
         grad_of(64 + i, 64 + j, yr, yi);
-        ar = xr + yr; ai = yi - xi;
+        ar = xr + yr; keep_scalar(ar); ai = yi - xi;
         br = 0.f; bi = 0.f;
         grad_of(j, 64 + i, br, bi);
         if (off) grad_of(i, 64 + j, br, bi);
@@ -1872,14 +2083,20 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
                 float ar, ai, br, bi;
                 entry(i, j, ti != tj, ar, ai, br, bi);
                 if (ti != tj) {
-                    n1[q] = ar + br; n2[q] = ar - br; n3[q] = -(ai + bi); n4[q] = ai - bi;
+                    n1[q] = ar + br; keep_scalar(n1[q]); n2[q] = ar - br; keep_scalar(n2[q]);
+                    n3[q] = -(ai + bi); keep_scalar(n3[q]); n4[q] = ai - bi;
                 } else {
                     float tr, ti_, ur, ui;                        // the (j, i) element of the same tile
                     entry(j, i, false, tr, ti_, ur, ui);
-                    n1[q] = 0.5f * ((ar + br) + (tr + ur));
-                    n2[q] = 0.5f * ((ar - br) + (tr - ur));
-                    n3[q] = (ti_ - ui) - (ai + bi);               // N3[i,j] + N4[j,i]
+                    float s1 = ar + br, s2 = tr + ur, d1 = ar - br, d2 = tr - ur;
+                    keep_scalar(s1); keep_scalar(s2); keep_scalar(d1);
+                    n1[q] = 0.5f * (s1 + s2); keep_scalar(n1[q]);
+                    n2[q] = 0.5f * (d1 + d2); keep_scalar(n2[q]);
+                    float e1 = ti_ - ui, e2 = ai + bi;
+                    keep_scalar(e1);
+                    n3[q] = e1 - e2;                              // N3[i,j] + N4[j,i]
                 }
+                keep_scalar(n1[q]); keep_scalar(n2[q]); keep_scalar(n3[q]); keep_scalar(n4[q]);
             }
         }
         uint32_t hi_, lo_;
@@ -1898,14 +2115,15 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
             // Re(conj(g) V[c, j]) with V[c, j] = e_j (row j) and conj(e_j) (row 64 + j): u c_j + v s_j
             float u = 0.f, v = 0.f;
             int b = A.centre[tid];
-            if (b >= 0) { u += gre[b]; v += gim[b]; }
+            if (b >= 0) { u += gre[b]; keep_scalar(u); v += gim[b]; keep_scalar(v); }
             b = A.centre[MF_NA + tid];
-            if (b >= 0) { u += gre[b]; v -= gim[b]; }
+            if (b >= 0) { u += gre[b]; keep_scalar(u); v -= gim[b]; keep_scalar(v); }
             b = A.centre[64 + tid];
-            if (b >= 0) { u += gre[b]; v -= gim[b]; }
+            if (b >= 0) { u += gre[b]; keep_scalar(u); v -= gim[b]; keep_scalar(v); }
             b = A.centre[MF_NA + 64 + tid];
-            if (b >= 0) { u += gre[b]; v += gim[b]; }
-            cen_u[tid] = u * gs; cen_v[tid] = v * gs;
+            if (b >= 0) { u += gre[b]; keep_scalar(u); v += gim[b]; keep_scalar(v); }
+            u *= gs; keep_scalar(u); v *= gs;
+            cen_u[tid] = u; cen_v[tid] = v;
         }
     }
     __syncthreads();
@@ -2461,6 +2679,14 @@ extern "C" int rime_fringe_pair_fwd_block(const double* antpos, int Nrows, const
     if (!workspace || workspace_bytes < rime_fringe_ant_workspace(Nbl, Nt, Nf, Pstride)) return RIME_EWORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
+    if (Nrows <= 32 && !centre) {                        // one row tile
+        // LDS: two image buffers (18.5 KB) during the loop, then the epilogue's transposition tiles + two partial tiles per wave pair
+        constexpr size_t lds1 = 4 * 33 * 32 * 4 + 2 * 2 * 16 * 64 * 4;
+        static_assert(lds1 >= 2 * (size_t)FwdShape<1, 1, false>::BUF, "the image buffers fit into the epilogue's scratch");
+        hipLaunchKernelGGL((fringe_pair_fwd1_kernel<true>), grid, dim3(256), lds1, st, A);
+        if (rowmin) hipLaunchKernelGGL((fringe_pair_fwd1_kernel<false>), grid, dim3(256), lds1, st, A);
+        return check_launch();
+    }
     using SH = FwdShape<2, 2, false>;
     static_assert(SH::LDS >= 4 * 33 * 32 * 4 + 2 * 64 * 2 * 4, "epilogue scratch: transposition tiles + the hub's column sums");
     if (centre) {

@@ -374,20 +374,21 @@ PAIR = _env_int('RIME_PAIR', 1) != 0            # RIME_PAIR=0: such blocks keep 
 PAIR_ROWS = 64                                  # rows of the pair kernels (firsts + antennas without a partner)
 
 
-def _pair_layout(P):
+def _pair_layout(P, rows=PAIR_ROWS, hub_ok=True):
     """
     Rows of the conjugate-pair form for antenna positions P (n, 3): (firsts, partner, hub, centre) -- firsts[k] the antenna
     of row k, partner[k] its mirror antenna or -1, hub the antenna AT the centre that is served outside the rows (or None)
-    -- or None when the set has no point symmetry or does not fit: at most 64 rows, plus the hub when the rows are full.
+    -- or None when the set has no point symmetry or does not fit: at most `rows` rows, plus (hub_ok) the hub when the rows
+    are full.
     """
     found = _mirror_pairs(P)
     if found is None:
         return None
     c, pairs, singles = found
     hub = None
-    if len(pairs) + len(singles) > PAIR_ROWS:
+    if len(pairs) + len(singles) > rows:
         at_c = [a for a in singles if np.abs(np.asarray(P[a]) - c).max() <= MIRROR_TOL]
-        if not at_c or len(pairs) + len(singles) - 1 > PAIR_ROWS:
+        if not hub_ok or not at_c or len(pairs) + len(singles) - 1 > rows:
             return None
         hub = at_c[0]
         singles = [a for a in singles if a != hub]
@@ -399,12 +400,14 @@ def _pair_layout(P):
 def _pair_block(blk, P, dev):
     """the conjugate-pair form of a built diagonal block (include/rime_hip.h, rime_fringe_pair_fwd_block): positions of the
     rows from the centre of symmetry, the pair tables of the virtual 128-row block (row k: firsts[k], row 64 + k: its
-    mirror), the hub's slot table; None when the block does not qualify.  Blocks of up to 64 antennas keep their kernels:
-    those are bound by operand generation, which the mirror-pair kernels already halve."""
+    mirror), the hub's slot table; None when the block does not qualify.  More than 64 antennas: up to 64 rows + the hub (two
+    row tiles: 26 MFMAs per K step against 63 / 100 of the three- / four-tile kernels); 33..64 antennas: up to 32 rows (one row
+    tile: 7 against 16 / 26); up to 32 antennas keep the one-tile kernels (the same 7 MFMAs; their generation is already
+    halved by the mirror pairs)."""
     n = int(blk['nrows'])
-    if blk['cross'] != 0 or n <= 64:
+    if blk['cross'] != 0 or n <= 32:
         return None
-    lay = _pair_layout(P)
+    lay = _pair_layout(P) if n > 64 else _pair_layout(P, rows=32, hub_ok=False)
     if lay is None:
         return None
     firsts, partner, hub, c = lay
@@ -439,7 +442,8 @@ def _pair_block(blk, P, dev):
     return dict(blk, pos=torch.as_tensor(pos, device=dev).contiguous(), nrows=len(firsts), mirror=0, pair=1,
                 firsts=list(firsts), partner=list(partner), hub=hub,
                 centre=None if hub is None else torch.as_tensor(centre.reshape(-1), device=dev),
-                cpass=0, fwd_cpass=0, self_pos=None, mf_self=0, mf_fwd=26, mf_bwd_real=30,
+                cpass=0, fwd_cpass=0, self_pos=None, mf_self=0, mf_fwd=26 if len(firsts) > 32 or hub is not None else 7,
+                mf_bwd_real=30 if len(firsts) > 32 else 9,
                 direct=torch.as_tensor(direct.reshape(-1), device=dev), conj=torch.as_tensor(conj.reshape(-1), device=dev))
 
 

@@ -668,9 +668,12 @@ def selfcheck_reference(inp, dev, bls, sample, first_times):
 
 OTHER_WORKLOADS = (('c3', [], None), ('c2', ['--steps', '20', '--warmup', '5'], None),
                    ('c5', ['--nf', '64', '--steps', '3', '--warmup', '2'], None),
-                   # the headline array is a 127-antenna hexagon + outrigger: 63 mirror pairs.  The same workload with the pairing
-                   # switched off = what an array WITHOUT point symmetry of this size costs (every phasor evaluated)
-                   ('c4', ['--steps', '5', '--warmup', '3'], {'RIME_MIRROR': '0'}))
+                   # the headline array is a 127-antenna hexagon + outrigger: 63 mirror pairs + the outrigger + the hub, served by the
+                   # conjugate-pair kernels (64 image rows).  The same workload with that form switched off (the mirror-pair
+                   # kernels: conjugate rows copied, all 128 rows contracted) and with the symmetry search switched off = what an
+                   # array WITHOUT point symmetry of this size costs (every phasor evaluated, every row contracted)
+                   ('c4', ['--steps', '5', '--warmup', '3'], {'RIME_MIRROR': '0'}),
+                   ('c4', ['--steps', '5', '--warmup', '3'], {'RIME_PAIR': '0'}))
 
 
 def other_workloads(budget_s, timeout_each=150.0, script=None):
@@ -721,6 +724,7 @@ def other_workloads(budget_s, timeout_each=150.0, script=None):
             return dict(kernel=k, frac=v.get('frac'), useful_frac_of_pipe_peak=v.get('useful_frac_of_pipe_peak'),
                         ms_per_step=round(v['total_ms'] / steps, 4))
         out.append(dict(workload=tag, desc=line['config']['workload'], mirror_groups=line['config'].get('antenna_mirror_groups'),
+                        pair_blocks=line['config'].get('antenna_pair_blocks'),
                         ms_per_step=round(line['ms_per_step'], 4),
                         value=line['value'], unit=line['unit'], steps=steps, warmup=line['warmup'],
                         kernels=dict(fwd=kern('fringe_ant_fwd') or kern('fringe_fwd'), bwd=kern('fringe_ant_bwd') or kern('fringe_bwd')),
@@ -979,7 +983,9 @@ def main():
         vis_bytes = len(bls) * nt * cfg['Nf'] * 8
         mg = sorted({tuple(g) for bg in rime._geom_cache.values() if bg['geom'].ant is not None
                      for g in bg['geom'].ant.get('mirror_groups', [])})
-        res = dict(shard=shard, label=label, dt=dt, prof=list(prof), vis_bytes=vis_bytes, grad_bytes=grad_bytes, mirror=mg,
+        pb = sorted({tuple(g) for bg in rime._geom_cache.values() if bg['geom'].ant is not None
+                     for g in bg['geom'].ant.get('pair_blocks', [])})
+        res = dict(shard=shard, label=label, dt=dt, prof=list(prof), vis_bytes=vis_bytes, grad_bytes=grad_bytes, mirror=mg, pair=pb,
                    plan_load=None if plan is None else [round(x, 1) for x in plan['load']],
                    hook_order=None if gsync is None else list(gsync.fired),
                    order_adapted=None if gsync is None else gsync.adapted, check=check)
@@ -1051,7 +1057,9 @@ def main():
             if traffic is None and args.workload == 'c4' and not distributed and not args.nf and os.path.exists(cpath):
                 try:
                     pm = json.load(open(cpath))
-                    inst = [v for k, v in pm.items() if k.split('<')[0] == dom and v.get('hbm_bytes_per_launch_larger_half')]
+                    # (the family label 'fringe_ant_*' covers the conjugate-pair kernels, profiled as fringe_pair_*)
+                    names = (dom, dom.replace('fringe_ant_', 'fringe_pair_')) if best['pair'] else (dom,)
+                    inst = [v for k, v in pm.items() if k.split('<')[0] in names and v.get('hbm_bytes_per_launch_larger_half')]
                     big = max(inst, key=lambda v: v['hbm_bytes_per_launch_larger_half'])
                     traffic = big['hbm_bytes_per_launch_larger_half']
                     traffic_source = rel + ' (separate rocprofv3 --pmc passes of this command, not this run; the kernel\'s largest launch)'
@@ -1089,6 +1097,12 @@ def main():
                     frac=round(achieved / peak, 4),
                     frac_note='EXECUTED flops of the dominant kernel / dense peak of its pipe' if mflops > 0 else
                               'algorithmic flops of the dominant kernel / fp32 peak',
+                    pair_form_note=None if not best['pair'] else
+                              'conjugate-pair kernels (point-symmetric array): all pairs from the images of one antenna of every mirror '
+                              'pair -- 26 (forward) / 30 (backward) MFMAs per 16-pixel K step instead of 100 / 108, so `frac` (EXECUTED '
+                              'flops / f16 peak) is lower than on the generic kernels while the useful rate (useful_frac_of_pipe_peak, '
+                              '8 flop per pair x pixel x channel x time) is more than twice theirs; the kernels are now bound by operand '
+                              'generation on the vector ALU (phases in f64, sin / cos), see profiles/r05/pair_form.txt',
                     useful_frac_of_pipe_peak=round(useful / peak, 4),
                     useful_tflops=round(useful, 2),
                     useful_note='8 flop (one complex MAC) per antenna pair x pixel x channel x time -- what the kernel is FOR; '
@@ -1142,6 +1156,7 @@ def main():
                                # (mirror groups, 16-row groups) of the antenna blocks: groups whose second octet of rows holds the
                                # MIRROR antennas of the first (r' - c = -(r - c)): conjugate phasors, not evaluated again
                                antenna_mirror_groups=[list(g) for g in best['mirror']] or None,
+                               antenna_pair_blocks=[list(g) for g in best['pair']] or None,
                                parallelism=best['label']),
                    roofline=roof)
         if selfcheck is not None and not distributed:

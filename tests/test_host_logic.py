@@ -560,8 +560,8 @@ def test_conjugate_pair_form_tables_and_algebra():
     """round 5, host side of the conjugate-pair form (ops._pair_layout / _pair_block) and the algebra its kernels implement,
     emulated in numpy: the headline array (63 pairs + outrigger in 64 rows, the hub outside them), a bare 127-antenna hexagon
     (the hub takes the 64th row), a 91-antenna hexagon; every baseline is written exactly once and both directions agree with
-    the baseline formulation to float64 rounding.  Blocks of up to 64 antennas, sets without symmetry and sets whose
-    firsts and singles exceed 64 rows without a hub keep their kernels"""
+    the baseline formulation to float64 rounding.  37 antennas take one row tile (19 rows); blocks of up to 32 antennas, sets
+    without symmetry and sets whose firsts and singles exceed the rows (32 / 64 + hub) keep their kernels"""
     from bayeslim_amd import ops
     hex7 = np.asarray(utils._make_hex(7, D=14.6)[1])
     hera128 = np.vstack([hex7, [[250.0, 0.0, 0.0]]]) + [3.0, -2.0, 0.5]
@@ -572,7 +572,11 @@ def test_conjugate_pair_form_tables_and_algebra():
     F, hub, ef, eb = _pair_form_emulated(np.asarray(utils._make_hex(6, D=14.6)[1]), 2)
     assert F == 46 and hub is None and ef < 1e-11 and eb < 1e-11
     rng = np.random.default_rng(5)
-    assert _pair_form_emulated(np.asarray(utils._make_hex(4, D=14.6)[1]), 3) is None             # 37 antennas: mirror-pair kernels
+    F, hub, ef, eb = _pair_form_emulated(np.asarray(utils._make_hex(4, D=14.6)[1]), 3)            # 37 antennas: one row tile
+    assert F == 19 and hub is None and ef < 1e-11 and eb < 1e-11
+    assert _pair_form_emulated(np.asarray(utils._make_hex(3, D=14.6)[1]), 6) is None             # 19 antennas: one-tile kernels
+    h2 = rng.normal(0, 60.0, (20, 3))
+    assert _pair_form_emulated(np.vstack([h2, -h2, rng.normal(0, 60.0, (13, 3))]), 7) is None    # 53 antennas, 33 rows
     assert _pair_form_emulated(rng.normal(0, 60.0, (100, 3)), 4) is None                         # no symmetry
     h = rng.normal(0, 60.0, (60, 3))
     assert _pair_form_emulated(np.vstack([h, -h, rng.normal(0, 60.0, (8, 3))]), 5) is None       # 68 rows, no hub

@@ -404,16 +404,17 @@ def test_fringe_sum_mirror_pairs(ops, kind, groups, conj, monkeypatch):
 
 
 @pytest.mark.parametrize('kind,pairs_rows_hub', [('hex91', (45, 46, 0)), ('hex127', (63, 64, 0)), ('hex127+1', (63, 64, 1)),
-                                                 ('rand70', (33, 37, 0)), ('rand100', (45, 55, 0)), ('rand128', None)])
+                                                 ('rand70', (33, 37, 0)), ('rand100', (45, 55, 0)), ('rand128', None),
+                                                 ('hex37', (18, 19, 0)), ('hex61', (30, 31, 0)), ('rand45', (20, 25, 0)), ('hex19', None)])
 @pytest.mark.parametrize('conj', [False, True])
 @pytest.mark.parametrize('full', [False, True])
 def test_fringe_sum_conjugate_pairs(ops, kind, pairs_rows_hub, conj, full, monkeypatch):
     """conjugate-pair form (round 5): blocks of more than 64 antennas of a point-symmetric array run on the images of ONE antenna
     of every mirror pair -- A = X^H s X and B = X^T s X from the same three real products (forward), the four real planes
     N1..N4 (backward), the hub of a full block on the vector ALU -- against the float64 oracle of the baseline formulation:
-    46 / 64 / 37 / 55 rows, with and without the hub path, both pair orientations and fringe signs, a partial pair set with
-    autocorrelations and the full set; an array whose firsts and singles do not fit into 64 rows (60 pairs + 8 singles)
-    keeps the mirror-pair kernels.  Equal to 2e-6 to the run on those kernels (RIME_PAIR=0)."""
+    46 / 64 / 37 / 55 rows, with and without the hub path, and 19 / 31 / 25 rows on the one-tile kernel (33..64 antennas), both
+    pair orientations and fringe signs, a partial pair set with autocorrelations and the full set; an array whose firsts and
+    singles do not fit into 64 rows (60 pairs + 8 singles) and one of up to 32 antennas keep the mirror-pair kernels.  Equal to 2e-6 to the run on those kernels (RIME_PAIR=0)."""
     rng = np.random.default_rng(abs(hash(kind)) % 1000 + 7)
     ant = _symmetric_array(kind, rng)
     Nant, Nt, Nf, P = len(ant), 2, 5, 700
@@ -453,6 +454,40 @@ def test_fringe_sum_conjugate_pairs(ops, kind, pairs_rows_hub, conj, full, monke
     if pairs_rows_hub is not None:
         assert not torch.equal(res[True], res[False])
     assert relmax(res[True], res[False].cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize('hub', [True, False])
+def test_conjugate_pair_kernels_at_the_headline_size_are_repeatable(ops, hub, monkeypatch):
+    """the conjugate-pair kernels are the first here whose blocks share a CU (three per CU): at the headline size -- 98 304
+    directions, enough blocks that many are dispatched while others stream MFMAs on the same SIMDs -- both directions must
+    be bit-identical from run to run and agree with the mirror-pair kernels.  (Round 5: packed-f32 adds in the backward's
+    staging code gave wrong G planes in a fraction of the late blocks, different every run; csrc/fringe_mfma.hip, keep_scalar.)"""
+    from bayeslim_amd import utils
+    ant = utils._make_hex(7, D=14.6)[1]
+    if hub:
+        ant = np.vstack([ant, [[250.0, 0.0, 0.0]]])
+    n, Nt, Nf, P = len(ant), 2, 24, 98304
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    rng = np.random.default_rng(0)
+    blvecs = T64(np.stack([ant[b] - ant[a] for a, b in pairs])).cuda()
+    freqs = T64(np.linspace(120e6, 180e6, Nf))
+    s = rng.normal(size=(Nt, 3, P))
+    s /= np.linalg.norm(s, axis=1, keepdims=True)
+    s[:, 2] = np.abs(s[:, 2])
+    sdir = T64(s).cuda()
+    g = torch.as_tensor(rng.normal(size=(1, len(pairs), Nt, Nf)) + 1j * rng.normal(size=(1, len(pairs), Nt, Nf))).to(torch.complex64).cuda()
+    psky = torch.as_tensor(rng.normal(size=(Nt, 1, 1, Nf, P))).float().cuda()
+    out = {}
+    for pair in (True, False):
+        monkeypatch.setattr(ops, 'PAIR', pair)
+        geom = ops.FringeGeometry(blvecs, sdir, freqs, antpos=T64(ant).cuda(), bl_ants=pairs, mfma=True)
+        assert bool(geom.ant.get('pair_blocks')) == pair
+        bwd = [ops.fringe_adjoint(g, geom).clone() for _ in range(3)]
+        fwd = [ops.fringe_sum(psky, geom).clone() for _ in range(3)]
+        assert all(torch.equal(bwd[0], b) for b in bwd[1:]) and all(torch.equal(fwd[0], v) for v in fwd[1:])
+        out[pair] = (bwd[0], fwd[0])
+    for a, b in zip(out[True], out[False]):
+        assert float((a - b).abs().max()) < 3e-6 * float(b.abs().max())
 
 
 @pytest.mark.parametrize('Nant,group,frac', [(128, 32, 1.0), (100, 32, 0.7), (128, 64, 1.0), (90, 64, 0.8), (40, 32, 1.0)])

@@ -8,11 +8,15 @@ along the straight path, and the loop-carried case is covered by scanning the bo
 (RIME_MFMA_SETTLE): the failing build of round 2 had 46 such readers, the closest at 13 wait states; builds that pass
 have none within 30.  `limit` 24 = the 16 wait states RIME_MFMA_SETTLE guarantees + the >= 8 the compiler's own hazard
 recogniser places between an 8-pass MFMA and a VALU read of its result -- an empirical margin, not an ISA number.
-usage: python tools/scan_packed_readers.py file.s [limit] [--fail]      (--fail: exit 1 on a hit)"""
+--no-packed=SUBSTRING (round 5): kernels whose mangled name contains SUBSTRING must hold NO v_pk_{add,mul,fma}_f32 at all -- the
+conjugate-pair kernels, whose blocks share a CU: packed f32 arithmetic of one block beside the MFMA stream of another gave
+wrong results there (csrc/fringe_mfma.hip, keep_scalar).
+usage: python tools/scan_packed_readers.py file.s [limit] [--fail] [--no-packed=SUBSTRING]     (--fail: exit 1 on a hit)"""
 import re, sys
 argv = [a for a in sys.argv[1:] if not a.startswith('--')]
 path, limit = argv[0], int(argv[1]) if len(argv) > 1 else 30
 fail = '--fail' in sys.argv
+no_packed = [a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--no-packed=')]
 rng = re.compile(r'\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b')
 
 
@@ -92,4 +96,14 @@ for f, hs in bad.items():
 if not bad:
     print('no packed-f32 reader of an MFMA result within', limit, 'wait states (%d kernels with %d MFMAs scanned, '
           'vector and accumulation registers)' % (nfunc, nmfma))
-sys.exit(1 if (bad and fail) else 0)
+packed = {}
+for f, lines in funcs.items():
+    if any(sub in f for sub in no_packed):
+        n = sum(1 for l in lines if re.match(r'v_pk_(add|mul|fma)_f32\b', l))
+        if n:
+            packed[f] = n
+for f, n in packed.items():
+    print(str(f)[:90], ':', n, 'packed f32 instructions in a kernel that must have none')
+if no_packed and not packed:
+    print('no packed f32 instruction in the %d kernels named *%s*' % (sum(1 for f in funcs if any(sub in f for sub in no_packed)), '*, *'.join(no_packed)))
+sys.exit(1 if ((bad or packed) and fail) else 0)
