@@ -72,7 +72,8 @@ for trial in range(ntrial):
     worst = [max(worst[0], ev), max(worst[1], eg)]
     flag = '' if (ev < 1e-5 and eg < 1e-4) else '   <-- FAIL'
     mg = gm.ant.get('mirror_groups', [])
-    print('trial %3d: Nant %3d Nbl %5d Nt %d Nf %2d P %4d Npp %d cplx %d conj %d uniform %d orient %-5s models %d (%d pairs) group %3d blocks %3d  sym %-9s mirror groups %-22s vis %.1e grad %.1e%s' % (
+    pb = gm.ant.get('pair_blocks', [])                        # conjugate-pair form: (pairs, rows, hub) per block (real psky passes)
+    print('trial %3d: Nant %3d Nbl %5d Nt %d Nf %2d P %4d Npp %d cplx %d conj %d uniform %d orient %-5s models %d (%d pairs) group %3d blocks %3d  sym %-9s mirror groups %-14s pair form %-16s vis %.1e grad %.1e%s' % (
         trial, Nant, len(pairs), Nt, Nf, P, Npp, cplx, conj, uniform, orient, Nmod, Nmp, group, len(gm.ant['blocks']), sym,
-        '+'.join('%d/%d' % g for g in mg) or '-', ev, eg, flag), flush=True)
+        '+'.join('%d/%d' % g for g in mg) or '-', '+'.join('%d/%d/%d' % g for g in pb) or '-', ev, eg, flag), flush=True)
 print('worst: vis %.2e grad %.2e' % tuple(worst))
