@@ -1283,34 +1283,44 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
             if (b >= 0) { dst[b] = vr; dst[(size_t)A.Nbl + b] = vi; }
         }
     }
+    // a private 32 x 33 float tile per wave takes the transposes (the image buffers are free after the loop's last barrier)
+    float* tr = reinterpret_cast<float*>(smem) + W * (32 * 33);
+    auto transposed = [&](const f32x16& v) {
+        f32x16 tv;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tr[((e & 3) + 8 * (e >> 2) + rb) * 33 + col] = v[e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tv[e] = tr[col * 33 + (e & 3) + 8 * (e >> 2) + rb];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return tv;
+    };
+    // Store order.  A wave's store instruction covers one accumulator element of all lanes: 32 consecutive COLUMNS of one row.
+    // With the baselines in antenna order (the usual sim_bls) the slots of V[r, c .. c + 31] are consecutive when the lanes run
+    // along the LATER antenna of the pair: true as they stand for V[i, j] and V[i, j'] (rows i, lanes j), but V[i', j'] and
+    // V[j, i'] of the off-diagonal tile want the lanes along i -- those two go out from the TRANSPOSED tile (3.5 -> 2.3 GB of slab
+    // traffic per headline launch); on a diagonal tile B = B^T lets element (r, c) write V[r, c'] itself.
     if constexpr (W < 2) {
         // tile (0,1), element (i, j): A[i,j] -> V[i, j] and conj -> V[i', j'];  conj(B[i,j]) -> V[j, i'] and V[i, j']
+        f32x16 s, d;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = (acc[0][e] + acc[1][e]) * inv; d[e] = (acc[0][e] - acc[1][e]) * inv; }
+        const f32x16 st = transposed(s), dt = transposed(d);          // st[e] of lane c = s at (row c, column row(e))
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int i = (e & 3) + 8 * (e >> 2) + rb, j = 32 + col;
-            const float s = (acc[0][e] + acc[1][e]) * inv, d = (acc[0][e] - acc[1][e]) * inv;
+            const int re = (e & 3) + 8 * (e >> 2) + rb;
+            const int i = re, j = 32 + col;                               // as accumulated: rows i, lanes j
+            const int it = col, jt = 32 + re;                             // transposed: rows j, lanes i
             if constexpr (W == 0) {                  // real parts: Ar = Pcc + Pss, Br = Pcc - Pss
-                put1(i, j, 0, s); put1(64 + i, 64 + j, 0, s);
-                put1(j, 64 + i, 0, d); put1(i, 64 + j, 0, d);
-            } else {                                 // imaginary parts: Ai = Pcs - Psc, Bi = Pcs + Psc
-                put1(i, j, 1, d); put1(64 + i, 64 + j, 1, -d);
-                put1(j, 64 + i, 1, -s); put1(i, 64 + j, 1, -s);
+                put1(i, j, 0, s[e]); put1(i, 64 + j, 0, d[e]);
+                put1(64 + it, 64 + jt, 0, st[e]); put1(jt, 64 + it, 0, dt[e]);
+            } else {                                 // imaginary parts: Ai = Pcs - Psc (d), Bi = Pcs + Psc (s)
+                put1(i, j, 1, d[e]); put1(i, 64 + j, 1, -s[e]);
+                put1(64 + it, 64 + jt, 1, -dt[e]); put1(jt, 64 + it, 1, -st[e]);
             }
         }
     } else {
         constexpr int tt = W - 2;
-        // a private 32 x 33 float tile per wave takes the transposes (the image buffers are free after the loop's last barrier)
-        float* tr = reinterpret_cast<float*>(smem) + W * (32 * 33);
-        auto transposed = [&](const f32x16& v) {
-            f32x16 tv;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) tr[((e & 3) + 8 * (e >> 2) + rb) * 33 + col] = v[e];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int e = 0; e < 16; ++e) tv[e] = tr[col * 33 + (e & 3) + 8 * (e >> 2) + rb];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            return tv;
-        };
         // Pcc = h + h^T (acc 0), Pss alike (acc 1);  Pcs = acc2 + acc3^T,  Pcs^T = acc2^T + acc3
         f32x16 ar, br, ai, bi, x, y;
 #pragma unroll
@@ -1330,7 +1340,7 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
             const int i = 32 * tt + (e & 3) + 8 * (e >> 2) + rb, j = 32 * tt + col;
             put(i, j, ar[e] * inv, ai[e] * inv);
             put(64 + i, 64 + j, ar[e] * inv, -ai[e] * inv);
-            put(j, 64 + i, br[e] * inv, -bi[e] * inv);
+            put(i, 64 + j, br[e] * inv, -bi[e] * inv);            // conj(B[j,i]) = conj(B[i,j]) -> V[i, j']
         }
     }
 }
@@ -1526,10 +1536,10 @@ __device__ __forceinline__ void pair_fwd1_body(const PairArgs& A, unsigned char*
         const int i = (e & 3) + 8 * (e >> 2) + rb, j = col;
         if constexpr (W == 0) {
             const float ar = (x[e] + xt[e]) * inv, br = (y[e] + yt[e]) * inv;
-            put1(i, j, 0, ar); put1(64 + i, 64 + j, 0, ar); put1(j, 64 + i, 0, br);
+            put1(i, j, 0, ar); put1(64 + i, 64 + j, 0, ar); put1(i, 64 + j, 0, br);     // (B = B^T: lanes along the later antenna)
         } else {
             const float ai = (x[e] - xt[e]) * inv, bi = (y[e] + yt[e]) * inv;
-            put1(i, j, 1, ai); put1(64 + i, 64 + j, 1, -ai); put1(j, 64 + i, 1, -bi);
+            put1(i, j, 1, ai); put1(64 + i, 64 + j, 1, -ai); put1(i, 64 + j, 1, -bi);
         }
     }
 }
