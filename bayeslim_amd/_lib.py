@@ -47,9 +47,9 @@ SIGNATURES = {
     'rime_fringe_ant_bwd_prepare': (_i, [_vp, _i, _i, _i, _vp, _sz, _vp]),
     'rime_fringe_ant_bwd_block': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
                                        _i, _i, _vp, _vp, _sz, _vp]),
-    'rime_fringe_pair_fwd_block': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
+    'rime_fringe_pair_fwd_block': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i,
                                         _vp, _sz, _vp]),
-    'rime_fringe_pair_bwd_block': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i, _i,
+    'rime_fringe_pair_bwd_block': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i, _i,
                                         _vp, _vp, _sz, _vp]),
     'rime_gen_fringe': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rime_comm_unique_id': (_i, [_vp]),

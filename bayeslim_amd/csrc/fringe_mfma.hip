@@ -116,6 +116,16 @@ __device__ __forceinline__ double phase3(double ax, double sx, double ay, double
 }
 __device__ __forceinline__ float turn_frac(double ph) { return (float)__builtin_amdgcn_fract(ph); }
 
+// FLAT (round 5, the conjugate-pair kernels): every row's z coordinate is zero (a coplanar array measured from a centre in its
+// plane -- the layouts simulations run on), so the third term of the phase is exactly zero and is not evaluated: one f64 FMA
+// less per phasor (3 % of a headline step; a licence stated by the caller, like `mirror`)
+template <bool FLAT>
+__device__ __forceinline__ double phase_of(double ax, double sx, double ay, double sy, double az, double sz)
+{
+    if constexpr (FLAT) return ax * sx + ay * sy;
+    else return phase3(ax, sx, ay, sy, az, sz);
+}
+
 __device__ __forceinline__ f16x8 as_frag(const uint4& v) { return __builtin_bit_cast(f16x8, v); }
 
 // ---------------------------------------------------------------------------------------
@@ -1059,7 +1069,7 @@ struct PairArgs : AntArgs {
     const int* centre;         // CEN: [2][128] baseline slots receiving V[c, r] (first 128) / conj(V[c, r]) (last 128), r = virtual row
 };
 
-template <int W, bool SIGNED, bool CEN>
+template <int W, bool SIGNED, bool CEN, bool FLAT>
 __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* smem)
 {
     using SH = FwdShape<2, 2, false>;
@@ -1110,7 +1120,7 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
     if (pbeg >= pend) return;                        // uniform over the block
 
     // panel fetch through buffer loads (see the generic kernel): descriptor in SGPRs + constant lane offset + scalar offset
-    double2 sx, sy, sz; float2 av;
+    double2 sx, sy, sz = make_double2(0.0, 0.0); float2 av;
     const uint32_t lo_s = 16u * pp, lo_a0 = 8u * pp * (uint32_t)st_p, lo_a1 = lo_a0 + 4u * (uint32_t)st_p;
     auto uniform_ptr = [](const void* q) {
         const unsigned long long a = reinterpret_cast<unsigned long long>(q);
@@ -1125,7 +1135,7 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
         const int p0 = panel * MF_KP + 16 * hf;      // uniform
         sx = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, p0 * 8, 0));
         sy = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (A.Pstride + p0) * 8, 0));
-        sz = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (2 * A.Pstride + p0) * 8, 0));
+        if constexpr (!FLAT) sz = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (2 * A.Pstride + p0) * 8, 0));
         const int so = p0 * st_p * 4;
         av = make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a0, so, 0)),
                          __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a1, so, 0)));
@@ -1144,8 +1154,8 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
 #pragma unroll
         for (int u = 0; u < NGEN; ++u) {
             if (u < nk) {
-                const double ph0 = phase3(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
-                const double ph1 = phase3(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
+                const double ph0 = phase_of<FLAT>(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
+                const double ph1 = phase_of<FLAT>(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
                 const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
                 const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                 const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
@@ -1345,17 +1355,17 @@ __device__ __forceinline__ void pair_fwd_body(const PairArgs& A, unsigned char* 
     }
 }
 
-template <bool SIGNED, bool CEN>
+template <bool SIGNED, bool CEN, bool FLAT>
 __global__ void __launch_bounds__(256, 3)
 fringe_pair_fwd_kernel(PairArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     if (row_is_signed(A) != SIGNED) return;              // uniform over the block
     switch (threadIdx.x >> 6) {                          // wave-uniform: every wave runs the same barriers
-        case 0: pair_fwd_body<0, SIGNED, CEN>(A, smem); break;
-        case 1: pair_fwd_body<1, SIGNED, CEN>(A, smem); break;
-        case 2: pair_fwd_body<2, SIGNED, CEN>(A, smem); break;
-        default: pair_fwd_body<3, SIGNED, CEN>(A, smem); break;
+        case 0: pair_fwd_body<0, SIGNED, CEN, FLAT>(A, smem); break;
+        case 1: pair_fwd_body<1, SIGNED, CEN, FLAT>(A, smem); break;
+        case 2: pair_fwd_body<2, SIGNED, CEN, FLAT>(A, smem); break;
+        default: pair_fwd_body<3, SIGNED, CEN, FLAT>(A, smem); break;
     }
 }
 
@@ -1364,7 +1374,7 @@ fringe_pair_fwd_kernel(PairArgs A)
 // the generic one-tile shape: a wave takes ONE K step of every panel (W & 1); waves 0, 1 the halves of Pcc and Pss (4 MFMAs),
 // waves 2, 3 the two accumulators of Pcs (3); the odd wave of a pair hands its partial tiles to the even one in the epilogue.
 // No hub path: an array whose rows exceed 32 takes the two-tile kernel.
-template <int W, bool SIGNED>
+template <int W, bool SIGNED, bool FLAT>
 __device__ __forceinline__ void pair_fwd1_body(const PairArgs& A, unsigned char* smem)
 {
     using SH = FwdShape<1, 1, false>;
@@ -1404,7 +1414,7 @@ __device__ __forceinline__ void pair_fwd1_body(const PairArgs& A, unsigned char*
     const int pend = __builtin_amdgcn_readfirstlane(min(npanel, pbeg + A.panels_per_split));
     if (pbeg >= pend) return;                        // uniform over the block
 
-    double2 sx, sy, sz; float2 av;
+    double2 sx, sy, sz = make_double2(0.0, 0.0); float2 av;
     const uint32_t lo_s = 16u * pp, lo_a0 = 8u * pp * (uint32_t)st_p, lo_a1 = lo_a0 + 4u * (uint32_t)st_p;
     auto uniform_ptr = [](const void* q) {
         const unsigned long long a = reinterpret_cast<unsigned long long>(q);
@@ -1419,7 +1429,7 @@ __device__ __forceinline__ void pair_fwd1_body(const PairArgs& A, unsigned char*
         const int p0 = panel * MF_KP + 16 * hf;      // uniform
         sx = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, p0 * 8, 0));
         sy = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (A.Pstride + p0) * 8, 0));
-        sz = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (2 * A.Pstride + p0) * 8, 0));
+        if constexpr (!FLAT) sz = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo_s, (2 * A.Pstride + p0) * 8, 0));
         const int so = p0 * st_p * 4;
         av = make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a0, so, 0)),
                          __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, (int)lo_a1, so, 0)));
@@ -1432,8 +1442,8 @@ __device__ __forceinline__ void pair_fwd1_body(const PairArgs& A, unsigned char*
 #pragma unroll
         for (int u = 0; u < NGEN; ++u) {
             if (u < nk) {
-                const double ph0 = phase3(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
-                const double ph1 = phase3(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
+                const double ph0 = phase_of<FLAT>(ax[u], sx.x, ay[u], sy.x, az[u], sz.x);
+                const double ph1 = phase_of<FLAT>(ax[u], sx.y, ay[u], sy.y, az[u], sz.y);
                 const float r0 = turn_frac(ph0), r1 = turn_frac(ph1);
                 const float s0 = __builtin_amdgcn_sinf(r0), c0 = __builtin_amdgcn_cosf(r0);
                 const float s1 = __builtin_amdgcn_sinf(r1), c1 = __builtin_amdgcn_cosf(r1);
@@ -1544,17 +1554,17 @@ __device__ __forceinline__ void pair_fwd1_body(const PairArgs& A, unsigned char*
     }
 }
 
-template <bool SIGNED>
+template <bool SIGNED, bool FLAT>
 __global__ void __launch_bounds__(256, 2)
 fringe_pair_fwd1_kernel(PairArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     if (row_is_signed(A) != SIGNED) return;              // uniform over the block
     switch (threadIdx.x >> 6) {                          // wave-uniform: every wave runs the same barriers
-        case 0: pair_fwd1_body<0, SIGNED>(A, smem); break;
-        case 1: pair_fwd1_body<1, SIGNED>(A, smem); break;
-        case 2: pair_fwd1_body<2, SIGNED>(A, smem); break;
-        default: pair_fwd1_body<3, SIGNED>(A, smem); break;
+        case 0: pair_fwd1_body<0, SIGNED, FLAT>(A, smem); break;
+        case 1: pair_fwd1_body<1, SIGNED, FLAT>(A, smem); break;
+        case 2: pair_fwd1_body<2, SIGNED, FLAT>(A, smem); break;
+        default: pair_fwd1_body<3, SIGNED, FLAT>(A, smem); break;
     }
 }
 
@@ -2042,7 +2052,7 @@ constexpr int PB_PLANE = 3 * 2 * 2 * 32 * 16;         // bytes per plane: (tile,
 constexpr int PB_THREADS = 256;
 constexpr size_t PB_LDS = 8 * (size_t)PB_PLANE + 64 * 3 * sizeof(double) + 2 * 64 * sizeof(float);
 
-template <bool CEN>
+template <bool CEN, bool FLAT>
 __global__ void __launch_bounds__(PB_THREADS, 3)
 fringe_pair_bwd_kernel(PairBwdArgs A)
 {
@@ -2149,7 +2159,7 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
     const uint32_t gl0 = (h * 32 + (lane & 31)) * 16;    // one lane base + 16-bit immediates reach all eight planes (48 KB)
     for (int pt = tbeg + wave; pt < tend; pt += PB_THREADS / 64) {
         const int p = pt * 32 + (lane & 31);
-        const double sx = sd[p], sy = sd[A.Pstride + p], sz = sd[2 * (size_t)A.Pstride + p];
+        const double sx = sd[p], sy = sd[A.Pstride + p], sz = FLAT ? 0.0 : sd[2 * (size_t)A.Pstride + p];
         f32x16 accR[2], accI[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -2187,7 +2197,7 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
                         for (int u = 0; u < 4; ++u) {
                             const int jj = 4 * jq + u;
                             const int an = 32 * tj + (jj & 3) + 8 * (2 * ks + (jj >> 2)) + 4 * h;
-                            const double ph = phase3(ant_lds[3 * an], sx, ant_lds[3 * an + 1], sy, ant_lds[3 * an + 2], sz);
+                            const double ph = phase_of<FLAT>(ant_lds[3 * an], sx, ant_lds[3 * an + 1], sy, ant_lds[3 * an + 2], sz);
                             const float rr = turn_frac(ph);
                             ec[8 * ks + jj] = __builtin_amdgcn_cosf(rr);
                             es[8 * ks + jj] = __builtin_amdgcn_sinf(rr);
@@ -2671,7 +2681,7 @@ static bool pair_common_ok(int Nrows, int Nbl, int Nt, int Nf, int Pstride, long
     return Nrows > 0 && Nrows <= 64 && ant_common_ok(Nrows, 0, Nbl, Nt, Nf, Pstride, st_p, sign, 0) && st_p == 1;
 }
 
-extern "C" int rime_fringe_pair_fwd_block(const double* antpos, int Nrows, const int* centre, const double* sdir,
+extern "C" int rime_fringe_pair_fwd_block(const double* antpos, int Nrows, const int* centre, int flat, const double* sdir,
                                           const double* freqs, const float* psky, const float* scale, const float* rowmin,
                                           const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
                                           long long st_t, long long st_f, long long st_p, int sign,
@@ -2693,23 +2703,29 @@ extern "C" int rime_fringe_pair_fwd_block(const double* antpos, int Nrows, const
         // LDS: two image buffers (18.5 KB) during the loop, then the epilogue's transposition tiles + two partial tiles per wave pair
         constexpr size_t lds1 = 4 * 33 * 32 * 4 + 2 * 2 * 16 * 64 * 4;
         static_assert(lds1 >= 2 * (size_t)FwdShape<1, 1, false>::BUF, "the image buffers fit into the epilogue's scratch");
-        hipLaunchKernelGGL((fringe_pair_fwd1_kernel<true>), grid, dim3(256), lds1, st, A);
-        if (rowmin) hipLaunchKernelGGL((fringe_pair_fwd1_kernel<false>), grid, dim3(256), lds1, st, A);
+        if (flat) {
+            hipLaunchKernelGGL((fringe_pair_fwd1_kernel<true, true>), grid, dim3(256), lds1, st, A);
+            if (rowmin) hipLaunchKernelGGL((fringe_pair_fwd1_kernel<false, true>), grid, dim3(256), lds1, st, A);
+        } else {
+            hipLaunchKernelGGL((fringe_pair_fwd1_kernel<true, false>), grid, dim3(256), lds1, st, A);
+            if (rowmin) hipLaunchKernelGGL((fringe_pair_fwd1_kernel<false, false>), grid, dim3(256), lds1, st, A);
+        }
         return check_launch();
     }
     using SH = FwdShape<2, 2, false>;
     static_assert(SH::LDS >= 4 * 33 * 32 * 4 + 2 * 64 * 2 * 4, "epilogue scratch: transposition tiles + the hub's column sums");
-    if (centre) {
-        hipLaunchKernelGGL((fringe_pair_fwd_kernel<true, true>), grid, dim3(256), SH::LDS, st, A);
-        if (rowmin) hipLaunchKernelGGL((fringe_pair_fwd_kernel<false, true>), grid, dim3(256), SH::LDS, st, A);
-    } else {
-        hipLaunchKernelGGL((fringe_pair_fwd_kernel<true, false>), grid, dim3(256), SH::LDS, st, A);
-        if (rowmin) hipLaunchKernelGGL((fringe_pair_fwd_kernel<false, false>), grid, dim3(256), SH::LDS, st, A);
-    }
+#define RIME_PAIR_FWD(CEN_, FLAT_)                                                                                       \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL((fringe_pair_fwd_kernel<true, CEN_, FLAT_>), grid, dim3(256), SH::LDS, st, A);                \
+        if (rowmin) hipLaunchKernelGGL((fringe_pair_fwd_kernel<false, CEN_, FLAT_>), grid, dim3(256), SH::LDS, st, A);   \
+    } while (0)
+    if (centre) { if (flat) RIME_PAIR_FWD(true, true); else RIME_PAIR_FWD(true, false); }
+    else { if (flat) RIME_PAIR_FWD(false, true); else RIME_PAIR_FWD(false, false); }
+#undef RIME_PAIR_FWD
     return check_launch();
 }
 
-extern "C" int rime_fringe_pair_bwd_block(const double* antpos, int Nrows, const int* centre, const double* sdir,
+extern "C" int rime_fringe_pair_bwd_block(const double* antpos, int Nrows, const int* centre, int flat, const double* sdir,
                                           const double* freqs, const float* gscale, const int* pair_direct,
                                           const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
                                           long long st_t, long long st_f, long long st_p, int sign, int accumulate,
@@ -2731,7 +2747,12 @@ extern "C" int rime_fringe_pair_bwd_block(const double* antpos, int Nrows, const
     A.S = (ntile + per - 1) / per;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
-    if (centre) hipLaunchKernelGGL(fringe_pair_bwd_kernel<true>, grid, dim3(PB_THREADS), PB_LDS, st, A);
-    else hipLaunchKernelGGL(fringe_pair_bwd_kernel<false>, grid, dim3(PB_THREADS), PB_LDS, st, A);
+    if (centre) {
+        if (flat) hipLaunchKernelGGL((fringe_pair_bwd_kernel<true, true>), grid, dim3(PB_THREADS), PB_LDS, st, A);
+        else hipLaunchKernelGGL((fringe_pair_bwd_kernel<true, false>), grid, dim3(PB_THREADS), PB_LDS, st, A);
+    } else {
+        if (flat) hipLaunchKernelGGL((fringe_pair_bwd_kernel<false, true>), grid, dim3(PB_THREADS), PB_LDS, st, A);
+        else hipLaunchKernelGGL((fringe_pair_bwd_kernel<false, false>), grid, dim3(PB_THREADS), PB_LDS, st, A);
+    }
     return check_launch();
 }

@@ -439,8 +439,13 @@ def _pair_block(blk, P, dev):
     nslots = int((direct >= 0).sum()) + int((conj >= 0).sum()) + int((centre >= 0).sum())
     assert nslots == int((od >= 0).sum()) + int((oc >= 0).sum())
     pos = np.asarray(P)[firsts] - c
+    # a coplanar array measured from a centre in its plane: z = 0 within the tolerance of the pairing itself -> exactly 0 and
+    # the `flat` licence (the kernels skip that term of the phase)
+    flat = int(np.abs(pos[:, 2]).max() <= MIRROR_TOL)
+    if flat:
+        pos[:, 2] = 0.0
     return dict(blk, pos=torch.as_tensor(pos, device=dev).contiguous(), nrows=len(firsts), mirror=0, pair=1,
-                firsts=list(firsts), partner=list(partner), hub=hub,
+                firsts=list(firsts), partner=list(partner), hub=hub, flat=flat,
                 centre=None if hub is None else torch.as_tensor(centre.reshape(-1), device=dev),
                 cpass=0, fwd_cpass=0, self_pos=None, mf_self=0, mf_fwd=26 if len(firsts) > 32 or hub is not None else 7,
                 mf_bwd_real=30 if len(firsts) > 32 else 9,
@@ -530,7 +535,7 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
                 check(rc, 'rime_fringe_ant_fwd_block')
                 return blk['mf_self']
             if blk.get('pair'):                              # conjugate-pair form (real psky only: `blocks_real`)
-                rc = lib.rime_fringe_pair_fwd_block(_ptr(blk['pos']), blk['nrows'], _ptr(blk['centre']), *geo, src,
+                rc = lib.rime_fringe_pair_fwd_block(_ptr(blk['pos']), blk['nrows'], _ptr(blk['centre']), blk['flat'], *geo, src,
                                                     _ptr(scale[mp, pp]), _ptr(rowmin[c][mp, pp]),
                                                     _ptr(blk['direct']), _ptr(blk['conj']),
                                                     *shape, _ptr(ws), ws.numel(), _stream())
@@ -588,7 +593,7 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
                     written.update(planes)
                     dst = ctypes.c_void_p(out.data_ptr() + 4 * (mp * st_mp + pp * st_pp + (0 if single else c)))
                     if blk.get('pair'):
-                        rc = lib.rime_fringe_pair_bwd_block(_ptr(blk['pos']), blk['nrows'], _ptr(blk['centre']), *geo,
+                        rc = lib.rime_fringe_pair_bwd_block(_ptr(blk['pos']), blk['nrows'], _ptr(blk['centre']), blk['flat'], *geo,
                                                             _ptr(scale_pp), _ptr(blk['direct']), _ptr(blk['conj']),
                                                             *shape, acc, dst, _ptr(ws), ws.numel(), _stream())
                         check(rc, 'rime_fringe_pair_bwd_block')

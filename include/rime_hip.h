@@ -207,14 +207,16 @@ int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cross, int mi
  *   centre: NULL, or int32 [2][128] for ONE more antenna that sits at c itself (its phasor is 1; needed when the firsts and
  *       singles already fill 64 rows): centre[r] = slot of the baseline (hub -> virtual row r), centre[128 + r] = slot of
  *       (virtual row r -> hub), or -1.
+ *   flat: nonzero = every antpos z is zero (a coplanar array measured from a centre in its plane): the kernels do not evaluate that
+ *       term of the phase.  A licence stated by the caller; 0 is always correct.
  *   st_p must be 1; the other arguments, the workspace and _finish / _prepare are those of rime_fringe_ant_fwd_block /
  *   rime_fringe_ant_bwd_block, and pair blocks mix with other blocks of the same launch sequence. */
-int rime_fringe_pair_fwd_block(const double* antpos, int Nrows, const int* centre, const double* sdir,
+int rime_fringe_pair_fwd_block(const double* antpos, int Nrows, const int* centre, int flat, const double* sdir,
                                const double* freqs, const float* psky, const float* scale, const float* rowmin,
                                const int* pair_direct, const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
                                long long st_t, long long st_f, long long st_p, int sign,
                                void* workspace, size_t workspace_bytes, void* stream);
-int rime_fringe_pair_bwd_block(const double* antpos, int Nrows, const int* centre, const double* sdir,
+int rime_fringe_pair_bwd_block(const double* antpos, int Nrows, const int* centre, int flat, const double* sdir,
                                const double* freqs, const float* gscale, const int* pair_direct,
                                const int* pair_conj, int Nbl, int Nt, int Nf, int Pstride,
                                long long st_t, long long st_f, long long st_p, int sign, int accumulate,

@@ -76,12 +76,12 @@ def test_bad_arguments_are_rejected_without_launching():
     assert lib.rime_fringe_ant_fwd_block(one, 40, 0, -1, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, one, big, None) == -1
     assert lib.rime_fringe_ant_bwd_block(one, 128, 0, 256, one, one, one, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, 0, one, one, big, None) == -1
     # round 5: conjugate-pair blocks -- at most 64 rows, unit pixel stride, a workspace
-    assert lib.rime_fringe_pair_fwd_block(one, 65, None, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 1, 1, one, big, None) == -1
-    assert lib.rime_fringe_pair_fwd_block(one, 64, None, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 2, 1, one, big, None) == -1
-    assert lib.rime_fringe_pair_fwd_block(one, 64, None, one, one, one, one, None, None, one, 1, 1, 1, 64, 64, 64, 1, 1, one, big, None) == -1
-    assert lib.rime_fringe_pair_fwd_block(one, 64, None, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 1, 1, one, 4, None) == -2
-    assert lib.rime_fringe_pair_bwd_block(one, 0, None, one, one, one, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, one, one, big, None) == -1
-    assert lib.rime_fringe_pair_bwd_block(one, 64, None, one, one, one, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, one, one, 0, None) == -2
+    assert lib.rime_fringe_pair_fwd_block(one, 65, None, 0, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 1, 1, one, big, None) == -1
+    assert lib.rime_fringe_pair_fwd_block(one, 64, None, 1, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 2, 1, one, big, None) == -1
+    assert lib.rime_fringe_pair_fwd_block(one, 64, None, 1, one, one, one, one, None, None, one, 1, 1, 1, 64, 64, 64, 1, 1, one, big, None) == -1
+    assert lib.rime_fringe_pair_fwd_block(one, 64, None, 1, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 1, 1, one, 4, None) == -2
+    assert lib.rime_fringe_pair_bwd_block(one, 0, None, 0, one, one, one, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, one, one, big, None) == -1
+    assert lib.rime_fringe_pair_bwd_block(one, 64, None, 1, one, one, one, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, one, one, 0, None) == -2
     # 16 384 pixels per forward block since round 4: the C4 diffuse launch (98 304 px, 8 x 256 rows) takes 6 slabs
     assert lib.rime_fringe_ant_workspace(8128, 8, 256, 98304) == 6 * 8128 * 8 * 256 * 8
     # workspace = S partial slabs of the vis tensor (forward) -- 0 when the grid is already large

@@ -345,10 +345,13 @@ def _symmetric_array(kind, rng):
     from bayeslim_amd import utils
     c = np.array([31.7, -12.3, 4.1])
     if kind.startswith('hex'):
-        side, extra = {'hex19': (3, 0), 'hex37': (4, 0), 'hex61': (5, 0), 'hex91': (6, 0), 'hex127': (7, 0), 'hex127+1': (7, 1)}[kind]
+        side, extra = {'hex19': (3, 0), 'hex37': (4, 0), 'hex61': (5, 0), 'hex91': (6, 0), 'hex127': (7, 0), 'hex127+1': (7, 1)}[kind.rstrip('t')]
         ant = utils._make_hex(side, D=14.6)[1]
         if extra:
             ant = np.vstack([ant, [[250.0, 3.0, 0.0]]])
+        if kind.endswith('t'):                                   # tilted: the plane of the array is not z = const (no `flat` licence)
+            t = np.deg2rad(3.0)
+            ant = ant @ np.array([[1, 0, 0], [0, np.cos(t), -np.sin(t)], [0, np.sin(t), np.cos(t)]]).T
     else:
         # `half` random antennas, their mirror images, `single` antennas without a partner; tilted (z matters)
         half, single = {'rand45': (20, 5), 'rand70': (33, 4), 'rand100': (45, 10), 'rand128': (60, 8)}[kind]
@@ -405,7 +408,8 @@ def test_fringe_sum_mirror_pairs(ops, kind, groups, conj, monkeypatch):
 
 @pytest.mark.parametrize('kind,pairs_rows_hub', [('hex91', (45, 46, 0)), ('hex127', (63, 64, 0)), ('hex127+1', (63, 64, 1)),
                                                  ('rand70', (33, 37, 0)), ('rand100', (45, 55, 0)), ('rand128', None),
-                                                 ('hex37', (18, 19, 0)), ('hex61', (30, 31, 0)), ('rand45', (20, 25, 0)), ('hex19', None)])
+                                                 ('hex37', (18, 19, 0)), ('hex61', (30, 31, 0)), ('rand45', (20, 25, 0)), ('hex19', None),
+                                                 ('hex127+1t', (63, 64, 1)), ('hex37t', (18, 19, 0))])
 @pytest.mark.parametrize('conj', [False, True])
 @pytest.mark.parametrize('full', [False, True])
 def test_fringe_sum_conjugate_pairs(ops, kind, pairs_rows_hub, conj, full, monkeypatch):
@@ -413,7 +417,8 @@ def test_fringe_sum_conjugate_pairs(ops, kind, pairs_rows_hub, conj, full, monke
     of every mirror pair -- A = X^H s X and B = X^T s X from the same three real products (forward), the four real planes
     N1..N4 (backward), the hub of a full block on the vector ALU -- against the float64 oracle of the baseline formulation:
     46 / 64 / 37 / 55 rows, with and without the hub path, and 19 / 31 / 25 rows on the one-tile kernel (33..64 antennas), both
-    pair orientations and fringe signs, a partial pair set with autocorrelations and the full set; an array whose firsts and
+    pair orientations and fringe signs, coplanar arrays (the `flat` licence: no z term in the phase) and tilted ones, a partial
+    pair set with autocorrelations and the full set; an array whose firsts and
     singles do not fit into 64 rows (60 pairs + 8 singles) and one of up to 32 antennas keep the mirror-pair kernels.  Equal to 2e-6 to the run on those kernels (RIME_PAIR=0)."""
     rng = np.random.default_rng(abs(hash(kind)) % 1000 + 7)
     ant = _symmetric_array(kind, rng)
@@ -422,7 +427,7 @@ def test_fringe_sum_conjugate_pairs(ops, kind, pairs_rows_hub, conj, full, monke
         pairs = [(i, j) for i in range(Nant) for j in range(i + 1, Nant)]
     else:
         pairs = [(i, j) if rng.random() < 0.5 else (j, i) for i in range(Nant) for j in range(i + 1, Nant) if rng.random() < 0.9]
-        hub = int(np.argmin(np.abs(ant - ant.mean(0)).sum(1))) if kind == 'hex127+1' else -1
+        hub = int(np.argmin(np.abs(ant - ant.mean(0)).sum(1))) if kind.startswith('hex127+1') else -1
         pairs += [(a, a) for a in range(Nant) if a % 40 == 3 and a != hub]       # (the hub's autocorrelation declines the form)
         pairs = [pairs[k] for k in rng.permutation(len(pairs))]
     blvecs = T64(np.stack([ant[b] - ant[a] for a, b in pairs]))
@@ -444,6 +449,8 @@ def test_fringe_sum_conjugate_pairs(ops, kind, pairs_rows_hub, conj, full, monke
             assert geom.ant['pair_blocks'] == [pairs_rows_hub], geom.ant['pair_blocks']
             blk = geom.ant['blocks_real'][0]
             assert blk['pair'] == 1 and (blk['centre'] is not None) == bool(pairs_rows_hub[2]) and geom.ant['mirror_groups'] == []
+            # coplanar arrays (the hexagons as generated, z = const) carry the `flat` licence, tilted and random ones do not
+            assert blk['flat'] == int(kind.startswith('hex') and not kind.endswith('t')), (kind, blk['flat'])
             pos = blk['pos'].cpu().numpy()                       # rows: firsts and singles, measured from the centre
             for k, (a, b) in enumerate(zip(blk['firsts'], blk['partner'])):
                 if b >= 0:

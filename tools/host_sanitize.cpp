@@ -47,12 +47,12 @@ int main()
     bad += rime_fringe_ant_fwd_block(d.data(), 40, 0, -1, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
     bad += rime_fringe_ant_bwd_block(d.data(), 128, 0, 256, d.data(), d.data(), f.data(), tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, 0, f.data(), f.data(), 1 << 20, nullptr) != RIME_EINVAL;
     // conjugate-pair blocks (round 5): more than 64 rows, a pixel stride other than 1, missing tables -> RIME_EINVAL; no workspace
-    bad += rime_fringe_pair_fwd_block(d.data(), 65, nullptr, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
-    bad += rime_fringe_pair_fwd_block(d.data(), 64, nullptr, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 2, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
-    bad += rime_fringe_pair_fwd_block(d.data(), 64, nullptr, d.data(), d.data(), f.data(), f.data(), nullptr, nullptr, tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
-    bad += rime_fringe_pair_fwd_block(d.data(), 64, nullptr, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, f.data(), 4, nullptr) != RIME_EWORKSPACE;
-    bad += rime_fringe_pair_bwd_block(d.data(), 0, nullptr, d.data(), d.data(), f.data(), tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), f.data(), 1 << 20, nullptr) != RIME_EINVAL;
-    bad += rime_fringe_pair_bwd_block(d.data(), 64, nullptr, d.data(), d.data(), f.data(), tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), f.data(), 0, nullptr) != RIME_EWORKSPACE;
+    bad += rime_fringe_pair_fwd_block(d.data(), 65, nullptr, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
+    bad += rime_fringe_pair_fwd_block(d.data(), 64, nullptr, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 2, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
+    bad += rime_fringe_pair_fwd_block(d.data(), 64, nullptr, 0, d.data(), d.data(), f.data(), f.data(), nullptr, nullptr, tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
+    bad += rime_fringe_pair_fwd_block(d.data(), 64, nullptr, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, f.data(), 4, nullptr) != RIME_EWORKSPACE;
+    bad += rime_fringe_pair_bwd_block(d.data(), 0, nullptr, 0, d.data(), d.data(), f.data(), tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), f.data(), 1 << 20, nullptr) != RIME_EINVAL;
+    bad += rime_fringe_pair_bwd_block(d.data(), 64, nullptr, 0, d.data(), d.data(), f.data(), tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), f.data(), 0, nullptr) != RIME_EWORKSPACE;
     bad += rime_eq2top(d.data(), d.data(), -1, d.data(), d.data(), 0.0, d.data(), d.data(), nullptr) != RIME_EINVAL;
     bad += rime_eq2top(d.data(), d.data(), 0, d.data(), d.data(), 0.0, d.data(), d.data(), nullptr) != RIME_OK;
     bad += rime_interp_gather_fwd(0, 0, nullptr, nullptr, nullptr, 1, 1, 1, 1, nullptr, 1, nullptr) == RIME_OK;
