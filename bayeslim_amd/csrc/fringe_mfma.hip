@@ -2045,17 +2045,20 @@ struct PairBwdArgs : AntBwdArgs {
     const int* centre;         // CEN: [2][128] slots of the hub's baselines (as PairArgs::centre)
 };
 
-constexpr int PB_PLANE = 3 * 2 * 2 * 32 * 16;         // bytes per plane: (tile, ks, h, row) x 8 f16; tiles (0,0) (0,1) (1,1)
+// TF: row tiles the instantiation is compiled for -- 2: up to 64 rows, tiles (0,0) (0,1) (1,1); 1: up to 32 rows (HERA-37-class
+// arrays), one tile: half the accumulators, a third of the planes
+template <int TF> constexpr int pb_plane() { return (TF == 1 ? 1 : 3) * 2 * 2 * 32 * 16; }   // bytes per plane: (tile, ks, h, row) x 8 f16
 // four waves per block and <= 168 registers: THREE blocks per CU (51 KB of LDS each) -- 12 % faster than one block of eight waves
 // at 172 registers (profiles/r05/pair_form.txt): with a third of the matrix work of the generic kernel a wave waits more often
 // for its own phasors, and only other waves fill those slots
 constexpr int PB_THREADS = 256;
-constexpr size_t PB_LDS = 8 * (size_t)PB_PLANE + 64 * 3 * sizeof(double) + 2 * 64 * sizeof(float);
+template <int TF> constexpr size_t pb_lds() { return 8 * (size_t)pb_plane<TF>() + 64 * 3 * sizeof(double) + 2 * 64 * sizeof(float); }
 
-template <bool CEN, bool FLAT>
+template <bool CEN, bool FLAT, int TF>
 __global__ void __launch_bounds__(PB_THREADS, 3)
 fringe_pair_bwd_kernel(PairBwdArgs A)
 {
+    constexpr int PB_PLANE = pb_plane<TF>();
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* g_img = smem;              // planes: 0 N1, 1 N3, 2 N2, 3 N4 (hi), 4..7 the same (lo)
     double* ant_lds = reinterpret_cast<double*>(smem + 8 * PB_PLANE);      // [64][3]
@@ -2090,7 +2093,7 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
         grad_of(j, 64 + i, br, bi);
         if (off) grad_of(i, 64 + j, br, bi);
     };
-    for (int e = tid; e < 3 * 2 * 2 * 32 * 4; e += PB_THREADS) {
+    for (int e = tid; e < (TF == 1 ? 1 : 3) * 2 * 2 * 32 * 4; e += PB_THREADS) {
         const int jp = e & 3, row = (e >> 2) & 31, h = (e >> 7) & 1, ks = (e >> 8) & 1, tile = e >> 9;
         const int ti = tile == 2 ? 1 : 0, tj = tile == 0 ? 0 : 1;
         const int i = 32 * ti + row;
@@ -2160,9 +2163,9 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
     for (int pt = tbeg + wave; pt < tend; pt += PB_THREADS / 64) {
         const int p = pt * 32 + (lane & 31);
         const double sx = sd[p], sy = sd[A.Pstride + p], sz = FLAT ? 0.0 : sd[2 * (size_t)A.Pstride + p];
-        f32x16 accR[2], accI[2];
+        f32x16 accR[TF], accI[TF];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < TF; ++q)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 if constexpr (CEN) {
@@ -2172,8 +2175,8 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
             }
         float part = 0.f;
 #pragma unroll
-        for (int tjr = 0; tjr < 2; ++tjr) {
-            const int tj = 1 - tjr;                          // descending: row tile tj completes here
+        for (int tjr = 0; tjr < TF; ++tjr) {
+            const int tj = TF - 1 - tjr;                          // descending: row tile tj completes here
             if (tj < TA) {
                 float ec[16], es[16];                        // E of antennas 32 tj + (e&3) + 8 (e>>2) + 4 h
 #pragma unroll
@@ -2209,7 +2212,7 @@ fringe_pair_bwd_kernel(PairBwdArgs A)
                         split2_plain(es[8 * ks + 2 * q], es[8 * ks + 2 * q + 1], eih[q], eil[q]);
                     }
 #pragma unroll
-                    for (int ti = 0; ti < 2; ++ti) {
+                    for (int ti = 0; ti < TF; ++ti) {
                         if (ti <= tj) {
                             const int tk = ((ti + tj) * 2 + ks) * 1024;
                             const uint4 N1h = *reinterpret_cast<const uint4*>(g_img + gl0 + 0 * PB_PLANE + tk);
@@ -2747,12 +2750,15 @@ extern "C" int rime_fringe_pair_bwd_block(const double* antpos, int Nrows, const
     A.S = (ntile + per - 1) / per;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((unsigned)Nt * A.S * Nf, 1, 1);
-    if (centre) {
-        if (flat) hipLaunchKernelGGL((fringe_pair_bwd_kernel<true, true>), grid, dim3(PB_THREADS), PB_LDS, st, A);
-        else hipLaunchKernelGGL((fringe_pair_bwd_kernel<true, false>), grid, dim3(PB_THREADS), PB_LDS, st, A);
+    if (Nrows <= 32 && !centre) {                        // one row tile
+        if (flat) hipLaunchKernelGGL((fringe_pair_bwd_kernel<false, true, 1>), grid, dim3(PB_THREADS), pb_lds<1>(), st, A);
+        else hipLaunchKernelGGL((fringe_pair_bwd_kernel<false, false, 1>), grid, dim3(PB_THREADS), pb_lds<1>(), st, A);
+    } else if (centre) {
+        if (flat) hipLaunchKernelGGL((fringe_pair_bwd_kernel<true, true, 2>), grid, dim3(PB_THREADS), pb_lds<2>(), st, A);
+        else hipLaunchKernelGGL((fringe_pair_bwd_kernel<true, false, 2>), grid, dim3(PB_THREADS), pb_lds<2>(), st, A);
     } else {
-        if (flat) hipLaunchKernelGGL((fringe_pair_bwd_kernel<false, true>), grid, dim3(PB_THREADS), PB_LDS, st, A);
-        else hipLaunchKernelGGL((fringe_pair_bwd_kernel<false, false>), grid, dim3(PB_THREADS), PB_LDS, st, A);
+        if (flat) hipLaunchKernelGGL((fringe_pair_bwd_kernel<false, true, 2>), grid, dim3(PB_THREADS), pb_lds<2>(), st, A);
+        else hipLaunchKernelGGL((fringe_pair_bwd_kernel<false, false, 2>), grid, dim3(PB_THREADS), pb_lds<2>(), st, A);
     }
     return check_launch();
 }
