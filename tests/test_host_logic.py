@@ -512,9 +512,9 @@ def _pair_form_emulated(P, seed):
     for ti, tj in tiles:
         for i in range(32 * ti, 32 * ti + 32):
             for j in range(32 * tj, 32 * tj + 32):
-                put(i, j, A[i, j]); put(64 + i, 64 + j, np.conj(A[i, j])); put(j, 64 + i, np.conj(B[i, j]))
+                put(i, j, A[i, j]); put(64 + i, 64 + j, np.conj(A[i, j])); put(i, 64 + j, np.conj(B[i, j]))     # V[i, j'] = conj B
                 if ti != tj:
-                    put(i, 64 + j, np.conj(B[i, j]))
+                    put(j, 64 + i, np.conj(B[i, j]))                                                       # V[j, i'] (B = B^T)
     if cen is not None:
         col = E @ w
         for r in range(64):
