@@ -85,11 +85,14 @@ __device__ __forceinline__ void split2_plain(float a, float b, uint32_t& hi, uin
 
 // Keeps a float a scalar computation of its own: the compiler's SLP pass pairs independent f32 adds / multiplies / FMAs into
 // v_pk_*_f32.  Round 5: in the conjugate-pair backward -- the first kernel here whose blocks SHARE a CU, so that one block stages its
-// G planes while another block's waves stream MFMAs on the same SIMDs -- the staging code's v_pk_add_f32 (sums of two freshly
-// loaded gradients) produced wrong planes in a fraction of the blocks that were dispatched late, different from run to run;
-// alone on the CU, or with scalar adds, the same code is exact (tools/debug_pair_bwd.py, profiles/r05/pair_form.txt).  With round
-// 2's stale packed reads of matrix-core results (rime_common.h) that makes two sightings of packed-f32 arithmetic going wrong
-// beside a busy matrix pipe; the pair kernels therefore contain NO packed f32 instruction (the build scans for them).
+// G planes while another block's waves stream MFMAs on the same SIMDs -- the build whose staging arithmetic the compiler had
+// vectorised (65 v_pk_add_f32: sums of two freshly loaded gradients) produced wrong planes in a fraction of the blocks that
+// were dispatched late, different from run to run; alone on the CU, or with scalar adds, the same code is exact
+// (tools/debug_pair_bwd.py, profiles/r05/pair_form.txt 3 and 8).  A hand-written v_pk_add_f32 in the same place, and the
+// compiler's add / subtract / select sequence verbatim in inline asm, are exact too: the mechanism is open.  With round 2's
+// stale packed reads of matrix-core results (rime_common.h) it is the second sighting of compiler-packed f32 arithmetic going
+// wrong beside a busy matrix pipe, so the pair kernels contain NO packed f32 instruction (the build scans for them): a fence
+// around an observed failure, not an explanation of it.
 __device__ __forceinline__ void keep_scalar(float& x) { asm("" : "+v"(x)); }
 
 // the split of two PRODUCTS (a0 b0, a1 b1) that are also read as f32 (p0, p1): the residuals a b - hi as one mixed-precision FMA
