@@ -2684,7 +2684,7 @@ extern "C" int rime_fringe_ant_bwd(const double* antpos, const double* sdir, con
 // ---- conjugate-pair form (fringe_pair_fwd_kernel / fringe_pair_bwd_kernel): one block of up to 64 rows -------------------
 static bool pair_common_ok(int Nrows, int Nbl, int Nt, int Nf, int Pstride, long long st_p, int sign)
 {
-    return Nrows > 0 && Nrows <= 64 && ant_common_ok(Nrows, 0, Nbl, Nt, Nf, Pstride, st_p, sign, 0) && st_p == 1;
+    return Nrows > 0 && Nrows <= 64 && ant_common_ok(Nrows, 0, Nbl, Nt, Nf, Pstride, st_p, sign, 0);     // st_p 1, or 2: one plane of a complex buffer
 }
 
 extern "C" int rime_fringe_pair_fwd_block(const double* antpos, int Nrows, const int* centre, int flat, const double* sdir,

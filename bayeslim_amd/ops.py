@@ -372,6 +372,7 @@ def _mirror_block(blk, P, dev):
 # contracted from the phasors of one antenna of every mirror pair.
 PAIR = _env_int('RIME_PAIR', 1) != 0            # RIME_PAIR=0: such blocks keep the mirror-pair kernels (A/B measurements)
 PAIR_ROWS = 64                                  # rows of the pair kernels (firsts + antennas without a partner)
+PAIR_CPLX = _env_int('RIME_PAIR_CPLX', 1) != 0  # complex psky on pair blocks, one pass per real plane (0: the plain blocks; A/B)
 
 
 def _pair_layout(P, rows=PAIR_ROWS, hub_ok=True):
@@ -483,7 +484,11 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
     others take one pass per real plane.  Returns the MFMA flops executed.
     """
     a = geom.ant
-    blocks = a['blocks'] if cplx else a.get('blocks_real', a['blocks'])
+    # real psky: mirror / pair forms where the array has them; complex psky: the plain blocks (single-pass forms where a
+    # block's baselines allow), except where a block has the conjugate-pair form -- V is linear in psky, so that block takes
+    # one pair pass per real plane (2 x 26 MFMAs per K step against 120 of the one-pass self block of 128 antennas)
+    blocks = a.get('blocks_cplx', a['blocks']) if cplx else a.get('blocks_real', a['blocks'])
+    tp_mask = a.get('two_pass_mask_cplx', a['two_pass_mask']) if cplx else a['two_pass_mask']
     m = 2 if cplx else 1                                     # floats per psky element
     st_t, st_mp, st_pp, st_f = (int(strides[k]) * m for k in range(4))
     Nbl, Nt, Nf, Nmp = geom.Nbl, geom.Nt, geom.Nf, geom.Nmp
@@ -534,7 +539,7 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
                                                    *shape, cflag, _ptr(ws), ws.numel(), _stream())
                 check(rc, 'rime_fringe_ant_fwd_block')
                 return blk['mf_self']
-            if blk.get('pair'):                              # conjugate-pair form (real psky only: `blocks_real`)
+            if blk.get('pair'):                              # conjugate-pair form: one real plane per call (c picks it)
                 rc = lib.rime_fringe_pair_fwd_block(_ptr(blk['pos']), blk['nrows'], _ptr(blk['centre']), blk['flat'], *geo, src,
                                                     _ptr(scale[mp, pp]), _ptr(rowmin[c][mp, pp]),
                                                     _ptr(blk['direct']), _ptr(blk['conj']),
@@ -560,7 +565,7 @@ def _fringe_ant_call(geom, backward, inp, out, strides, Npp, cplx):
                 check(lib.rime_fringe_ant_fwd_finish(_ptr(ws), ws.numel(), _ptr(tmp), Nbl, Nt, Nf, geom.Pstride,
                                                      _stream()), 'rime_fringe_ant_fwd_finish')
                 if len(two_pass) < len(blocks):
-                    tmp *= a['two_pass_mask']                # slots of single-pass blocks hold stale values
+                    tmp *= tp_mask                           # slots of single-pass blocks hold stale values
                 out[pp][..., 0] -= tmp[..., 1]
                 out[pp][..., 1] += tmp[..., 0]
     else:
@@ -709,6 +714,16 @@ def _setup_antenna_path(self, antpos, bl_ants, force=False, bl_mp=None, mp_pairs
                                          for m, q in zip(mb, pb) if m is not None and q is None]
             self.ant['pair_blocks'] = [(sum(1 for x in q['partner'] if x >= 0), q['nrows'], int(q['hub'] is not None))
                                        for q in pb if q is not None]
+            if PAIR_CPLX and any(q is not None for q in pb):
+                # complex psky: pair blocks (two real passes: fwd_cpass = cpass = 0) in place of their plain blocks
+                self.ant['blocks_cplx'] = [q if q is not None else b for q, b in zip(pb, blocks)]
+                mask = torch.zeros_like(two_pass_mask)
+                for b in self.ant['blocks_cplx']:
+                    if b['fwd_cpass'] == 0:
+                        tabs = [b['direct'], b['conj']] + ([b['centre']] if b.get('centre') is not None else [])
+                        slots = torch.cat([t[t >= 0] for t in tabs]).to(torch.int64)
+                        mask[slots] = 1.0
+                self.ant['two_pass_mask_cplx'] = mask
             self.ant['mfma_fwd'] = sum(b['mf_fwd'] for b in self.ant['blocks_real'])
             self.ant['mfma_bwd'] = sum(b['mf_bwd_real'] for b in self.ant['blocks_real'])
             self.ant['mfma_flops_fwd'], self.ant['mfma_flops_bwd'] = per16 * self.ant['mfma_fwd'], per16 * self.ant['mfma_bwd']

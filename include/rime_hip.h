@@ -209,7 +209,8 @@ int rime_fringe_ant_bwd_block(const double* antpos, int Nrows, int cross, int mi
  *       (virtual row r -> hub), or -1.
  *   flat: nonzero = every antpos z is zero (a coplanar array measured from a centre in its plane): the kernels do not evaluate that
  *       term of the phase.  A licence stated by the caller; 0 is always correct.
- *   st_p must be 1; the other arguments, the workspace and _finish / _prepare are those of rime_fringe_ant_fwd_block /
+ *   psky / gpsky is ONE real plane (st_p = 1, or 2 for a plane of an interleaved complex buffer: V is linear in psky, a complex
+ *   psky takes one call per plane as on every diagonal block); the other arguments, the workspace and _finish / _prepare are those of rime_fringe_ant_fwd_block /
  *   rime_fringe_ant_bwd_block, and pair blocks mix with other blocks of the same launch sequence. */
 int rime_fringe_pair_fwd_block(const double* antpos, int Nrows, const int* centre, int flat, const double* sdir,
                                const double* freqs, const float* psky, const float* scale, const float* rowmin,

@@ -75,9 +75,9 @@ def test_bad_arguments_are_rejected_without_launching():
     assert lib.rime_fringe_ant_fwd_block(one, 40, 0, 8, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, one, big, None) == -1
     assert lib.rime_fringe_ant_fwd_block(one, 40, 0, -1, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, one, big, None) == -1
     assert lib.rime_fringe_ant_bwd_block(one, 128, 0, 256, one, one, one, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, 0, one, one, big, None) == -1
-    # round 5: conjugate-pair blocks -- at most 64 rows, unit pixel stride, a workspace
+    # round 5: conjugate-pair blocks -- at most 64 rows, a pixel stride of 1 or 2, a workspace
     assert lib.rime_fringe_pair_fwd_block(one, 65, None, 0, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 1, 1, one, big, None) == -1
-    assert lib.rime_fringe_pair_fwd_block(one, 64, None, 1, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 2, 1, one, big, None) == -1
+    assert lib.rime_fringe_pair_fwd_block(one, 64, None, 1, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 3, 1, one, big, None) == -1
     assert lib.rime_fringe_pair_fwd_block(one, 64, None, 1, one, one, one, one, None, None, one, 1, 1, 1, 64, 64, 64, 1, 1, one, big, None) == -1
     assert lib.rime_fringe_pair_fwd_block(one, 64, None, 1, one, one, one, one, None, one, one, 1, 1, 1, 64, 64, 64, 1, 1, one, 4, None) == -2
     assert lib.rime_fringe_pair_bwd_block(one, 0, None, 0, one, one, one, one, one, 1, 1, 1, 64, 64, 64, 1, 1, 0, one, one, big, None) == -1

@@ -463,6 +463,42 @@ def test_fringe_sum_conjugate_pairs(ops, kind, pairs_rows_hub, conj, full, monke
     assert relmax(res[True], res[False].cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize('kind,pairs_rows_hub', [('hex37', (18, 19, 0)), ('hex91', (45, 46, 0)), ('hex127+1', (63, 64, 1)), ('rand100', (45, 55, 0))])
+@pytest.mark.parametrize('conj', [False, True])
+def test_fringe_sum_conjugate_pairs_complex_psky(ops, kind, pairs_rows_hub, conj, monkeypatch):
+    """a COMPLEX psky (Jones layouts) on a point-symmetric array: V is linear in psky, so a block with the conjugate-pair form
+    takes one pair pass per real plane (forward: the second plane's visibilities enter as i V; backward: the imaginary plane's
+    gradient from -i g) in place of the one-pass self block -- against the float64 oracle, both fringe signs, mixed pair
+    orientations (the plain blocks would need two passes as well), and equal to 2e-6 to the plain blocks (RIME_PAIR_CPLX=0)"""
+    rng = np.random.default_rng(abs(hash(kind)) % 1000 + 11)
+    ant = _symmetric_array(kind, rng)
+    Nant, Nt, Nf, P = len(ant), 2, 4, 500
+    hub = int(np.argmin(np.abs(ant - ant.mean(0)).sum(1))) if kind.startswith('hex127+1') else -1
+    pairs = [(i, j) if rng.random() < 0.5 else (j, i) for i in range(Nant) for j in range(i + 1, Nant) if rng.random() < 0.9]
+    pairs += [(a, a) for a in range(Nant) if a % 30 == 2 and a != hub]
+    pairs = [pairs[k] for k in rng.permutation(len(pairs))]
+    blvecs = T64(np.stack([ant[b] - ant[a] for a, b in pairs]))
+    freqs = T64(np.linspace(120e6, 180e6, Nf))
+    zenaz = T64(np.stack([np.rad2deg(np.arccos(rng.uniform(0, 1, (Nt, P)))), rng.uniform(0, 360, (Nt, P))], axis=1))
+    shape = (Nt, 1, 2, Nf, P)                                   # two polarisation products
+    psky = torch.as_tensor(rng.normal(size=shape) * np.exp(-9.0 * rng.uniform(size=shape))
+                           + 1j * rng.normal(size=shape) * np.exp(-9.0 * rng.uniform(size=shape)))
+    Ps = ops.pad_to_tile(P)
+    sdir = torch.zeros(Nt, 3, Ps, dtype=torch.float64)
+    for t in range(Nt):
+        sdir[t, :, :P] = orc.pointing_vectors(zenaz[t, 0], zenaz[t, 1])
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, 'PAIR_CPLX', on)
+        geom = ops.FringeGeometry(blvecs.cuda(), sdir.cuda(), freqs, conj=conj, antpos=T64(ant).cuda(), bl_ants=pairs, mfma=True)
+        assert geom.ant['pair_blocks'] == [pairs_rows_hub] and ('blocks_cplx' in geom.ant) == on
+        if on:
+            assert geom.ant['blocks_cplx'][0]['pair'] == 1 and float(geom.ant['two_pass_mask_cplx'].sum()) == len(pairs)
+        res[on] = _check_ant_path(ops, geom, psky, blvecs, zenaz, freqs, [0] * len(pairs), P, Ps, True, conj=conj).detach()
+    assert not torch.equal(res[True], res[False])
+    assert relmax(res[True], res[False].cpu().numpy()) < 2e-6
+
+
 @pytest.mark.parametrize('hub', [True, False])
 def test_conjugate_pair_kernels_at_the_headline_size_are_repeatable(ops, hub, monkeypatch):
     """the conjugate-pair kernels are the first here whose blocks share a CU (three per CU): at the headline size -- 98 304

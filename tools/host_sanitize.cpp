@@ -46,9 +46,9 @@ int main()
     bad += rime_fringe_ant_fwd_block(d.data(), 40, 0, 8, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
     bad += rime_fringe_ant_fwd_block(d.data(), 40, 0, -1, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
     bad += rime_fringe_ant_bwd_block(d.data(), 128, 0, 256, d.data(), d.data(), f.data(), tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, 0, f.data(), f.data(), 1 << 20, nullptr) != RIME_EINVAL;
-    // conjugate-pair blocks (round 5): more than 64 rows, a pixel stride other than 1, missing tables -> RIME_EINVAL; no workspace
+    // conjugate-pair blocks (round 5): more than 64 rows, a pixel stride other than 1 or 2, missing tables -> RIME_EINVAL; no workspace
     bad += rime_fringe_pair_fwd_block(d.data(), 65, nullptr, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
-    bad += rime_fringe_pair_fwd_block(d.data(), 64, nullptr, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 2, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
+    bad += rime_fringe_pair_fwd_block(d.data(), 64, nullptr, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 3, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
     bad += rime_fringe_pair_fwd_block(d.data(), 64, nullptr, 0, d.data(), d.data(), f.data(), f.data(), nullptr, nullptr, tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, f.data(), 1 << 20, nullptr) != RIME_EINVAL;
     bad += rime_fringe_pair_fwd_block(d.data(), 64, nullptr, 0, d.data(), d.data(), f.data(), f.data(), nullptr, tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, f.data(), 4, nullptr) != RIME_EWORKSPACE;
     bad += rime_fringe_pair_bwd_block(d.data(), 0, nullptr, 0, d.data(), d.data(), f.data(), tab.data(), tab.data(), 1, 1, 1, 64, 64, 64, 1, 1, 0, f.data(), f.data(), 1 << 20, nullptr) != RIME_EINVAL;
