@@ -673,7 +673,10 @@ OTHER_WORKLOADS = (('c3', [], None), ('c2', ['--steps', '20', '--warmup', '5'], 
                    # kernels: conjugate rows copied, all 128 rows contracted) and with the symmetry search switched off = what an
                    # array WITHOUT point symmetry of this size costs (every phasor evaluated, every row contracted)
                    ('c4', ['--steps', '5', '--warmup', '3'], {'RIME_MIRROR': '0'}),
-                   ('c4', ['--steps', '5', '--warmup', '3'], {'RIME_PAIR': '0'}))
+                   ('c4', ['--steps', '5', '--warmup', '3'], {'RIME_PAIR': '0'}),
+                   # one rank's share of the headline workload under the channel partition at N = 8 (32 of the 256 channels), as a
+                   # plain one-GPU run: what the scaling at 8 GPUs starts from before any collective
+                   ('c4', ['--nf', '32', '--steps', '20', '--warmup', '5'], None))
 
 
 def other_workloads(budget_s, timeout_each=150.0, script=None):
@@ -690,6 +693,8 @@ def other_workloads(budget_s, timeout_each=150.0, script=None):
     for wl, extra, env in OTHER_WORKLOADS:
         left = budget_s - (time.perf_counter() - t0)
         tag = wl if env is None else wl + ' [' + ' '.join('%s=%s' % kv for kv in sorted(env.items())) + ']'
+        if extra and '--nf' in extra:
+            tag += ' [--nf %s]' % extra[extra.index('--nf') + 1]
         if left < 20.0:
             out.append(dict(workload=tag, skipped='time budget of the default run used up'))
             continue

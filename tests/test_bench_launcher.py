@@ -119,16 +119,16 @@ def test_other_workloads_are_child_runs_that_cannot_lose_the_line(tmp_path):
         """)
     res = bench.other_workloads(60.0, script=stub)
     by = {r['workload']: r for r in res}
-    assert set(by) == {'c3', 'c2', 'c5', 'c4 [RIME_MIRROR=0]', 'c4 [RIME_PAIR=0]'}
+    assert set(by) == {'c3', 'c2', 'c5 [--nf 64]', 'c4 [RIME_MIRROR=0]', 'c4 [RIME_PAIR=0]', 'c4 [--nf 32]'}
     assert by['c3']['ms_per_step'] == 23.0 and by['c3']['kernels']['fwd'] == dict(kernel='fringe_ant_fwd_kernel', frac=0.4,
                                                                                 useful_frac_of_pipe_peak=0.1, ms_per_step=10.0)
     assert by['c3']['kernels']['bwd']['ms_per_step'] == 12.0 and by['c3']['mirror_groups'] == [[7, 8]]
-    assert by['c2'] == dict(workload='c2', failed=3) and by['c5'] == dict(workload='c5', failed=0)
+    assert by['c2'] == dict(workload='c2', failed=3) and by['c5 [--nf 64]'] == dict(workload='c5 [--nf 64]', failed=0)
     assert by['c4 [RIME_MIRROR=0]']['mirror_groups'] is None            # the switch reached the child
     assert by['c3']['pair_blocks'] == [[63, 64, 1]] and by['c4 [RIME_PAIR=0]']['pair_blocks'] is None
     assert by['c4 [RIME_PAIR=0]']['mirror_groups'] == [[7, 8]]
     res = bench.other_workloads(5.0, script=stub)                     # no budget: nothing is started
-    assert all('skipped' in r for r in res) and len(res) == 5
+    assert all('skipped' in r for r in res) and len(res) == 6
 
 
 def test_rank_process_refuses_a_world_size_other_than_gpus():
