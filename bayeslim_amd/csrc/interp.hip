@@ -533,7 +533,9 @@ sky_grad_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const in
 #pragma unroll
     for (int k16 = 0; k16 < 16; ++k16) acc[k16] = T(0);
     if constexpr (NNN == 4) {
-        if ((R & 3) == 0 && r0 + 64 <= R) {            // uniform: every lane's 4 channels are one vector load
+        if ((R & 3) == 0) {                            // uniform: every lane's 4 channels are one vector load (round 5: tiles that
+                                                       // reach past the last channel too -- their lanes beyond R are masked; a rank's
+                                                       // share of 32 channels at N = 8 took the slow path below)
             // Software pipeline over the time steps: the chain pos -> stencil -> beam nodes of step t+1 is walked while step
             // t is contracted.  The stencils of the tile's 64 pixels (256 indices + 256 weights: one of each per thread) go
             // through LDS, double buffered: thread (pixel pl, node k) loads its entry for step t+1 during step t (from the
@@ -549,7 +551,8 @@ sky_grad_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const in
             __shared__ int sten_q[2][64];
             const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
             const int qs = lane >> 4, rq = lane & 15;
-            const int r = r0 + 4 * rq;
+            const int r = min(r0 + 4 * rq, R - 4);               // (clamped: lanes past the last channel read row R - 4 and store zeros)
+            const bool rin = r0 + 4 * rq < R;
             const int pl = threadIdx.x >> 2, pk = threadIdx.x & 3, jp = j0 + pl;
             auto q_of = [&](int t) {
                 const int pp = (t < Nt && jp < Npix) ? pos[(size_t)t * Npix + jp] : -1;
@@ -577,13 +580,13 @@ sky_grad_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const in
                 if (any) {
 #pragma unroll
                     for (int k16 = 0; k16 < 16; ++k16)
-                        g[k16] = q >= 0 ? gps[(size_t)(r0 + ly + 4 * k16) * Q + q] : T(0);
+                        g[k16] = (q >= 0 && r0 + ly + 4 * k16 < R) ? gps[(size_t)(r0 + ly + 4 * k16) * Q + q] : T(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int ql = 16 * w + 4 * u + qs;
                         const int4 id = *reinterpret_cast<const int4*>(&sten_i[cur][ql][0]);
                         const vec4<T> wk = *reinterpret_cast<const vec4<T>*>(&sten_w[cur][ql][0]);
-                        const bool ok = sten_q[cur][ql] >= 0;
+                        const bool ok = sten_q[cur][ql] >= 0 && rin;
                         const vec4<T> v0 = *reinterpret_cast<const vec4<T>*>(bmapT + (size_t)id.x * R + r);
                         const vec4<T> v1 = *reinterpret_cast<const vec4<T>*>(bmapT + (size_t)id.y * R + r);
                         const vec4<T> v2 = *reinterpret_cast<const vec4<T>*>(bmapT + (size_t)id.z * R + r);
@@ -608,7 +611,8 @@ sky_grad_kernel(const T* __restrict__ gps, const T* __restrict__ bmapT, const in
             }
             if (j < Npix) {
 #pragma unroll
-                for (int k16 = 0; k16 < 16; ++k16) gsky[(size_t)(r0 + ly + 4 * k16) * Npix + j] = acc[k16];
+                for (int k16 = 0; k16 < 16; ++k16)
+                    if (r0 + ly + 4 * k16 < R) gsky[(size_t)(r0 + ly + 4 * k16) * Npix + j] = acc[k16];
             }
             return;
         }

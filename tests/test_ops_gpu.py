@@ -1068,11 +1068,11 @@ def test_beam_sky_product(ops, dtype, Nnn):
     assert float(out.detach().reshape(R, Nt, Ps)[:, 0, 150:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('Nt,R', [(1, 64), (2, 128), (5, 192), (9, 68)])
+@pytest.mark.parametrize('Nt,R', [(1, 64), (2, 128), (5, 192), (9, 68), (3, 32), (4, 8), (2, 100)])
 def test_beam_sky_product_time_pipeline_edges(ops, Nt, R):
     """the sky gradient's software pipeline over the time steps (stencils of step t+1 staged through LDS while step t is
     contracted, positions two steps ahead) at its edges: a single step, two steps, an odd count, whole 64-channel tiles and
-    a partial one, sky pixels never visible / visible at every step, a time step with NO visible pixel in whole tiles"""
+    partial ones (round 5: masked lanes on the pipelined path -- 68 = 64 + 4, 100, and fewer than one tile: 32, 8 channels), sky pixels never visible / visible at every step, a time step with NO visible pixel in whole tiles"""
     rng = np.random.default_rng(100 * Nt + R)
     Npb, Npix, Ps, Nnn = 257, 700, 256, 4
     cut = np.full((Nt, Ps), Npix, dtype=np.int64)
