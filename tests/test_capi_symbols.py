@@ -92,6 +92,26 @@ def test_bad_arguments_are_rejected_without_launching():
     assert lib.rime_fringe_sum_workspace(0, 3, 2, 33, 9024, 1, 1, 0, 0) > 0
 
 
+def test_build_scan_refuses_packed_f32_in_the_pair_kernels(tmp_path):
+    """round 5: kernels whose blocks share a CU (the conjugate-pair kernels) must hold no v_pk_{add,mul,fma}_f32 at all
+    (csrc/fringe_mfma.hip, keep_scalar); tools/scan_packed_readers.py --no-packed=... is what the Makefile runs -- here on two
+    synthetic listings, and the record of the shipped build names the kernels it covered"""
+    import subprocess, sys
+    tool = os.path.join(ROOT, 'tools', 'scan_packed_readers.py')
+    body = '_ZN4rime22fringe_pair_fwd_kernelILb1EEEvv:\n\tv_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]\n\ts_nop 15\n\ts_nop 15\n\t%s\n\ts_endpgm\n.Lfunc_end0:\n'
+    bad, good = tmp_path / 'bad.s', tmp_path / 'good.s'
+    bad.write_text(body % 'v_pk_add_f32 v[40:41], v[42:43], v[44:45]')
+    good.write_text(body % 'v_add_f32_e32 v40, v42, v44')
+    r = subprocess.run([sys.executable, tool, str(bad), '24', '--fail', '--no-packed=fringe_pair_'], capture_output=True, text=True)
+    assert r.returncode == 1 and 'packed f32 instructions in a kernel that must have none' in r.stdout
+    r = subprocess.run([sys.executable, tool, str(good), '24', '--fail', '--no-packed=fringe_pair_'], capture_output=True, text=True)
+    assert r.returncode == 0 and 'no packed f32 instruction in the 1 kernels' in r.stdout
+    r = subprocess.run([sys.executable, tool, str(bad), '24', '--fail'], capture_output=True, text=True)      # the old rule alone: far from the MFMA
+    assert r.returncode == 0
+    rec = open(os.path.join(ROOT, 'bayeslim_amd', 'lib', 'obj', 'fringe_mfma.scan')).read()
+    assert 'no packed f32 instruction in the 18 kernels named *fringe_pair_*' in rec, rec
+
+
 @pytest.mark.parametrize('src', ['alm', 'fringe_mfma'])
 def test_no_packed_f32_reader_close_to_an_mfma(src):
     """regression guard for the round-2 defect (rime_common.h, RIME_MFMA_SETTLE): the Makefile scans the gfx950 assembly
