@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import test_rime_gpu as tr              # noqa: E402  (the fixtures' model builders)
 
 torch.set_default_dtype(torch.float32)
-for tag in ['hex37', 'rand70', 'rand128', 'rand150']:
+for tag in ['hex37', 'rand70', 'rand128', 'rand150', 'hex128']:     # hex37 and hex128: the conjugate-pair kernels
     g = tr.load_golden('rime_%s_mini' % tag)
     rime, sky, beam = tr._c2_setup(None, g)
     v = rime().data.detach().cpu().numpy().astype(np.complex128)
