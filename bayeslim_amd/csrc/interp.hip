@@ -140,7 +140,9 @@ interp_scatter_kernel(const T* __restrict__ goutT, const int* __restrict__ csr_p
     for (int rb = by * 64; rb < RN; rb += gridDim.y * 64) {
         const int r = rb + 4 * rq;
         T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
-        if (vec_rows && rb + 64 <= RN) {                // uniform
+        if (vec_rows) {                                 // uniform (round 5: partial tiles too -- a rank's 32 channels at N = 8 --
+                                                        // whose lanes beyond RN read the last valid vector and never store)
+            const int rr = min(r, RN - 4);
             // a node's list is a chain entry -> source index -> (weight, row of the source point): the indices of the NEXT
             // four entries of the lane's slot are fetched while the rows of these four are in flight (the list is walked in
             // the same order as by the plain loop below: same sums)
@@ -159,7 +161,7 @@ interp_scatter_kernel(const T* __restrict__ goutT, const int* __restrict__ csr_p
                 for (int u = 0; u < U; ++u) {
                     const int src = sc[u] >= 0 ? sc[u] : 0;
                     w[u] = sc[u] >= 0 ? wgts[src] : T(0);
-                    v[u] = *reinterpret_cast<const svec4<T>*>(goutT + (size_t)(pow2 ? src >> sh : src / Nnn) * RN + r);
+                    v[u] = *reinterpret_cast<const svec4<T>*>(goutT + (size_t)(pow2 ? src >> sh : src / Nnn) * RN + rr);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
